@@ -1,0 +1,79 @@
+"""ctypes binding of libfpv_env.so — exactly the symbols include/fpv_env.h declares.
+
+The library is the product's only compute path: if it is missing or fails to load this
+module raises; there is no CPU or PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .build import LIB_PATH, build_extension
+
+FPV_F32, FPV_F64 = 0, 1
+STATE_WORDS, OBS_WORDS, ACT_WORDS = 36, 20, 4
+INFO_TERMINATED, INFO_TRUNCATED, INFO_OUT_OF_BOUNDS, INFO_ON_FLOOR = 1, 2, 4, 8
+
+
+class FpvConfig(C.Structure):
+    _fields_ = [
+        ("num_envs", C.c_int64), ("device", C.c_int32), ("precision", C.c_int32),
+        ("floor_check", C.c_int32), ("reserved0", C.c_int32), ("noise_ratio", C.c_double),
+        ("seed", C.c_uint64), ("id_offset", C.c_uint64), ("ledger_capacity", C.c_int64),
+    ]
+
+
+class FpvLedger(C.Structure):
+    _fields_ = [
+        ("capacity", C.c_int64), ("count", C.c_void_p), ("idx", C.c_void_p), ("info", C.c_void_p),
+        ("tag", C.c_void_p), ("ep_return", C.c_void_p), ("obs", C.c_void_p),
+    ]
+
+
+# every symbol of include/fpv_env.h: name -> (restype, argtypes)
+_vp, _i64, _i32, _f32, _u64 = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_uint64
+SIGNATURES = {
+    "fpv_create": (C.c_int, [C.POINTER(FpvConfig), C.POINTER(_vp)]),
+    "fpv_destroy": (C.c_int, [_vp]),
+    "fpv_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "fpv_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fpv_step_f64": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fpv_get_state": (C.c_int, [_vp, _vp, _vp]),
+    "fpv_set_state": (C.c_int, [_vp, _vp, _vp]),
+    "fpv_set_tick": (C.c_int, [_vp, _u64, _vp]),
+    "fpv_get_tick": (C.c_int, [_vp, C.POINTER(_u64), _vp]),
+    "fpv_ledger_view": (C.c_int, [_vp, C.POINTER(FpvLedger)]),
+    "fpv_ledger_clear": (C.c_int, [_vp, _vp]),
+    "fpv_ledger_bind": (C.c_int, [_vp, C.POINTER(FpvLedger)]),
+    "fpv_gae": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "fpv_normalize": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _i32, _f32, _f32, _vp]),
+    "fpv_normalize_reward": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _vp]),
+    "fpv_last_error": (C.c_char_p, []),
+    "fpv_version": (C.c_int, []),
+}
+
+_lib = None
+
+
+def load(build_if_missing: bool = True):
+    """Load libfpv_env.so (building it in-tree with hipcc when absent).  Raises on failure."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if not build_if_missing:
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with fpv_drone_rl_agent_amd.build.build_extension()")
+        build_extension()
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and the header drift apart
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "fpv call") -> None:
+    if rc != 0:
+        msg = load().fpv_last_error().decode("utf-8", "replace")
+        exc = ValueError if rc == -1 else RuntimeError
+        raise exc(f"{what} failed ({rc}): {msg}")

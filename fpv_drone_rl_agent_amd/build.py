@@ -1,0 +1,47 @@
+"""In-tree build of the HIP extension (libfpv_env.so) for gfx950 with hipcc.
+
+The shared library sits next to this file so that it travels with a snapshot of the repo;
+nothing is installed into site-packages or a JIT cache.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libfpv_env.so")
+SOURCES = ["fpv_step.hip", "fpv_rollout.hip", "fpv_policy.hip", "fpv_capi.hip"]
+HEADERS = ["fpv_dynamics.h", "fpv_internal.h", os.path.join("..", "..", "include", "fpv_env.h")]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the MI355X extension cannot be built")
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    files = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    return any(os.path.exists(f) and os.path.getmtime(f) > t for f in files)
+
+
+def build_extension(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/*.hip into libfpv_env.so for gfx950.  Returns the library path."""
+    if not force and not _stale():
+        return LIB_PATH
+    srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_extension(force=True, verbose=True))

@@ -1,0 +1,269 @@
+// fpv_capi.hip — host side of the C ABI declared in include/fpv_env.h.
+// Owns device allocations for the persistent drone state, the reset template, the done
+// ledger and the tick; launches the kernels of fpv_step.hip / fpv_rollout.hip on the
+// caller's stream.  No allocation and no host synchronisation inside fpv_step.
+#include "../../include/fpv_env.h"
+#include "fpv_dynamics.h"
+#include "fpv_internal.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+using namespace fpv;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define FPV_HIP(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(FPV_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));        \
+    } while (0)
+
+struct fpv_env {
+    fpv_config cfg;
+    int64_t tiles;
+    size_t word;         // sizeof(real)
+    void* state;         // [tiles][9][64] granules
+    void* tmpl;          // 56 reals
+    uint64_t* tick;      // device
+    uint32_t* led_count;
+    int32_t* led_idx;
+    uint32_t* led_info;
+    uint32_t* led_tag;
+    void* led_ret;
+    void* led_obs;
+    int64_t led_cap;
+    bool led_owned;
+};
+
+// per-device reduction scratch for the handle-less rollout primitives
+static std::mutex g_scratch_mu;
+static double* g_scratch[64] = {};
+static int scratch_for_current_device(double** out) {
+    int dev = 0;
+    FPV_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(FPV_ERR_ARG, "device ordinal %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch[dev]) FPV_HIP(hipMalloc(&g_scratch[dev], sizeof(double) * kScratchDoubles));
+    *out = g_scratch[dev];
+    return FPV_OK;
+}
+
+template <typename T>
+static int step_impl(fpv_env* e, const T* actions, T* obs, T* reward, uint8_t* term, uint8_t* trunc, void* stream) {
+    if (!e) return fail(FPV_ERR_ARG, "fpv_step: null handle");
+    if (!actions || !obs || !reward || !term || !trunc) return fail(FPV_ERR_ARG, "fpv_step: null buffer");
+    if ((e->cfg.precision == FPV_F64) != (sizeof(T) == 8))
+        return fail(FPV_ERR_ARG, "fpv_step: handle precision does not match this entry point");
+    if (((uintptr_t)actions | (uintptr_t)obs) & (sizeof(T) * 4 - 1))
+        return fail(FPV_ERR_ARG, "fpv_step: actions/obs must be %zu-byte aligned", sizeof(T) * 4);
+    StepArgs<T> a;
+    a.state = (Vec4<T>*)e->state;
+    a.actions = actions; a.obs = obs; a.reward = reward; a.terminated = term; a.truncated = trunc;
+    a.tick = e->tick;
+    a.tmpl = (const T*)e->tmpl;
+    a.led_count = e->led_count; a.led_idx = e->led_idx; a.led_info = e->led_info; a.led_tag = e->led_tag;
+    a.led_ret = (T*)e->led_ret; a.led_obs = (T*)e->led_obs; a.led_cap = e->led_cap;
+    a.n = e->cfg.num_envs;
+    a.seed = e->cfg.seed;
+    a.id_offset = e->cfg.id_offset;
+    a.sigma = (T)e->cfg.noise_ratio;
+    a.floor_check = e->cfg.floor_check;
+    FPV_HIP(launch_step<T>(a, e->cfg.noise_ratio != 0.0, (hipStream_t)stream));
+    return FPV_OK;
+}
+
+extern "C" {
+
+const char* fpv_last_error(void) { return g_err; }
+int fpv_version(void) { return 1; }
+
+int fpv_create(const fpv_config* cfg, fpv_env** out) {
+    if (!cfg || !out) return fail(FPV_ERR_ARG, "fpv_create: null argument");
+    if (cfg->num_envs <= 0) return fail(FPV_ERR_ARG, "fpv_create: num_envs must be positive");
+    if (cfg->num_envs > (int64_t)1 << 31) return fail(FPV_ERR_ARG, "fpv_create: num_envs too large");
+    if (cfg->precision != FPV_F32 && cfg->precision != FPV_F64)
+        return fail(FPV_ERR_ARG, "fpv_create: unknown precision %d", cfg->precision);
+    if (cfg->noise_ratio < 0.0) return fail(FPV_ERR_ARG, "fpv_create: negative noise_ratio");
+    int ndev = 0;
+    FPV_HIP(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(FPV_ERR_ARG, "fpv_create: device %d not present (%d visible)", cfg->device, ndev);
+    FPV_HIP(hipSetDevice(cfg->device));
+    fpv_env* e = new (std::nothrow) fpv_env();
+    if (!e) return fail(FPV_ERR_ALLOC, "fpv_create: host allocation failed");
+    e->cfg = *cfg;
+    e->tiles = (cfg->num_envs + kTile - 1) / kTile;
+    e->word = cfg->precision == FPV_F64 ? sizeof(double) : sizeof(float);
+    e->led_cap = cfg->ledger_capacity > 0 ? cfg->ledger_capacity : 2 * cfg->num_envs;
+    e->led_owned = true;
+    hipError_t err = hipSuccess;
+    auto alloc = [&](void** p, size_t bytes) {
+        if (err == hipSuccess) err = hipMalloc(p, bytes);
+    };
+    alloc(&e->state, (size_t)e->tiles * kGranules * kTile * 4 * e->word);
+    alloc(&e->tmpl, (size_t)(kStateWords + kObsWords) * e->word);
+    alloc((void**)&e->tick, sizeof(uint64_t));
+    alloc((void**)&e->led_count, sizeof(uint32_t));
+    alloc((void**)&e->led_idx, (size_t)e->led_cap * sizeof(int32_t));
+    alloc((void**)&e->led_info, (size_t)e->led_cap * sizeof(uint32_t));
+    alloc((void**)&e->led_tag, (size_t)e->led_cap * sizeof(uint32_t));
+    alloc(&e->led_ret, (size_t)e->led_cap * e->word);
+    alloc(&e->led_obs, (size_t)e->led_cap * kObsWords * e->word);
+    if (err == hipSuccess) err = hipMemset(e->tick, 0, sizeof(uint64_t));
+    if (err == hipSuccess) err = hipMemset(e->led_count, 0, sizeof(uint32_t));
+    if (err == hipSuccess)
+        err = cfg->precision == FPV_F64 ? launch_init<double>(e->state, e->tmpl, cfg->num_envs, nullptr)
+                                        : launch_init<float>(e->state, e->tmpl, cfg->num_envs, nullptr);
+    if (err == hipSuccess) err = hipDeviceSynchronize();
+    if (err != hipSuccess) {
+        fpv_destroy(e);
+        return fail(FPV_ERR_HIP, "fpv_create: %s", hipGetErrorString(err));
+    }
+    *out = e;
+    return FPV_OK;
+}
+
+int fpv_destroy(fpv_env* e) {
+    if (!e) return FPV_OK;
+    void* own[] = {e->state, e->tmpl, e->tick};
+    for (void* p : own)
+        if (p) (void)hipFree(p);
+    if (e->led_owned) {
+        void* led[] = {e->led_count, e->led_idx, e->led_info, e->led_tag, e->led_ret, e->led_obs};
+        for (void* p : led)
+            if (p) (void)hipFree(p);
+    }
+    delete e;
+    return FPV_OK;
+}
+
+int fpv_reset(fpv_env* e, const uint8_t* mask, void* obs, void* stream) {
+    if (!e) return fail(FPV_ERR_ARG, "fpv_reset: null handle");
+    hipStream_t s = (hipStream_t)stream;
+    FPV_HIP(e->cfg.precision == FPV_F64 ? launch_reset<double>(e->state, e->tmpl, mask, obs, e->cfg.num_envs, s)
+                                        : launch_reset<float>(e->state, e->tmpl, mask, obs, e->cfg.num_envs, s));
+    return FPV_OK;
+}
+
+int fpv_step(fpv_env* e, const float* actions, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated,
+             void* stream) {
+    return step_impl<float>(e, actions, obs, reward, terminated, truncated, stream);
+}
+
+int fpv_step_f64(fpv_env* e, const double* actions, double* obs, double* reward, uint8_t* terminated,
+                 uint8_t* truncated, void* stream) {
+    return step_impl<double>(e, actions, obs, reward, terminated, truncated, stream);
+}
+
+int fpv_get_state(fpv_env* e, void* state_out, void* stream) {
+    if (!e || !state_out) return fail(FPV_ERR_ARG, "fpv_get_state: null argument");
+    FPV_HIP(e->cfg.precision == FPV_F64
+                ? launch_convert<double>(e->state, state_out, e->cfg.num_envs, true, (hipStream_t)stream)
+                : launch_convert<float>(e->state, state_out, e->cfg.num_envs, true, (hipStream_t)stream));
+    return FPV_OK;
+}
+
+int fpv_set_state(fpv_env* e, const void* state_in, void* stream) {
+    if (!e || !state_in) return fail(FPV_ERR_ARG, "fpv_set_state: null argument");
+    FPV_HIP(e->cfg.precision == FPV_F64
+                ? launch_convert<double>(e->state, (void*)state_in, e->cfg.num_envs, false, (hipStream_t)stream)
+                : launch_convert<float>(e->state, (void*)state_in, e->cfg.num_envs, false, (hipStream_t)stream));
+    return FPV_OK;
+}
+
+int fpv_set_tick(fpv_env* e, uint64_t tick, void* stream) {
+    if (!e) return fail(FPV_ERR_ARG, "fpv_set_tick: null handle");
+    FPV_HIP(hipMemcpyAsync(e->tick, &tick, sizeof tick, hipMemcpyHostToDevice, (hipStream_t)stream));
+    FPV_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return FPV_OK;
+}
+
+int fpv_get_tick(fpv_env* e, uint64_t* tick_host, void* stream) {
+    if (!e || !tick_host) return fail(FPV_ERR_ARG, "fpv_get_tick: null argument");
+    FPV_HIP(hipMemcpyAsync(tick_host, e->tick, sizeof *tick_host, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    FPV_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return FPV_OK;
+}
+
+int fpv_ledger_view(fpv_env* e, fpv_ledger* out) {
+    if (!e || !out) return fail(FPV_ERR_ARG, "fpv_ledger_view: null argument");
+    out->capacity = e->led_cap;
+    out->count = e->led_count;
+    out->idx = e->led_idx;
+    out->info = e->led_info;
+    out->tag = e->led_tag;
+    out->ep_return = e->led_ret;
+    out->obs = e->led_obs;
+    return FPV_OK;
+}
+
+int fpv_ledger_bind(fpv_env* e, const fpv_ledger* b) {
+    if (!e || !b) return fail(FPV_ERR_ARG, "fpv_ledger_bind: null argument");
+    if (b->capacity <= 0 || !b->count || !b->idx || !b->info || !b->tag || !b->ep_return || !b->obs)
+        return fail(FPV_ERR_ARG, "fpv_ledger_bind: every buffer and a positive capacity are required");
+    if (e->led_owned) {
+        FPV_HIP(hipDeviceSynchronize());
+        void* led[] = {e->led_count, e->led_idx, e->led_info, e->led_tag, e->led_ret, e->led_obs};
+        for (void* p : led)
+            if (p) (void)hipFree(p);
+        e->led_owned = false;
+    }
+    e->led_cap = b->capacity;
+    e->led_count = b->count; e->led_idx = b->idx; e->led_info = b->info; e->led_tag = b->tag;
+    e->led_ret = b->ep_return; e->led_obs = b->obs;
+    return FPV_OK;
+}
+
+int fpv_ledger_clear(fpv_env* e, void* stream) {
+    if (!e) return fail(FPV_ERR_ARG, "fpv_ledger_clear: null handle");
+    FPV_HIP(hipMemsetAsync(e->led_count, 0, sizeof(uint32_t), (hipStream_t)stream));
+    return FPV_OK;
+}
+
+int fpv_gae(int64_t T, int64_t n, const float* rewards, const float* values, const uint8_t* episode_starts,
+            const float* last_values, const uint8_t* last_dones, float gamma, float lam, float* advantages,
+            float* returns, double* stats, void* stream) {
+    if (T <= 0 || n <= 0) return fail(FPV_ERR_ARG, "fpv_gae: T and n must be positive");
+    if (!rewards || !values || !episode_starts || !last_values || !last_dones || !advantages || !returns)
+        return fail(FPV_ERR_ARG, "fpv_gae: null buffer");
+    double* scratch = nullptr;
+    if (int rc = scratch_for_current_device(&scratch)) return rc;
+    FPV_HIP(launch_gae(T, n, rewards, values, episode_starts, last_values, last_dones, gamma, lam, advantages,
+                       returns, stats, scratch, (hipStream_t)stream));
+    return FPV_OK;
+}
+
+int fpv_normalize(int64_t n, int32_t d, const float* x, float* y, double* rms, int32_t update, float clip, float eps,
+                  void* stream) {
+    if (n <= 0 || d <= 0 || d > 32) return fail(FPV_ERR_ARG, "fpv_normalize: need n > 0 and 0 < d <= 32");
+    if (!x || !rms) return fail(FPV_ERR_ARG, "fpv_normalize: null buffer");
+    double* scratch = nullptr;
+    if (int rc = scratch_for_current_device(&scratch)) return rc;
+    FPV_HIP(launch_normalize(n, d, x, y, rms, update, clip, eps, scratch, (hipStream_t)stream));
+    return FPV_OK;
+}
+
+int fpv_normalize_reward(int64_t n, const float* r, const uint8_t* done, float* ret, float* r_out, double* rms,
+                         int32_t update, float gamma, float clip, float eps, void* stream) {
+    if (n <= 0) return fail(FPV_ERR_ARG, "fpv_normalize_reward: n must be positive");
+    if (!r || !done || !ret || !r_out || !rms) return fail(FPV_ERR_ARG, "fpv_normalize_reward: null buffer");
+    double* scratch = nullptr;
+    if (int rc = scratch_for_current_device(&scratch)) return rc;
+    FPV_HIP(launch_normalize_reward(n, r, done, ret, r_out, rms, update, gamma, clip, eps, scratch,
+                                    (hipStream_t)stream));
+    return FPV_OK;
+}
+
+}  // extern "C"

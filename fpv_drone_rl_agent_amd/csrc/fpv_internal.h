@@ -1,0 +1,58 @@
+// fpv_internal.h — declarations shared by the kernel translation units and the C ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fpv {
+
+template <typename T>
+struct Vec4;
+
+constexpr uint32_t kInfoTerm = 1u, kInfoTrunc = 2u, kInfoOob = 4u, kInfoFloor = 8u;  // = FPV_INFO_*
+
+template <typename T>
+struct StepArgs {
+    Vec4<T>* state;        // [tiles][9][64] granules
+    const T* actions;      // [n][4]
+    T* obs;                // [n][20]
+    T* reward;             // [n]
+    uint8_t* terminated;   // [n]
+    uint8_t* truncated;    // [n]
+    uint64_t* tick;        // device agent-tick counter
+    const T* tmpl;         // reset template: 36 state words (storage-slot order) + 20 obs words
+    uint32_t* led_count;
+    int32_t* led_idx;
+    uint32_t* led_info;
+    uint32_t* led_tag;
+    T* led_ret;
+    T* led_obs;
+    int64_t led_cap;
+    int64_t n;
+    uint64_t seed;
+    uint64_t id_offset;
+    T sigma;
+    int32_t floor_check;
+};
+
+template <typename T>
+hipError_t launch_step(const StepArgs<T>& a, bool noise, hipStream_t s);
+template <typename T>
+hipError_t launch_reset(void* state, const void* tmpl, const uint8_t* mask, void* obs, int64_t n, hipStream_t s);
+template <typename T>
+hipError_t launch_init(void* state, void* tmpl, int64_t n, hipStream_t s);
+template <typename T>
+hipError_t launch_convert(void* state, void* canon, int64_t n, bool to_canon, hipStream_t s);
+
+// fpv_rollout.hip
+hipError_t launch_gae(int64_t T, int64_t n, const float* rewards, const float* values, const uint8_t* episode_starts,
+                      const float* last_values, const uint8_t* last_dones, float gamma, float lam, float* adv,
+                      float* returns, double* stats, double* scratch, hipStream_t s);
+hipError_t launch_normalize(int64_t n, int32_t d, const float* x, float* y, double* rms, int32_t update, float clip,
+                            float eps, double* scratch, hipStream_t s);
+hipError_t launch_normalize_reward(int64_t n, const float* r, const uint8_t* done, float* ret, float* r_out,
+                                   double* rms, int32_t update, float gamma, float clip, float eps, double* scratch,
+                                   hipStream_t s);
+constexpr int kScratchDoubles = 1024 * 80;  // per-device reduction scratch (partials)
+
+}  // namespace fpv

@@ -1,0 +1,261 @@
+// fpv_step.hip — the fused env-step kernel and its small companions (gfx950).
+//
+// K1 step_kernel: one lane per drone, one 64-lane workgroup per storage tile.
+//   HBM traffic per drone and agent step: 9 granule loads + 9 granule stores (16 B per lane,
+//   1 KiB contiguous per wave instruction), one 16-B action load, 80 B of observation staged
+//   through LDS so that the [N][20] rows leave as five 1-KiB contiguous stores per wave, 4 B
+//   reward, 2 flag bytes.  All 12 physics sub-steps run in registers.
+//   Episode ends are compacted into the done ledger with one wave ballot + one atomic per
+//   wave that has any; the reset state is a constant template (docs/SPEC.md §8), so a
+//   finished drone costs its wave a few selects, not a divergent warm-up loop.
+//
+// Reference path replaced: QuadXHoverEnv.step()/reset() simulation/hover.py:72-114,334-358
+// under the SB3 VecEnv auto-reset protocol (simulation/train_hover.py:42).
+#include "fpv_dynamics.h"
+#include "fpv_internal.h"
+
+namespace fpv {
+
+// ---------------------------------------------------------------- reward (SPEC §7)
+template <typename T>
+__device__ __forceinline__ T reward_and_flags(const Drone<T>& d, T roll, T pitch, bool vis, const T (&o)[kObsWords],
+                                              T a0, T a1, T a2, T a3, bool floor_check, uint32_t& bits) {
+    T reward = T(-0.1);                                             // hover.py:343
+    bits = 0;
+    if (d.steps > T(400)) bits |= kInfoTrunc;                       // hover.py:275
+    if (sqrt_(d.px * d.px + d.py * d.py + d.pz * d.pz) > T(3.0)) {  // hover.py:278-281
+        reward = T(-100);
+        bits |= kInfoTerm | kInfoOob;
+    }
+    if (floor_check && d.steps > T(30) && d.pz < T(0.1)) {          // hover.py:283-290
+        reward = T(-100);
+        bits |= kInfoTerm | kInfoFloor;
+    }
+    const T target = vis ? -sqrt_(o[7] * o[7] + o[8] * o[8]) - abs_(o[11] - T(0.013)) - abs_(o[14] - T(1.53))
+                         : T(-2);                                   // hover.py:296-320
+    reward -= T(0.01) * d.wz * d.wz;                                // hover.py:322-324
+    reward += target - sqrt_(roll * roll + pitch * pitch);          // hover.py:326-327
+    const T d0 = a0 - d.a0, d1 = a1 - d.a1, d2 = a2 - d.a2, d3 = a3 - d.a3;
+    reward -= T(0.2) * sqrt_(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3);  // hover.py:329-331
+    reward += T(1);                                                 // hover.py:332
+    return reward;
+}
+
+template <typename T>
+__device__ __forceinline__ void drone_from_template(Drone<T>& d, const T* __restrict__ tm) {
+    // tm is in storage-slot order; prev_action (slots 32..35) is deliberately not taken:
+    // hover.py:101 resets only self.action, prev_action survives reset()
+    d.px = tm[0]; d.py = tm[1]; d.pz = tm[2]; d.steps = tm[3];
+    d.qx = tm[4]; d.qy = tm[5]; d.qz = tm[6]; d.qw = tm[7];
+    d.vx = tm[8]; d.vy = tm[9]; d.vz = tm[10]; d.ep_ret = tm[11];
+    d.wx = tm[12]; d.wy = tm[13]; d.wz = tm[14]; d.prev_area = tm[15];
+    d.t0 = tm[16]; d.t1 = tm[17]; d.t2 = tm[18]; d.t3 = tm[19];
+    d.ix = tm[20]; d.iy = tm[21]; d.iz = tm[22]; d.prev_ratio = tm[23];
+    d.ex = tm[24]; d.ey = tm[25]; d.ez = tm[26]; d.prev_cx = tm[27];
+    d.er = tm[28]; d.ep = tm[29]; d.eyaw = tm[30]; d.prev_cy = tm[31];
+}
+
+// stage a wave's [64][20] observation tile through LDS and write it out row-major
+template <typename T>
+__device__ __forceinline__ void store_obs_tile(const T (&o)[kObsWords], T* __restrict__ obs, int64_t tile,
+                                               int lane, int64_t n, Vec4<T>* lds) {
+#pragma unroll
+    for (int g = 0; g < kObsWords / 4; ++g)
+        lds[lane * (kObsWords / 4) + g] = Vec4<T>{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+    __syncthreads();
+    Vec4<T>* out = reinterpret_cast<Vec4<T>*>(obs + tile * (kTile * kObsWords));
+    const int64_t rows_left = n - tile * kTile;  // rows of this tile that exist
+#pragma unroll
+    for (int r = 0; r < kObsWords / 4; ++r) {
+        const int f4 = r * kTile + lane;         // 16-byte granule index inside the tile
+        if (f4 / (kObsWords / 4) < rows_left) out[f4] = lds[f4];
+    }
+}
+
+// ---------------------------------------------------------------- K1
+template <typename T, bool NOISE>
+__global__ __launch_bounds__(kTile) void step_kernel(StepArgs<T> p) {
+    __shared__ Vec4<T> lds[kTile * kObsWords / 4];
+    const int lane = threadIdx.x;
+    const int64_t tile = blockIdx.x;
+    const int64_t i = tile * kTile + lane;
+    const bool live = i < p.n;
+
+    Drone<T> d;
+    load_drone(d, p.state, tile, lane);
+    const Vec4<T> act = live ? reinterpret_cast<const Vec4<T>*>(p.actions)[i] : Vec4<T>{T(0), T(0), T(0), T(-1)};
+    const uint64_t agent_tick = *p.tick;
+    const uint32_t gid = (uint32_t)(p.id_offset + (uint64_t)i);
+
+    // hover.py:337-341 action scaling; the mode-0 thrust setpoint is clipped to [0,1] (SPEC §4.1)
+    const T spx = act.x * T(30), spy = act.y * T(30), spz = act.z * T(-30);
+    const T thrust = clip_((act.w + T(1)) * T(0.5), T(0), T(1));
+
+    // hover.py:346-349: 6 aviary steps = 6 x (control tick + 2 physics sub-steps)
+    T pwm[4];
+#pragma unroll 1
+    for (int k = 0; k < kSubstepPairs; ++k) {
+        control_tick(d, spx, spy, spz, thrust, pwm);
+        const uint64_t t0 = agent_tick * (uint64_t)(2 * kSubstepPairs) + (uint64_t)(2 * k);
+        physics_substep<T, NOISE>(d, pwm, p.sigma, p.seed, gid, t0);
+        physics_substep<T, NOISE>(d, pwm, p.sigma, p.seed, gid, t0 + 1);
+    }
+
+    // hover.py:351-357
+    T roll, pitch, yaw;
+    euler_from_quat(d.qx, d.qy, d.qz, d.qw, roll, pitch, yaw);
+    T o[kObsWords];
+    const bool vis = observe(d, roll, pitch, yaw, act.x, act.y, act.z, act.w, o);
+    uint32_t bits;
+    const T reward = reward_and_flags(d, roll, pitch, vis, o, act.x, act.y, act.z, act.w, p.floor_check != 0, bits);
+    d.er = roll; d.ep = pitch; d.eyaw = yaw;
+    d.steps += T(1);
+    d.a0 = act.x; d.a1 = act.y; d.a2 = act.z; d.a3 = act.w;
+    d.ep_ret += reward;
+
+    // episode ends -> done ledger (wave-ballot compaction), then constant-template reset
+    const bool done = live && (bits & (kInfoTerm | kInfoTrunc)) != 0;
+    const unsigned long long m = __ballot(done);
+    if (m != 0ull) {
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(p.led_count, (uint32_t)__popcll(m));
+        base = __shfl(base, leader);
+        if (done) {
+            const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if ((int64_t)slot < p.led_cap) {
+                p.led_idx[slot] = (int32_t)i;
+                p.led_info[slot] = bits | ((uint32_t)d.steps << 8);
+                p.led_tag[slot] = (uint32_t)agent_tick;
+                p.led_ret[slot] = d.ep_ret;
+                T* lo = p.led_obs + (int64_t)slot * kObsWords;
+#pragma unroll
+                for (int j = 0; j < kObsWords; ++j) lo[j] = o[j];
+            }
+            drone_from_template(d, p.tmpl);
+#pragma unroll
+            for (int j = 0; j < kObsWords; ++j) o[j] = p.tmpl[kStateWords + j];
+        }
+    }
+
+    store_drone(d, p.state, tile, lane);
+    if (live) {
+        p.reward[i] = reward;
+        p.terminated[i] = (bits & kInfoTerm) ? 1 : 0;
+        p.truncated[i] = (bits & kInfoTrunc) ? 1 : 0;
+    }
+    store_obs_tile(o, p.obs, tile, lane, p.n, lds);
+}
+
+// ---------------------------------------------------------------- K2 masked reset
+template <typename T>
+__global__ __launch_bounds__(kTile) void reset_kernel(Vec4<T>* state, const T* tmpl, const uint8_t* mask, T* obs,
+                                                      int64_t n) {
+    const int lane = threadIdx.x;
+    const int64_t tile = blockIdx.x;
+    const int64_t i = tile * kTile + lane;
+    if (i >= n) return;
+    if (mask && !mask[i]) return;
+    Drone<T> d;
+    load_drone(d, state, tile, lane);
+    drone_from_template(d, tmpl);
+    store_drone(d, state, tile, lane);
+    if (obs) {
+        T* o = obs + i * kObsWords;
+#pragma unroll
+        for (int j = 0; j < kObsWords; ++j) o[j] = tmpl[kStateWords + j];
+    }
+}
+
+// reset template = spawn state + noise-free motor warm-up + first observation (SPEC §8);
+// evaluated once at fpv_create with the same device functions the step uses.
+template <typename T>
+__global__ void template_kernel(T* tmpl) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Drone<T> d = {};
+    d.pz = C<T>::z_rest;
+    d.qw = T(1);
+    T thr = T(0);
+    for (int k = 0; k < 20; ++k) thr += C<T>::alpha * (C<T>::pwm_idle - thr);  // hover.py:109-110
+    d.t0 = d.t1 = d.t2 = d.t3 = thr;
+    T o[kObsWords];
+    observe(d, T(0), T(0), T(0), T(0), T(0), T(0), T(0), o);                   // hover.py:112-113
+    const T s[kStateWords] = {d.px, d.py, d.pz, d.steps, d.qx, d.qy, d.qz, d.qw, d.vx, d.vy, d.vz, d.ep_ret,
+                              d.wx, d.wy, d.wz, d.prev_area, d.t0, d.t1, d.t2, d.t3, d.ix, d.iy, d.iz,
+                              d.prev_ratio, d.ex, d.ey, d.ez, d.prev_cx, d.er, d.ep, d.eyaw, d.prev_cy,
+                              d.a0, d.a1, d.a2, d.a3};
+    for (int j = 0; j < kStateWords; ++j) tmpl[j] = s[j];
+    for (int j = 0; j < kObsWords; ++j) tmpl[kStateWords + j] = o[j];
+}
+
+// fill every storage tile (padding lanes included) with the template
+template <typename T>
+__global__ void fill_kernel(Vec4<T>* state, const T* tmpl, int64_t tiles) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // granule index
+    if (g >= tiles * kGranules * kTile) return;
+    const int gran = (int)((g / kTile) % kGranules);
+    state[g] = Vec4<T>{tmpl[4 * gran], tmpl[4 * gran + 1], tmpl[4 * gran + 2], tmpl[4 * gran + 3]};
+}
+
+// canonical [n][36] <-> tiled granule storage
+template <typename T, bool TO_CANON>
+__global__ void convert_kernel(Vec4<T>* state, T* canon, int64_t n) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * kStateWords) return;
+    const int64_t i = e / kStateWords;
+    const int slot = (int)(e % kStateWords);
+    T* word = reinterpret_cast<T*>(state + (i / kTile) * (kGranules * kTile) + (slot / 4) * kTile + (i % kTile)) +
+              (slot % 4);
+    T* c = canon + i * kStateWords + canon_of_slot(slot);
+    if (TO_CANON) *c = *word;
+    else *word = *c;
+}
+
+__global__ void tick_advance_kernel(uint64_t* tick) { *tick += 1ull; }
+
+// ---------------------------------------------------------------- launchers
+template <typename T>
+hipError_t launch_step(const StepArgs<T>& a, bool noise, hipStream_t s) {
+    const int64_t tiles = (a.n + kTile - 1) / kTile;
+    if (noise) hipLaunchKernelGGL((step_kernel<T, true>), dim3((unsigned)tiles), dim3(kTile), 0, s, a);
+    else hipLaunchKernelGGL((step_kernel<T, false>), dim3((unsigned)tiles), dim3(kTile), 0, s, a);
+    hipLaunchKernelGGL(tick_advance_kernel, dim3(1), dim3(1), 0, s, a.tick);
+    return hipGetLastError();
+}
+template hipError_t launch_step<float>(const StepArgs<float>&, bool, hipStream_t);
+template hipError_t launch_step<double>(const StepArgs<double>&, bool, hipStream_t);
+
+template <typename T>
+hipError_t launch_reset(void* state, const void* tmpl, const uint8_t* mask, void* obs, int64_t n, hipStream_t s) {
+    const int64_t tiles = (n + kTile - 1) / kTile;
+    hipLaunchKernelGGL(reset_kernel<T>, dim3((unsigned)tiles), dim3(kTile), 0, s, (Vec4<T>*)state, (const T*)tmpl,
+                       mask, (T*)obs, n);
+    return hipGetLastError();
+}
+template hipError_t launch_reset<float>(void*, const void*, const uint8_t*, void*, int64_t, hipStream_t);
+template hipError_t launch_reset<double>(void*, const void*, const uint8_t*, void*, int64_t, hipStream_t);
+
+template <typename T>
+hipError_t launch_init(void* state, void* tmpl, int64_t n, hipStream_t s) {
+    const int64_t tiles = (n + kTile - 1) / kTile;
+    hipLaunchKernelGGL(template_kernel<T>, dim3(1), dim3(64), 0, s, (T*)tmpl);
+    const int64_t g = tiles * kGranules * kTile;
+    hipLaunchKernelGGL(fill_kernel<T>, dim3((unsigned)((g + 255) / 256)), dim3(256), 0, s, (Vec4<T>*)state,
+                       (const T*)tmpl, tiles);
+    return hipGetLastError();
+}
+template hipError_t launch_init<float>(void*, void*, int64_t, hipStream_t);
+template hipError_t launch_init<double>(void*, void*, int64_t, hipStream_t);
+
+template <typename T>
+hipError_t launch_convert(void* state, void* canon, int64_t n, bool to_canon, hipStream_t s) {
+    const int64_t e = n * kStateWords;
+    const dim3 grid((unsigned)((e + 255) / 256)), block(256);
+    if (to_canon) hipLaunchKernelGGL((convert_kernel<T, true>), grid, block, 0, s, (Vec4<T>*)state, (T*)canon, n);
+    else hipLaunchKernelGGL((convert_kernel<T, false>), grid, block, 0, s, (Vec4<T>*)state, (T*)canon, n);
+    return hipGetLastError();
+}
+template hipError_t launch_convert<float>(void*, void*, int64_t, bool, hipStream_t);
+template hipError_t launch_convert<double>(void*, void*, int64_t, bool, hipStream_t);
+
+}  // namespace fpv

@@ -1,0 +1,138 @@
+"""FpvEngine — thin owner of one fpv_env handle over torch-allocated device buffers.
+
+torch is used here only for device memory and stream handles; every computation is a call
+into libfpv_env.so through the C ABI of include/fpv_env.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class FpvEngine:
+    """N parallel hover drones on one GPU.  Mirrors QuadXHoverEnv's constructor arguments
+    (simulation/hover.py:11-16) plus the vectorisation / sharding knobs of SURVEY.md §8e."""
+
+    def __init__(self, num_envs: int, device: int | str | torch.device = 0, *, render: bool = False,
+                 noise_ratio: float = 0.02, seed: int = 0, id_offset: int = 0, precision: str = "f32",
+                 ledger_capacity: int = 0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("FpvEngine needs a HIP device: the MI355X extension has no CPU fallback")
+        self.lib = L.load()
+        dev = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        if dev.type != "cuda":
+            raise ValueError("FpvEngine runs on a HIP device only")
+        self.device = dev
+        self.num_envs = int(num_envs)
+        self.dtype = torch.float64 if precision == "f64" else torch.float32
+        self._f64 = precision == "f64"
+        cfg = L.FpvConfig(self.num_envs, dev.index or 0, L.FPV_F64 if self._f64 else L.FPV_F32,
+                          0 if render else 1, 0, float(noise_ratio), int(seed), int(id_offset), int(ledger_capacity))
+        h = C.c_void_p()
+        L.check(self.lib.fpv_create(C.byref(cfg), C.byref(h)), "fpv_create")
+        self._h = h
+        n = self.num_envs
+        with torch.cuda.device(dev):
+            self.obs = torch.empty((n, L.OBS_WORDS), dtype=self.dtype, device=dev)
+            self.reward = torch.empty((n,), dtype=self.dtype, device=dev)
+            self.terminated = torch.empty((n,), dtype=torch.uint8, device=dev)
+            self.truncated = torch.empty((n,), dtype=torch.uint8, device=dev)
+            cap = int(ledger_capacity) if ledger_capacity > 0 else 2 * n
+            # caller-owned done ledger (fpv_ledger_bind): torch can view it without copies
+            self.led_count = torch.zeros((1,), dtype=torch.int32, device=dev)
+            self.led_idx = torch.zeros((cap,), dtype=torch.int32, device=dev)
+            self.led_info = torch.zeros((cap,), dtype=torch.int32, device=dev)
+            self.led_tag = torch.zeros((cap,), dtype=torch.int32, device=dev)
+            self.led_ret = torch.zeros((cap,), dtype=self.dtype, device=dev)
+            self.led_obs = torch.zeros((cap, L.OBS_WORDS), dtype=self.dtype, device=dev)
+        self.ledger_capacity = cap
+        led = L.FpvLedger(cap, self.led_count.data_ptr(), self.led_idx.data_ptr(), self.led_info.data_ptr(),
+                          self.led_tag.data_ptr(), self.led_ret.data_ptr(), self.led_obs.data_ptr())
+        L.check(self.lib.fpv_ledger_bind(self._h, C.byref(led)), "fpv_ledger_bind")
+
+    # -- lifecycle -----------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            torch.cuda.synchronize(self.device)
+            self.lib.fpv_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- reference-shaped operations -----------------------------------------------
+    def reset(self, mask: torch.Tensor | None = None, obs: torch.Tensor | None = None) -> torch.Tensor:
+        obs = self.obs if obs is None else obs
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        L.check(self.lib.fpv_reset(self._h, _ptr(mask), _ptr(obs), _stream(self.device)), "fpv_reset")
+        return obs
+
+    def step(self, actions: torch.Tensor, obs=None, reward=None, terminated=None, truncated=None):
+        """actions [N,4] on device, same dtype as the engine.  Returns (obs, reward, terminated, truncated)
+        — the engine's own buffers unless output tensors are given."""
+        if actions.dtype != self.dtype or actions.device != self.device or not actions.is_contiguous():
+            raise ValueError("actions must be a contiguous device tensor of the engine's dtype")
+        if actions.shape != (self.num_envs, L.ACT_WORDS):
+            raise ValueError(f"actions must have shape ({self.num_envs}, {L.ACT_WORDS})")
+        obs = self.obs if obs is None else obs
+        reward = self.reward if reward is None else reward
+        terminated = self.terminated if terminated is None else terminated
+        truncated = self.truncated if truncated is None else truncated
+        fn = self.lib.fpv_step_f64 if self._f64 else self.lib.fpv_step
+        L.check(fn(self._h, _ptr(actions), _ptr(obs), _ptr(reward), _ptr(terminated), _ptr(truncated),
+                   _stream(self.device)), "fpv_step")
+        return obs, reward, terminated, truncated
+
+    # -- state blobs ----------------------------------------------------------------
+    def get_state(self) -> torch.Tensor:
+        out = torch.empty((self.num_envs, L.STATE_WORDS), dtype=self.dtype, device=self.device)
+        L.check(self.lib.fpv_get_state(self._h, _ptr(out), _stream(self.device)), "fpv_get_state")
+        return out
+
+    def set_state(self, state: torch.Tensor) -> None:
+        state = state.to(device=self.device, dtype=self.dtype).contiguous()
+        if state.shape != (self.num_envs, L.STATE_WORDS):
+            raise ValueError("state must be [num_envs, 36]")
+        L.check(self.lib.fpv_set_state(self._h, _ptr(state), _stream(self.device)), "fpv_set_state")
+        torch.cuda.current_stream(self.device).synchronize()  # `state` may be a temporary
+
+    def set_tick(self, tick: int) -> None:
+        L.check(self.lib.fpv_set_tick(self._h, C.c_uint64(tick), _stream(self.device)), "fpv_set_tick")
+
+    def get_tick(self) -> int:
+        t = C.c_uint64()
+        L.check(self.lib.fpv_get_tick(self._h, C.byref(t), _stream(self.device)), "fpv_get_tick")
+        return int(t.value)
+
+    # -- done ledger ------------------------------------------------------------------
+    def ledger_clear(self) -> None:
+        L.check(self.lib.fpv_ledger_clear(self._h, _stream(self.device)), "fpv_ledger_clear")
+
+    def ledger_read(self):
+        """Synchronising read of the ledger: dict of host numpy arrays sorted by (tag, drone)."""
+        import numpy as np
+        total = int(self.led_count.item())
+        c = min(total, self.ledger_capacity)
+        idx = self.led_idx[:c].cpu().numpy()
+        info = self.led_info[:c].cpu().numpy().view(np.uint32)
+        tag = self.led_tag[:c].cpu().numpy().view(np.uint32)
+        ret = self.led_ret[:c].cpu().numpy()
+        obs = self.led_obs[:c].cpu().numpy()
+        order = np.lexsort((idx, tag))
+        return {"count": total, "idx": idx[order], "info": info[order], "tag": tag[order],
+                "ep_return": ret[order], "obs": obs[order]}

@@ -1,0 +1,145 @@
+/*
+ * fpv_env.h — C ABI of the MI355X-native vectorised quadrotor hover environment and the
+ * PPO rollout primitives (GAE, running-moment normaliser).
+ *
+ * The reference has no FFI: its replaceable seam is two duck-typed Python protocols
+ * (SURVEY.md §8b).  Each entry point below names the reference interface it stands
+ * under; the Python facades in fpv_drone_rl_agent_amd/ present those protocols and call
+ * only these symbols (ctypes).  Plain pointers and sizes, no torch / HIP types: a
+ * `stream` argument is a hipStream_t passed as void* (NULL = the default stream).
+ *
+ * All array arguments are DEVICE pointers unless a name ends in `_host`.  Calls are
+ * stream-ordered and asynchronous with respect to the host; no entry point except
+ * fpv_create / fpv_destroy / fpv_set_tick / fpv_get_tick / *_host synchronises.
+ * One fpv_env per (process, device); a handle is not re-entrant.
+ *
+ * Return value: 0 on success, a negative fpv_status otherwise; fpv_last_error() then
+ * holds a thread-local message.  HIP errors are captured, never abort().
+ */
+#ifndef FPV_ENV_H
+#define FPV_ENV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FPV_STATE_WORDS 36 /* docs/SPEC.md §2 canonical order */
+#define FPV_OBS_WORDS 20   /* simulation/hover.py:63-70 */
+#define FPV_ACT_WORDS 4    /* simulation/hover.py:59-61 */
+
+typedef enum {
+    FPV_OK = 0,
+    FPV_ERR_ARG = -1,
+    FPV_ERR_HIP = -2,
+    FPV_ERR_ALLOC = -3,
+    FPV_ERR_UNSUPPORTED = -4
+} fpv_status;
+
+typedef enum { FPV_F32 = 0, FPV_F64 = 1 } fpv_precision;
+
+/* info bits of a done-ledger entry; ep_len is stored in bits 8..31 */
+#define FPV_INFO_TERMINATED 1u    /* hover.py:281,290 */
+#define FPV_INFO_TRUNCATED 2u     /* hover.py:275-276 */
+#define FPV_INFO_OUT_OF_BOUNDS 4u /* hover.py:280 */
+#define FPV_INFO_ON_FLOOR 8u      /* hover.py:289 */
+
+typedef struct fpv_env fpv_env;
+
+/* Constructor arguments.  Stands under QuadXHoverEnv.__init__(flight_mode=0, agent_hz=40,
+ * render=False) (simulation/hover.py:11-70) for num_envs drones at once, i.e. under
+ * make_vec_env(make_env, n_envs=...) (simulation/train_hover.py:36-42). */
+typedef struct {
+    int64_t num_envs;        /* drones owned by this handle (this rank's shard) */
+    int32_t device;          /* HIP device ordinal */
+    int32_t precision;       /* fpv_precision: arithmetic + I/O type of this handle */
+    int32_t floor_check;     /* 1 = render=False (hover.py:283); 0 disables the floor rule */
+    int32_t reserved0;
+    double noise_ratio;      /* cf2x.yaml:5 motor noise (0.02); 0 = noise-free */
+    uint64_t seed;           /* Philox key (docs/SPEC.md §9) */
+    uint64_t id_offset;      /* global id of drone 0: rank * num_envs */
+    int64_t ledger_capacity; /* done-ledger rows; 0 = 2 * num_envs */
+} fpv_config;
+
+/* Device-side view of the done ledger (SB3 VecEnv `infos[i]["terminal_observation"]`,
+ * `["TimeLimit.truncated"]`, Monitor `["episode"] = {r, l}` — SURVEY.md §8a A11).  Rows
+ * are appended by fpv_step in unspecified order with wave-ballot compaction. */
+typedef struct {
+    int64_t capacity;
+    uint32_t* count; /* device: rows appended since the last fpv_ledger_clear (may exceed capacity: overflow rows are dropped) */
+    int32_t* idx;    /* [capacity] local drone index */
+    uint32_t* info;  /* [capacity] FPV_INFO_* | ep_len << 8 */
+    uint32_t* tag;   /* [capacity] low 32 bits of the agent tick of the step that ended the episode */
+    void* ep_return; /* [capacity] float or double by precision */
+    void* obs;       /* [capacity][FPV_OBS_WORDS] terminal observation */
+} fpv_ledger;
+
+/* ---- lifecycle ---- */
+int fpv_create(const fpv_config* cfg, fpv_env** out);
+/* QuadXHoverEnv.close() — hover.py:363-365 */
+int fpv_destroy(fpv_env* env);
+
+/* QuadXHoverEnv.reset() — hover.py:72-114; VecEnv.reset().  mask (uint8[num_envs]) selects
+ * drones, NULL = all.  obs [num_envs][20] receives the reset observation of the selected
+ * drones (others untouched); obs may be NULL.  prev_action is preserved (hover.py:101). */
+int fpv_reset(fpv_env* env, const uint8_t* mask, void* obs, void* stream);
+
+/* QuadXHoverEnv.step() — hover.py:334-358 for every drone, with VecEnv auto-reset.
+ * actions [num_envs][4] raw (unscaled, unclipped); obs [num_envs][20]; reward [num_envs];
+ * terminated / truncated uint8 [num_envs].  Float handles only. */
+int fpv_step(fpv_env* env, const float* actions, float* obs, float* reward, uint8_t* terminated,
+             uint8_t* truncated, void* stream);
+/* Same for an FPV_F64 handle (trajectory-level parity runs). */
+int fpv_step_f64(fpv_env* env, const double* actions, double* obs, double* reward,
+                 uint8_t* terminated, uint8_t* truncated, void* stream);
+
+/* Canonical state blobs [num_envs][36] in the handle's precision (docs/SPEC.md §2); used by
+ * parity tests and the synthetic random-init benchmark. */
+int fpv_get_state(fpv_env* env, void* state_out, void* stream);
+int fpv_set_state(fpv_env* env, const void* state_in, void* stream);
+
+/* Agent-tick counter that keys the motor-noise RNG (device resident so that fpv_step can be
+ * captured into a HIP graph).  These two synchronise the stream. */
+int fpv_set_tick(fpv_env* env, uint64_t tick, void* stream);
+int fpv_get_tick(fpv_env* env, uint64_t* tick_host, void* stream);
+
+int fpv_ledger_view(fpv_env* env, fpv_ledger* out);
+int fpv_ledger_clear(fpv_env* env, void* stream);
+/* Replace the handle-owned ledger by caller-owned device buffers (same layout as fpv_ledger;
+ * ep_return / obs in the handle's precision).  The caller keeps them alive until
+ * fpv_destroy or the next bind.  Lets a host runtime view the ledger without copies. */
+int fpv_ledger_bind(fpv_env* env, const fpv_ledger* buffers);
+
+/* ---- PPO rollout primitives ---- */
+
+/* SB3 RolloutBuffer.compute_returns_and_advantage: rewards / values / episode_starts are
+ * [T][n] (time-major), last_values / last_dones [n]; writes advantages / returns [T][n].
+ * stats (optional, device double[3]) receives {count, sum(A), sum(A^2)} of this shard —
+ * the payload of the one all-gather per update. */
+int fpv_gae(int64_t T, int64_t n, const float* rewards, const float* values,
+            const uint8_t* episode_starts, const float* last_values, const uint8_t* last_dones,
+            float gamma, float lam, float* advantages, float* returns, double* stats,
+            void* stream);
+
+/* SB3 VecNormalize running moments (train_hover.py:43): merge the batch x [n][d] into
+ * rms = double[2*d + 1] = {mean[d], var[d], count} (parallel-variance merge), when
+ * update != 0, then write y = clip((x - mean) / sqrt(var + eps), +-clip) (y may alias x,
+ * or be NULL to only update).  d <= 32. */
+int fpv_normalize(int64_t n, int32_t d, const float* x, float* y, double* rms, int32_t update,
+                  float clip, float eps, void* stream);
+
+/* VecNormalize reward path: ret = ret * gamma + r; merge ret into rms = double[3]
+ * {mean, var, count} when update != 0; r_out = clip(r / sqrt(var + eps), +-clip);
+ * ret[done] = 0.  r_out may alias r. */
+int fpv_normalize_reward(int64_t n, const float* r, const uint8_t* done, float* ret, float* r_out,
+                         double* rms, int32_t update, float gamma, float clip, float eps,
+                         void* stream);
+
+const char* fpv_last_error(void);
+int fpv_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
