@@ -31,14 +31,26 @@ def _actions(n, seed, dtype):
     return rng.uniform(-1, 1, (n, 4)).astype(dtype)
 
 
-def _done_margin(st_after_oracle_pre_reset_pos):
-    pass
+def _with_edge_cases(st, seed):
+    """Push a tenth of the synthetic drones to where episodes end (hover.py:275-290): just inside the
+    dome flying outwards, just above the 0.1 m floor line descending, and past max_steps."""
+    rng = np.random.Generator(np.random.Philox(seed + 77))
+    n = st.shape[0]
+    k = max(n // 30, 1)
+    a, b, c = np.arange(0, k), np.arange(k, 2 * k), np.arange(2 * k, 3 * k)
+    d = rng.normal(size=(k, 3)); d[:, 2] = np.abs(d[:, 2]) + 0.2
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    st[a, 0:3] = d * rng.uniform(2.9, 2.999, (k, 1)); st[a, 7:10] = d * rng.uniform(0.5, 4.0, (k, 1))
+    st[b, 2] = rng.uniform(0.1, 0.2, k); st[b, 9] = -rng.uniform(0.2, 3.0, k); st[b, 34] = rng.integers(31, 400, k)
+    st[b, 0:2] = rng.uniform(-1, 1, (k, 2))
+    st[c, 34] = rng.integers(399, 404, k)
+    return st
 
 
 @pytest.mark.parametrize("noise", [0.0, 0.02])
 def test_fp32_single_step_matches_oracle(oracle, noise):
     n = N_SMALL
-    st0 = oracle.synthetic_states(n, seed=0)
+    st0 = _with_edge_cases(oracle.synthetic_states(n, seed=0), 0)
     act = _actions(n, 0, np.float32)
     tick = 7
     # oracle (fp64) from the fp32-rounded inputs, so both sides start from identical states
@@ -81,7 +93,7 @@ def test_fp32_single_step_matches_oracle(oracle, noise):
 def test_fp64_trajectory_matches_oracle(oracle, noise):
     """40 agent steps with auto-reset, random actions: fp64 kernel tracks the oracle to 1e-9."""
     n, steps = 1000, 40  # n deliberately not a multiple of the 64-drone tile
-    st_ref = oracle.synthetic_states(n, seed=3)
+    st_ref = _with_edge_cases(oracle.synthetic_states(n, seed=3), 3)
     cfg = oracle.make_cfg(noise_ratio=noise, seed=99, id_offset=5000)
     eng = _engine(n, noise_ratio=noise, seed=99, id_offset=5000, precision="f64")
     eng.set_state(torch.from_numpy(st_ref))
