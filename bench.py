@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of the on-device PPO rollout at 65 536 drones per MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched by
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per GPU
+over RCCL.  A "step" is one vectorised pass of the hot path over this rank's drones: policy MLP
+forward + Gaussian sample, the fused HIP env-step (12 physics sub-steps, obs, reward, done,
+auto-reset), VecNormalize of obs and reward, rollout-buffer writes; every n_steps steps the rollout
+is closed with the value bootstrap, GAE (HIP) and the ONE all-gather of advantage statistics.
+K is timed exactly (barrier + synchronize on both sides, MAX over ranks); value = drones on all
+ranks x K / time.  Inputs are synthetic (random-init policy, seeded random-init drone states,
+BASELINE.md §3) and resident in HBM before the timed region.
+
+Adds to the JSON line: `roofline` for the dominant kernel (the env-step kernel) from a kernel-only
+pass timed with HIP events on the launch stream, and `cpu_baseline` (the C oracle on host cores,
+rank 0, N = 1 only).  oracle/ is used here ONLY for the cpu_baseline leg.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_BYTES_PER_STEP = 382  # 35 words r+w, 16 B action, 80 B obs, 4 B reward, 2 B flags
+HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def synthetic_states(n: int, seed: int):
+    """Seeded airborne random-init drone states, canonical [n,36] float32 numpy."""
+    from fpv_drone_rl_agent_amd.synthetic import synthetic_states as gen
+    return gen(n, seed=seed).astype("float32")
+
+
+def cpu_baseline(n: int, seed: int, budget_s: float = 12.0):
+    """The C oracle (kind "port") on this box's host cores, OpenMP over drones, bounded sample."""
+    import numpy as np
+    from oracle import oracle as orc
+    orc.build()
+    cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 64))
+    st = orc.synthetic_states(n, seed=seed)
+    rng = np.random.Generator(np.random.Philox(seed + 1))
+    act = rng.uniform(-1, 1, (n, 4))
+    cfg = orc.make_cfg(noise_ratio=0.02, seed=seed)
+    t0 = time.perf_counter()
+    orc.step_batch(cfg, st, act, 0, nthreads=threads)           # calibration step (also warms the pool)
+    one = time.perf_counter() - t0
+    steps = int(max(2, min(200, budget_s / max(one, 1e-4))))
+    t0 = time.perf_counter()
+    for t in range(steps):
+        orc.step_batch(cfg, st, act, 1 + t, nthreads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/fpv_oracle.c env-step only (no policy), {n} drones x {steps} steps, "
+                      f"OpenMP {threads} threads of {cores} host cores, {dt:.1f} s"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--drones", type=int, default=65536, help="drones per GPU (BASELINE.json configs[2])")
+    ap.add_argument("--n-steps", type=int, default=32, help="rollout length between GAE passes")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-launches", type=int, default=200)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as td
+    from fpv_drone_rl_agent_amd import dist as D
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    from fpv_drone_rl_agent_amd.rollout import RolloutCollector
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    rank, world, local = D.init_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    n = args.drones
+    K, W = args.steps, args.warmup
+    # rollout length: the largest divisor of K not above --n-steps, so that exactly K steps are timed
+    T = max(d for d in range(1, min(args.n_steps, K) + 1) if K % d == 0)
+
+    torch.manual_seed(0)
+    policy = ActorCritic().to(dev)
+    eng = FpvEngine(n, dev, noise_ratio=0.02, seed=0, id_offset=rank * n)
+    col = RolloutCollector(eng, policy, n_steps=T, use_graph=not args.no_graph)
+    col.start()
+    eng.set_state(torch.from_numpy(synthetic_states(n, seed=rank)))  # staggered step counts => staggered dones
+
+    def barrier():
+        if world > 1:
+            td.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(max(1, math.ceil(W / T))):
+        col.collect()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(K // T):
+        col.collect()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        td.all_reduce(tmax, op=td.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    episodes = int(col.episodes["count"])
+
+    # ---- roofline of the dominant kernel: kernel-only pass, HIP events on the launch stream ----
+    roofline = None
+    if rank == 0:
+        L = args.kernel_launches
+        act = torch.rand((n, 4), device=dev) * 2 - 1
+        for _ in range(20):
+            eng.step(act)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(L):
+            eng.step(act)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        us = e0.elapsed_time(e1) * 1e3 / L
+        achieved = ALG_BYTES_PER_STEP * n / us / 1e3  # GB/s
+        roofline = {"bound": "hbm", "kernel": "fpv::step_kernel<float,true>", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                    "traffic": None, "us_per_launch": round(us, 2), "launches": L,
+                    "algorithmic_bytes_per_launch": ALG_BYTES_PER_STEP * n}
+
+    if rank == 0:
+        out = {
+            "metric": "env_steps_per_sec", "value": n * world * K / elapsed, "unit": "env-steps/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (random-init policy, seeded random-init drone states, motor noise on)",
+            "config": {"workload": "BASELINE.json configs[2]: 65 536 hover drones per GPU, on-device PPO rollout "
+                                   "(policy MLP forward + sample, fused HIP env-step, VecNormalize, buffer) + GAE + "
+                                   "advantage-stat all-gather every n_steps",
+                       "drones_per_gpu": n, "total_drones": n * world, "n_steps": T,
+                       "hip_graph": not args.no_graph, "policy": "MlpPolicy pi/vf [128,128] tanh (39 049 params)",
+                       "episodes_in_last_rollout": episodes},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, seed=0)
+        print(json.dumps(out), flush=True)
+    barrier()
+    eng.close()
+    if world > 1:
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

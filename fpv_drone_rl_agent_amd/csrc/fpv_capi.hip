@@ -36,7 +36,7 @@ struct fpv_env {
     size_t word;         // sizeof(real)
     void* state;         // [tiles][9][64] granules
     void* tmpl;          // 56 reals
-    uint64_t* tick;      // device
+    uint64_t* tick;      // device [tiles]
     uint32_t* led_count;
     int32_t* led_idx;
     uint32_t* led_info;
@@ -114,14 +114,14 @@ int fpv_create(const fpv_config* cfg, fpv_env** out) {
     };
     alloc(&e->state, (size_t)e->tiles * kGranules * kTile * 4 * e->word);
     alloc(&e->tmpl, (size_t)(kStateWords + kObsWords) * e->word);
-    alloc((void**)&e->tick, sizeof(uint64_t));
+    alloc((void**)&e->tick, (size_t)e->tiles * sizeof(uint64_t));
     alloc((void**)&e->led_count, sizeof(uint32_t));
     alloc((void**)&e->led_idx, (size_t)e->led_cap * sizeof(int32_t));
     alloc((void**)&e->led_info, (size_t)e->led_cap * sizeof(uint32_t));
     alloc((void**)&e->led_tag, (size_t)e->led_cap * sizeof(uint32_t));
     alloc(&e->led_ret, (size_t)e->led_cap * e->word);
     alloc(&e->led_obs, (size_t)e->led_cap * kObsWords * e->word);
-    if (err == hipSuccess) err = hipMemset(e->tick, 0, sizeof(uint64_t));
+    if (err == hipSuccess) err = hipMemset(e->tick, 0, (size_t)e->tiles * sizeof(uint64_t));
     if (err == hipSuccess) err = hipMemset(e->led_count, 0, sizeof(uint32_t));
     if (err == hipSuccess)
         err = cfg->precision == FPV_F64 ? launch_init<double>(e->state, e->tmpl, cfg->num_envs, nullptr)
@@ -185,7 +185,7 @@ int fpv_set_state(fpv_env* e, const void* state_in, void* stream) {
 
 int fpv_set_tick(fpv_env* e, uint64_t tick, void* stream) {
     if (!e) return fail(FPV_ERR_ARG, "fpv_set_tick: null handle");
-    FPV_HIP(hipMemcpyAsync(e->tick, &tick, sizeof tick, hipMemcpyHostToDevice, (hipStream_t)stream));
+    FPV_HIP(launch_tick_fill(e->tick, e->tiles, tick, (hipStream_t)stream));
     FPV_HIP(hipStreamSynchronize((hipStream_t)stream));
     return FPV_OK;
 }

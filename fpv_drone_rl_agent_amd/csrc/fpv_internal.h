@@ -19,7 +19,7 @@ struct StepArgs {
     T* reward;             // [n]
     uint8_t* terminated;   // [n]
     uint8_t* truncated;    // [n]
-    uint64_t* tick;        // device agent-tick counter
+    uint64_t* tick;        // [tiles] device agent-tick counters (all equal; one per wave)
     const T* tmpl;         // reset template: 36 state words (storage-slot order) + 20 obs words
     uint32_t* led_count;
     int32_t* led_idx;
@@ -43,6 +43,8 @@ template <typename T>
 hipError_t launch_init(void* state, void* tmpl, int64_t n, hipStream_t s);
 template <typename T>
 hipError_t launch_convert(void* state, void* canon, int64_t n, bool to_canon, hipStream_t s);
+
+hipError_t launch_tick_fill(uint64_t* tick, int64_t tiles, uint64_t v, hipStream_t s);
 
 // fpv_rollout.hip
 hipError_t launch_gae(int64_t T, int64_t n, const float* rewards, const float* values, const uint8_t* episode_starts,

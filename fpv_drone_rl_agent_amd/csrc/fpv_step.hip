@@ -84,7 +84,9 @@ __global__ __launch_bounds__(kTile) void step_kernel(StepArgs<T> p) {
     Drone<T> d;
     load_drone(d, p.state, tile, lane);
     const Vec4<T> act = live ? reinterpret_cast<const Vec4<T>*>(p.actions)[i] : Vec4<T>{T(0), T(0), T(0), T(-1)};
-    const uint64_t agent_tick = *p.tick;
+    // per-tile copy of the agent tick: read and advanced by its own wave only, so the step stays
+    // one kernel and is graph-replayable without host-side argument updates
+    const uint64_t agent_tick = p.tick[tile];
     const uint32_t gid = (uint32_t)(p.id_offset + (uint64_t)i);
 
     // hover.py:337-341 action scaling; the mode-0 thrust setpoint is clipped to [0,1] (SPEC §4.1)
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(kTile) void step_kernel(StepArgs<T> p) {
     }
 
     store_drone(d, p.state, tile, lane);
+    if (lane == 0) p.tick[tile] = agent_tick + 1ull;
     if (live) {
         p.reward[i] = reward;
         p.terminated[i] = (bits & kInfoTerm) ? 1 : 0;
@@ -211,7 +214,10 @@ __global__ void convert_kernel(Vec4<T>* state, T* canon, int64_t n) {
     else *word = *c;
 }
 
-__global__ void tick_advance_kernel(uint64_t* tick) { *tick += 1ull; }
+__global__ void tick_fill_kernel(uint64_t* tick, int64_t tiles, uint64_t v) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < tiles) tick[t] = v;
+}
 
 // ---------------------------------------------------------------- launchers
 template <typename T>
@@ -219,7 +225,6 @@ hipError_t launch_step(const StepArgs<T>& a, bool noise, hipStream_t s) {
     const int64_t tiles = (a.n + kTile - 1) / kTile;
     if (noise) hipLaunchKernelGGL((step_kernel<T, true>), dim3((unsigned)tiles), dim3(kTile), 0, s, a);
     else hipLaunchKernelGGL((step_kernel<T, false>), dim3((unsigned)tiles), dim3(kTile), 0, s, a);
-    hipLaunchKernelGGL(tick_advance_kernel, dim3(1), dim3(1), 0, s, a.tick);
     return hipGetLastError();
 }
 template hipError_t launch_step<float>(const StepArgs<float>&, bool, hipStream_t);
@@ -257,5 +262,10 @@ hipError_t launch_convert(void* state, void* canon, int64_t n, bool to_canon, hi
 }
 template hipError_t launch_convert<float>(void*, void*, int64_t, bool, hipStream_t);
 template hipError_t launch_convert<double>(void*, void*, int64_t, bool, hipStream_t);
+
+hipError_t launch_tick_fill(uint64_t* tick, int64_t tiles, uint64_t v, hipStream_t s) {
+    hipLaunchKernelGGL(tick_fill_kernel, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, s, tick, tiles, v);
+    return hipGetLastError();
+}
 
 }  // namespace fpv

@@ -1,0 +1,74 @@
+"""Multi-GPU glue: one process per GPU, env shards are independent.
+
+The only exchange on the rollout path is ONE all-gather per PPO update of a few fp64 words per
+rank — {count, sum A, sum A^2} of the advantages, with the VecNormalize moments riding in the
+same payload — from which every rank derives the same global mean/std.  The message is < 400 B,
+so it is latency-bound: a single all_gather (RCCL `ncclAllGather` on GPUs, gloo on CPU tests),
+never a ring of our own.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as td
+
+
+def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
+    """Initialise torch.distributed from torchrun's environment.  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not td.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            td.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            td.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world_size() -> int:
+    return td.get_world_size() if td.is_available() and td.is_initialized() else 1
+
+
+def rank() -> int:
+    return td.get_rank() if td.is_available() and td.is_initialized() else 0
+
+
+def allgather_payload(payload: torch.Tensor) -> torch.Tensor:
+    """The one collective per update: gather each rank's 1-D fp64 payload.  Returns [world, len]."""
+    if payload.dtype != torch.float64 or payload.dim() != 1:
+        raise ValueError("payload must be a 1-D float64 tensor")
+    w = world_size()
+    if w == 1:
+        return payload.unsqueeze(0)
+    out = torch.empty((w, payload.numel()), dtype=torch.float64, device=payload.device)
+    td.all_gather_into_tensor(out, payload.contiguous())
+    return out
+
+
+def merge_advantage_stats(gathered: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    """rows = {count, sum, sum_sq} per rank -> global (mean, std) with SB3's unbiased=False std + 1e-8
+    applied by the caller.  Summation is in rank order, so every rank computes identical bits."""
+    tot = gathered[:, :3].sum(dim=0)
+    mean = tot[1] / tot[0]
+    var = torch.clamp(tot[2] / tot[0] - mean * mean, min=0.0)
+    return mean, torch.sqrt(var)
+
+
+def merge_moments(gathered_mean: torch.Tensor, gathered_var: torch.Tensor, gathered_count: torch.Tensor):
+    """Parallel-variance merge of per-rank RunningMeanStd states ([world, d], [world, d], [world])."""
+    mean, var, count = gathered_mean[0].clone(), gathered_var[0].clone(), gathered_count[0].clone()
+    for r in range(1, gathered_mean.shape[0]):
+        bm, bv, bc = gathered_mean[r], gathered_var[r], gathered_count[r]
+        delta = bm - mean
+        tot = count + bc
+        m2 = var * count + bv * bc + delta * delta * count * bc / tot
+        mean = mean + delta * bc / tot
+        var, count = m2 / tot, tot
+    return mean, var, count

@@ -1,0 +1,108 @@
+"""Device ops of the PPO rollout path — thin ctypes calls into libfpv_env.so.
+
+GAE: SB3 RolloutBuffer.compute_returns_and_advantage; RunningNorm: SB3 VecNormalize's
+RunningMeanStd + clip (simulation/train_hover.py:43).  No torch arithmetic here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _need(t, dtype, name):
+    if t.dtype != dtype or not t.is_cuda or not t.is_contiguous():
+        raise ValueError(f"{name} must be a contiguous device tensor of dtype {dtype}")
+
+
+def gae(rewards, values, episode_starts, last_values, last_dones, gamma=0.99, lam=0.95,
+        advantages=None, returns=None, stats=None):
+    """rewards/values [T,N] f32, episode_starts [T,N] u8, last_values [N] f32, last_dones [N] u8.
+    Returns (advantages, returns); stats (optional f64[3]) gets {count, sum A, sum A^2}."""
+    T, n = rewards.shape
+    for t, dt, nm in ((rewards, torch.float32, "rewards"), (values, torch.float32, "values"),
+                      (episode_starts, torch.uint8, "episode_starts"), (last_values, torch.float32, "last_values"),
+                      (last_dones, torch.uint8, "last_dones")):
+        _need(t, dt, nm)
+    if advantages is None:
+        advantages = torch.empty_like(rewards)
+    if returns is None:
+        returns = torch.empty_like(rewards)
+    if stats is not None:
+        _need(stats, torch.float64, "stats")
+    lib = L.load()
+    L.check(lib.fpv_gae(T, n, _ptr(rewards), _ptr(values), _ptr(episode_starts), _ptr(last_values),
+                        _ptr(last_dones), float(gamma), float(lam), _ptr(advantages), _ptr(returns), _ptr(stats),
+                        _stream(rewards.device)), "fpv_gae")
+    return advantages, returns
+
+
+class RunningNorm:
+    """Running mean/var/count of a [N,d] stream with SB3 RunningMeanStd semantics (epsilon-count
+    start, parallel-variance merge) and VecNormalize's clip((x-mu)/sqrt(var+eps), +-clip)."""
+
+    def __init__(self, dim: int, device, clip: float = 10.0, eps: float = 1e-8, count_eps: float = 1e-4):
+        self.dim, self.clip, self.eps = int(dim), float(clip), float(eps)
+        self.rms = torch.zeros(2 * dim + 1, dtype=torch.float64, device=device)
+        self.rms[dim:2 * dim] = 1.0
+        self.rms[2 * dim] = count_eps
+        self.device = torch.device(device)
+
+    @property
+    def mean(self):
+        return self.rms[: self.dim]
+
+    @property
+    def var(self):
+        return self.rms[self.dim: 2 * self.dim]
+
+    @property
+    def count(self):
+        return self.rms[2 * self.dim]
+
+    def __call__(self, x, out=None, update=True):
+        _need(x, torch.float32, "x")
+        if x.shape[-1] != self.dim:
+            raise ValueError("last dimension must equal dim")
+        n = x.numel() // self.dim
+        if out is None:
+            out = torch.empty_like(x)
+        L.check(L.load().fpv_normalize(n, self.dim, _ptr(x), _ptr(out), _ptr(self.rms), 1 if update else 0,
+                                       self.clip, self.eps, _stream(x.device)), "fpv_normalize")
+        return out
+
+    def update_only(self, x):
+        _need(x, torch.float32, "x")
+        n = x.numel() // self.dim
+        L.check(L.load().fpv_normalize(n, self.dim, _ptr(x), C.c_void_p(0), _ptr(self.rms), 1, self.clip, self.eps,
+                                       _stream(x.device)), "fpv_normalize")
+
+
+class RewardNorm:
+    """VecNormalize reward path: discounted-return accumulator + running variance of it."""
+
+    def __init__(self, num_envs: int, device, gamma: float = 0.99, clip: float = 10.0, eps: float = 1e-8,
+                 count_eps: float = 1e-4):
+        self.gamma, self.clip, self.eps = float(gamma), float(clip), float(eps)
+        self.ret = torch.zeros(num_envs, dtype=torch.float32, device=device)
+        self.rms = torch.tensor([0.0, 1.0, count_eps], dtype=torch.float64, device=device)
+
+    def __call__(self, r, done, out=None, update=True):
+        _need(r, torch.float32, "r")
+        _need(done, torch.uint8, "done")
+        if out is None:
+            out = torch.empty_like(r)
+        L.check(L.load().fpv_normalize_reward(r.numel(), _ptr(r), _ptr(done), _ptr(self.ret), _ptr(out),
+                                              _ptr(self.rms), 1 if update else 0, self.gamma, self.clip, self.eps,
+                                              _stream(r.device)), "fpv_normalize_reward")
+        return out

@@ -1,0 +1,60 @@
+"""Actor-critic policy of the PPO rollout (SB3 MlpPolicy shape).
+
+The reference's only stated architecture is net_arch=[128, 128] (simulation/train_hover.py:57);
+north_star asks for PPO, so this is SB3's PPO MlpPolicy: separate tanh trunks for pi and V,
+a state-independent log-std, orthogonal init (gain sqrt 2 trunks, 0.01 action head, 1 value
+head).  torch.nn holds the parameters (autograd for the update); the rollout-time forward can
+run either through torch (rocBLAS GEMMs) or through the fused HIP kernel (ops_policy).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+LOG_2PI = math.log(2.0 * math.pi)
+
+
+class ActorCritic(nn.Module):
+    def __init__(self, obs_dim: int = 20, act_dim: int = 4, hidden: int = 128, log_std_init: float = 0.0):
+        super().__init__()
+        self.obs_dim, self.act_dim, self.hidden = obs_dim, act_dim, hidden
+        self.pi = nn.Sequential(nn.Linear(obs_dim, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh())
+        self.vf = nn.Sequential(nn.Linear(obs_dim, hidden), nn.Tanh(), nn.Linear(hidden, hidden), nn.Tanh())
+        self.action_net = nn.Linear(hidden, act_dim)
+        self.value_net = nn.Linear(hidden, 1)
+        self.log_std = nn.Parameter(torch.full((act_dim,), float(log_std_init)))
+        for seq in (self.pi, self.vf):
+            for m in seq:
+                if isinstance(m, nn.Linear):
+                    nn.init.orthogonal_(m.weight, gain=math.sqrt(2.0))
+                    nn.init.zeros_(m.bias)
+        nn.init.orthogonal_(self.action_net.weight, gain=0.01)
+        nn.init.zeros_(self.action_net.bias)
+        nn.init.orthogonal_(self.value_net.weight, gain=1.0)
+        nn.init.zeros_(self.value_net.bias)
+
+    def mean_value(self, obs: torch.Tensor):
+        return self.action_net(self.pi(obs)), self.value_net(self.vf(obs)).squeeze(-1)
+
+    def value(self, obs: torch.Tensor):
+        return self.value_net(self.vf(obs)).squeeze(-1)
+
+    def log_prob(self, mean: torch.Tensor, actions: torch.Tensor):
+        z = (actions - mean) * torch.exp(-self.log_std)
+        return (-0.5 * z * z - self.log_std - 0.5 * LOG_2PI).sum(-1)
+
+    @torch.no_grad()
+    def act(self, obs: torch.Tensor, eps: torch.Tensor):
+        """Sample a = mu + sigma * eps.  Returns (action, value, log_prob); the env receives clip(a, -1, 1)."""
+        mean, value = self.mean_value(obs)
+        action = mean + torch.exp(self.log_std) * eps
+        logp = (-0.5 * eps * eps - self.log_std - 0.5 * LOG_2PI).sum(-1)
+        return action, value, logp
+
+    def evaluate(self, obs: torch.Tensor, actions: torch.Tensor):
+        mean, value = self.mean_value(obs)
+        logp = self.log_prob(mean, actions)
+        entropy = (0.5 + 0.5 * LOG_2PI + self.log_std).sum().expand_as(logp)
+        return value, logp, entropy

@@ -1,0 +1,166 @@
+"""On-device PPO rollout collector: observations, actions, rewards and values never leave HBM.
+
+Semantics follow SB3's OnPolicyAlgorithm.collect_rollouts over VecNormalize(VecEnv) — the
+stack simulation/train_hover.py:42-60 builds — as restated in SURVEY.md §3.5:
+
+    obs_t (normalised) -> actor-critic -> a_t ~ N(mu, sigma), v_t, log-prob
+    env.step(clip(a_t, -1, 1)) -> r_t, done_t            (fpv_step, auto-reset, done ledger)
+    VecNormalize: obs running moments + clip, reward / sqrt(var(discounted return)) + clip
+    truncated & not terminated: r_t += gamma * V(normalised terminal observation)
+    GAE backward scan per env (fpv_gae) -> advantages, returns, {count, sum, sum^2}
+    ONE all-gather of those statistics per update -> global advantage mean / std
+
+Every per-step operation is asynchronous device work on one stream; the T-step loop is
+captured once into a HIP graph and replayed, so the host issues one launch per rollout.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import dist as D
+from . import ops
+from .engine import FpvEngine
+from .policy import ActorCritic
+
+
+class RolloutCollector:
+    def __init__(self, engine: FpvEngine, policy: ActorCritic, n_steps: int = 32, gamma: float = 0.99,
+                 lam: float = 0.95, norm_obs: bool = True, norm_reward: bool = True, use_graph: bool = True,
+                 clip_obs: float = 10.0, clip_reward: float = 10.0):
+        if engine.dtype != torch.float32:
+            raise ValueError("the rollout collector runs on an fp32 engine")
+        self.engine, self.policy = engine, policy
+        self.T, self.N = int(n_steps), engine.num_envs
+        self.gamma, self.lam = float(gamma), float(lam)
+        self.norm_obs, self.norm_reward = bool(norm_obs), bool(norm_reward)
+        self.use_graph = bool(use_graph)
+        dev = self.device = engine.device
+        T, N = self.T, self.N
+        f32, u8 = torch.float32, torch.uint8
+        self.obs_norm = ops.RunningNorm(20, dev, clip=clip_obs)
+        self.rew_norm = ops.RewardNorm(N, dev, gamma=gamma, clip=clip_reward)
+        self.buf_obs = torch.zeros((T, N, 20), dtype=f32, device=dev)
+        self.buf_act = torch.zeros((T, N, 4), dtype=f32, device=dev)
+        self.buf_rew = torch.zeros((T, N), dtype=f32, device=dev)
+        self.buf_start = torch.zeros((T, N), dtype=u8, device=dev)
+        self.buf_val = torch.zeros((T, N), dtype=f32, device=dev)
+        self.buf_logp = torch.zeros((T, N), dtype=f32, device=dev)
+        self.adv = torch.zeros((T, N), dtype=f32, device=dev)
+        self.ret = torch.zeros((T, N), dtype=f32, device=dev)
+        self.cur_obs = torch.zeros((N, 20), dtype=f32, device=dev)       # normalised s_t
+        self.episode_start = torch.ones((N,), dtype=u8, device=dev)
+        self.done = torch.zeros((N,), dtype=u8, device=dev)
+        self.clipped = torch.zeros((N, 4), dtype=f32, device=dev)
+        self.last_val = torch.zeros((N,), dtype=f32, device=dev)
+        self.rms_hist = torch.zeros((T, 41), dtype=torch.float64, device=dev)
+        self.stats = torch.zeros((3,), dtype=torch.float64, device=dev)
+        self._graph = None
+        self._tick0 = 0
+        self._started = False
+        self.adv_mean = self.adv_std = None
+        self.episodes = {"count": 0, "ep_return": None, "ep_len": None}
+
+    # ------------------------------------------------------------------ one vectorised step
+    def _normalise_obs(self, raw, out, update=True):
+        if self.norm_obs:
+            self.obs_norm(raw, out=out, update=update)
+        else:
+            out.copy_(raw)
+
+    def _step(self, t: int) -> None:
+        eng, pol = self.engine, self.policy
+        self.buf_obs[t].copy_(self.cur_obs)
+        self.buf_start[t].copy_(self.episode_start)
+        eps = torch.randn((self.N, 4), dtype=torch.float32, device=self.device)
+        action, value, logp = pol.act(self.cur_obs, eps)
+        self.buf_act[t].copy_(action)
+        self.buf_val[t].copy_(value)
+        self.buf_logp[t].copy_(logp)
+        torch.clamp(action, -1.0, 1.0, out=self.clipped)       # SB3 clips to the Box before env.step
+        eng.step(self.clipped)
+        torch.bitwise_or(eng.terminated, eng.truncated, out=self.done)
+        self._normalise_obs(eng.obs, self.cur_obs)
+        self.rms_hist[t].copy_(self.obs_norm.rms)
+        if self.norm_reward:
+            self.rew_norm(eng.reward, self.done, out=self.buf_rew[t])
+        else:
+            self.buf_rew[t].copy_(eng.reward)
+        self.episode_start.copy_(self.done)
+
+    def _all_steps(self) -> None:
+        for t in range(self.T):
+            self._step(t)
+
+    # ------------------------------------------------------------------ public API
+    def start(self) -> None:
+        """VecNormalize.reset(): reset every drone, fold the first observation into the statistics."""
+        self.engine.reset()
+        self._normalise_obs(self.engine.obs, self.cur_obs)
+        self.rew_norm.ret.zero_()
+        self.episode_start.fill_(1)
+        self._tick0 = self.engine.get_tick()
+        self._started = True
+
+    def _capture(self) -> None:
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):       # warm-up outside capture: lazy allocations, rocBLAS handles
+            self._step(0)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        self._tick0 += 1
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._all_steps()
+        self._graph = g
+
+    def collect(self) -> dict:
+        """Collect T steps from every drone, compute GAE and the global advantage statistics."""
+        if not self._started:
+            self.start()
+        eng = self.engine
+        if self.use_graph and self._graph is None:
+            self._capture()
+        eng.ledger_clear()
+        if self.use_graph:
+            self._graph.replay()
+        else:
+            self._all_steps()
+        with torch.no_grad():
+            self.last_val.copy_(self.policy.value(self.cur_obs))
+        self._bootstrap_timeouts()
+        ops.gae(self.buf_rew, self.buf_val, self.buf_start, self.last_val, self.episode_start, self.gamma,
+                self.lam, advantages=self.adv, returns=self.ret, stats=self.stats)
+        gathered = D.allgather_payload(self.stats)          # the one collective per update
+        self.adv_mean, self.adv_std = D.merge_advantage_stats(gathered)
+        self._tick0 += self.T
+        return {"obs": self.buf_obs, "actions": self.buf_act, "values": self.buf_val, "log_probs": self.buf_logp,
+                "advantages": self.adv, "returns": self.ret, "adv_mean": self.adv_mean, "adv_std": self.adv_std}
+
+    def _bootstrap_timeouts(self) -> None:
+        """r_t += gamma * V(terminal obs) for truncated-but-not-terminated episode ends; also harvests
+        the Monitor-style episode statistics from the done ledger.  One host read of the row count."""
+        eng = self.engine
+        total = int(eng.led_count.item())
+        c = min(total, eng.ledger_capacity)
+        self.episodes = {"count": total, "ep_return": eng.led_ret[:c], "ep_len": eng.led_info[:c] >> 8}
+        if c == 0:
+            return
+        info = eng.led_info[:c]
+        sel = ((info & 2) != 0) & ((info & 1) == 0)
+        rows = torch.nonzero(sel, as_tuple=False).squeeze(1)
+        if rows.numel() == 0:
+            return
+        t_idx = (eng.led_tag[rows].to(torch.int64) - (self._tick0 & 0xFFFFFFFF)) & 0xFFFFFFFF
+        if int(t_idx.max()) >= self.T:
+            raise RuntimeError("done-ledger tag outside this rollout: tick bookkeeping is out of sync")
+        d_idx = eng.led_idx[rows].to(torch.int64)
+        tobs = eng.led_obs[rows]
+        if self.norm_obs:
+            rms = self.rms_hist[t_idx]                      # statistics as they were at that step
+            mean, var = rms[:, :20], rms[:, 20:40]
+            tobs = torch.clamp((tobs.double() - mean) / torch.sqrt(var + self.obs_norm.eps), -self.obs_norm.clip,
+                               self.obs_norm.clip).float()
+        with torch.no_grad():
+            v = self.policy.value(tobs)
+        self.buf_rew.index_put_((t_idx, d_idx), self.gamma * v, accumulate=True)

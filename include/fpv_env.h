@@ -99,8 +99,9 @@ int fpv_step_f64(fpv_env* env, const double* actions, double* obs, double* rewar
 int fpv_get_state(fpv_env* env, void* state_out, void* stream);
 int fpv_set_state(fpv_env* env, const void* state_in, void* stream);
 
-/* Agent-tick counter that keys the motor-noise RNG (device resident so that fpv_step can be
- * captured into a HIP graph).  These two synchronise the stream. */
+/* Agent-tick counter that keys the motor-noise RNG.  It lives on the device (one copy per
+ * 64-drone tile, advanced by the step kernel itself) so that fpv_step is a single kernel and
+ * can be captured into a HIP graph.  These two synchronise the stream. */
 int fpv_set_tick(fpv_env* env, uint64_t tick, void* stream);
 int fpv_get_tick(fpv_env* env, uint64_t* tick_host, void* stream);
 

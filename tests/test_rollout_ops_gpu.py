@@ -1,0 +1,80 @@
+"""GPU parity of the rollout primitives (GAE, VecNormalize moments) against the oracle."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("T,n", [(1, 1), (5, 7), (32, 4096), (16, 70001)])
+def test_gae_matches_oracle(oracle, T, n):
+    from fpv_drone_rl_agent_amd import ops
+    rng = np.random.default_rng(T * 1000 + n)
+    r = rng.normal(size=(T, n)).astype(np.float32)
+    v = rng.normal(size=(T, n)).astype(np.float32)
+    es = (rng.random((T, n)) < 0.1).astype(np.uint8)
+    lv = rng.normal(size=n).astype(np.float32)
+    ld = (rng.random(n) < 0.1).astype(np.uint8)
+    adv_r, ret_r = oracle.gae(r, v, es, lv, ld, 0.99, 0.95)
+    stats = torch.zeros(3, dtype=torch.float64, device="cuda")
+    adv, ret = ops.gae(*(torch.from_numpy(x).cuda() for x in (r, v, es, lv, ld)), 0.99, 0.95, stats=stats)
+    assert np.allclose(adv.cpu().numpy(), adv_r, atol=2e-5, rtol=1e-5)
+    assert np.allclose(ret.cpu().numpy(), ret_r, atol=2e-5, rtol=1e-5)
+    s = stats.cpu().numpy()
+    a64 = adv.cpu().numpy().astype(np.float64)
+    assert s[0] == T * n and np.isclose(s[1], a64.sum(), rtol=1e-12, atol=1e-9)
+    assert np.isclose(s[2], (a64 * a64).sum(), rtol=1e-12)
+
+
+def test_gae_is_bitwise_reproducible():
+    from fpv_drone_rl_agent_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(1)
+    r = torch.randn(8, 50000, device="cuda", generator=g)
+    v = torch.randn(8, 50000, device="cuda", generator=g)
+    es = torch.zeros(8, 50000, dtype=torch.uint8, device="cuda")
+    lv = torch.randn(50000, device="cuda", generator=g)
+    ld = torch.zeros(50000, dtype=torch.uint8, device="cuda")
+    s1 = torch.zeros(3, dtype=torch.float64, device="cuda")
+    s2 = torch.zeros(3, dtype=torch.float64, device="cuda")
+    a1, _ = ops.gae(r, v, es, lv, ld, stats=s1)
+    a2, _ = ops.gae(r, v, es, lv, ld, stats=s2)
+    assert torch.equal(a1, a2) and torch.equal(s1, s2)
+
+
+@pytest.mark.parametrize("n,d", [(1, 20), (333, 20), (65536, 20), (1000, 12)])
+def test_running_norm_matches_vecnormalize(oracle, n, d):
+    from fpv_drone_rl_agent_amd import ops
+    rng = np.random.default_rng(n + d)
+    ref = oracle.RunningMeanStd((d,))
+    rn = ops.RunningNorm(d, "cuda")
+    for it in range(3):
+        x = (rng.normal(size=(n, d)) * rng.uniform(0.1, 30, d) + rng.uniform(-5, 5, d)).astype(np.float32)
+        ref.update(x)
+        y_ref = np.clip((x - ref.mean) / np.sqrt(ref.var + 1e-8), -10, 10)
+        y = rn(torch.from_numpy(x).cuda())
+        assert np.allclose(rn.mean.cpu().numpy(), ref.mean, rtol=1e-10, atol=1e-10)
+        assert np.allclose(rn.var.cpu().numpy(), ref.var, rtol=1e-9, atol=1e-12)
+        assert np.isclose(float(rn.count), ref.count)
+        assert np.allclose(y.cpu().numpy(), y_ref, atol=2e-5, rtol=1e-5)
+    # frozen statistics (test_hover.py:9 training=False)
+    x = rng.normal(size=(n, d)).astype(np.float32)
+    before = rn.rms.clone()
+    y = rn(torch.from_numpy(x).cuda(), update=False)
+    assert torch.equal(before, rn.rms)
+    assert np.allclose(y.cpu().numpy(), np.clip((x - ref.mean) / np.sqrt(ref.var + 1e-8), -10, 10), atol=2e-5)
+
+
+def test_reward_norm_matches_vecnormalize(oracle):
+    from fpv_drone_rl_agent_amd import ops
+    n = 5000
+    rng = np.random.default_rng(5)
+    ref = oracle.VecNormalizeRef(n)
+    rw = ops.RewardNorm(n, "cuda")
+    for it in range(6):
+        r = rng.normal(size=n).astype(np.float32) * 3
+        done = (rng.random(n) < 0.2)
+        _, r_ref = ref.step(np.zeros((n, 20)), r.astype(np.float64), done)
+        out = rw(torch.from_numpy(r).cuda(), torch.from_numpy(done.astype(np.uint8)).cuda())
+        assert np.allclose(out.cpu().numpy(), r_ref, atol=2e-5, rtol=1e-5)
+        assert np.allclose(rw.ret.cpu().numpy(), ref.returns, atol=1e-4, rtol=1e-5)
+        assert np.isclose(float(rw.rms[1]), ref.ret_rms.var, rtol=1e-6)
