@@ -11,7 +11,7 @@
 namespace fpv {
 
 constexpr int kRedBlock = 256;
-constexpr int kMaxRedBlocks = 1024;
+constexpr int kMaxRedBlocks = 256;
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -66,10 +66,17 @@ __global__ __launch_bounds__(kRedBlock) void gae_kernel(int64_t T, int64_t n, co
     }
 }
 
-__global__ void gae_stats_kernel(const double* __restrict__ partial, int blocks, double count, double* stats) {
-    if (threadIdx.x != 0) return;
+__global__ __launch_bounds__(64) void gae_stats_kernel(const double* __restrict__ partial, int blocks, double count,
+                                                       double* stats) {
+    __shared__ double l1[64], l2[64];
     double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < blocks; ++b) { s1 += partial[2 * b]; s2 += partial[2 * b + 1]; }
+    for (int b = threadIdx.x; b < blocks; b += 64) { s1 += partial[2 * b]; s2 += partial[2 * b + 1]; }
+    l1[threadIdx.x] = s1;
+    l2[threadIdx.x] = s2;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    s1 = 0.0; s2 = 0.0;
+    for (int w = 0; w < 64; ++w) { s1 += l1[w]; s2 += l2[w]; }
     stats[0] = count; stats[1] = s1; stats[2] = s2;
 }
 
@@ -110,15 +117,28 @@ __global__ void moments_partial_kernel(int64_t total, int d, const float* __rest
     }
 }
 
-// SB3 RunningMeanStd.update_from_moments (parallel-variance merge), one thread per channel
-__global__ void moments_merge_kernel(const double* __restrict__ partial, int blocks, int d, double batch_count,
-                                     double* rms /* mean[d], var[d], count */) {
-    const int c = threadIdx.x;
+// SB3 RunningMeanStd.update_from_moments (parallel-variance merge).  kMergeWays threads per
+// channel walk the partial table in a fixed interleave, then one of them folds the kMergeWays
+// sums in order: deterministic, and ~blocks / kMergeWays dependent loads deep instead of blocks.
+constexpr int kMergeWays = 16;
+__global__ __launch_bounds__(32 * kMergeWays) void moments_merge_kernel(const double* __restrict__ partial, int blocks,
+                                                                        int d, double batch_count,
+                                                                        double* rms /* mean[d], var[d], count */) {
+    __shared__ double l1[32 * kMergeWays], l2[32 * kMergeWays];
+    const int c = threadIdx.x % 32, j = threadIdx.x / 32;
     const double count = rms[2 * d];
+    double s1 = 0.0, s2 = 0.0;
+    if (c < d)
+        for (int b = j; b < blocks; b += kMergeWays) {
+            s1 += partial[(int64_t)b * 2 * d + c];
+            s2 += partial[(int64_t)b * 2 * d + d + c];
+        }
+    l1[threadIdx.x] = s1;
+    l2[threadIdx.x] = s2;
     __syncthreads();
-    if (c < d) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int b = 0; b < blocks; ++b) { s1 += partial[(int64_t)b * 2 * d + c]; s2 += partial[(int64_t)b * 2 * d + d + c]; }
+    if (j == 0 && c < d) {
+        s1 = 0.0; s2 = 0.0;
+        for (int w = 0; w < kMergeWays; ++w) { s1 += l1[w * 32 + c]; s2 += l2[w * 32 + c]; }
         const double bm = s1 / batch_count;
         double bv = s2 / batch_count - bm * bm;
         if (bv < 0.0) bv = 0.0;
@@ -127,7 +147,7 @@ __global__ void moments_merge_kernel(const double* __restrict__ partial, int blo
         rms[c] = mean + delta * batch_count / tot;
         rms[d + c] = (var * count + bv * batch_count + delta * delta * count * batch_count / tot) / tot;
     }
-    if (c == 0) rms[2 * d] = count + batch_count;
+    if (threadIdx.x == 0) rms[2 * d] = count + batch_count;
 }
 
 __global__ void normalize_apply_kernel(int64_t total, int d, const float* __restrict__ x, float* __restrict__ y,
@@ -161,8 +181,8 @@ hipError_t launch_normalize(int64_t n, int32_t d, const float* x, float* y, doub
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(moments_partial_kernel, dim3((unsigned)blocks), dim3(block), 2 * block * sizeof(double), s,
                            total, (int)d, x, scratch);
-        hipLaunchKernelGGL(moments_merge_kernel, dim3(1), dim3(64), 0, s, scratch, (int)blocks, (int)d, (double)n,
-                           rms);
+        hipLaunchKernelGGL(moments_merge_kernel, dim3(1), dim3(32 * kMergeWays), 0, s, scratch, (int)blocks, (int)d,
+                           (double)n, rms);
     }
     if (y) {
         int64_t blocks = (total + 256 * 4 - 1) / (256 * 4);
@@ -210,7 +230,8 @@ hipError_t launch_normalize_reward(int64_t n, const float* r, const uint8_t* don
         hipLaunchKernelGGL(return_update_kernel, dim3((unsigned)blocks), dim3(kRedBlock), 0, s, n, r, ret, gamma,
                            scratch);
         // a [blocks][2] partial table is the d = 1 case of the obs merge
-        hipLaunchKernelGGL(moments_merge_kernel, dim3(1), dim3(64), 0, s, scratch, (int)blocks, 1, (double)n, rms);
+        hipLaunchKernelGGL(moments_merge_kernel, dim3(1), dim3(32 * kMergeWays), 0, s, scratch, (int)blocks, 1, (double)n,
+                           rms);
     }
     hipLaunchKernelGGL(reward_apply_kernel, dim3((unsigned)blocks), dim3(kRedBlock), 0, s, n, r, done, ret, r_out, rms,
                        clip, eps);
