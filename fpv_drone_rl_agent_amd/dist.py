@@ -47,9 +47,9 @@ def allgather_payload(payload: torch.Tensor) -> torch.Tensor:
     w = world_size()
     if w == 1:
         return payload.unsqueeze(0)
-    out = torch.empty((w, payload.numel()), dtype=torch.float64, device=payload.device)
-    td.all_gather_into_tensor(out, payload.contiguous())
-    return out
+    out = torch.empty((w * payload.numel(),), dtype=torch.float64, device=payload.device)
+    td.all_gather_into_tensor(out, payload.contiguous())   # flat output: accepted by RCCL and gloo alike
+    return out.view(w, payload.numel())
 
 
 def merge_advantage_stats(gathered: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:

@@ -1,0 +1,73 @@
+"""world_size-2 gloo run of the one collective on the rollout path: every rank ends up
+with the same global advantage mean/std and merged VecNormalize moments as a single process over the
+union of the shards."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as td
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from fpv_drone_rl_agent_amd import dist as D
+    r, w, _ = D.init_from_env("gloo")
+    assert (r, w) == (rank, world) and D.world_size() == world and D.rank() == rank
+    rng = np.random.default_rng(100 + rank)
+    adv = rng.normal(rank, 1.0 + rank, 1000 * (rank + 1))          # this shard's advantages
+    obs = rng.normal(size=(200 * (rank + 1), 20)) * (1 + rank)      # this shard's observations
+    payload = torch.tensor([adv.size, adv.sum(), (adv * adv).sum(), *obs.mean(0), *obs.var(0), obs.shape[0]],
+                           dtype=torch.float64)                     # 44 words: a single collective
+    g = D.allgather_payload(payload)
+    mean, std = D.merge_advantage_stats(g)
+    m, v, c = D.merge_moments(g[:, 3:23], g[:, 23:43], g[:, 43])
+    q.put((rank, float(mean), float(std), m.numpy(), v.numpy(), float(c)))
+    td.barrier()
+    td.destroy_process_group()
+
+
+def test_two_rank_allgather_matches_single_process():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    advs = [np.random.default_rng(100 + r).normal(r, 1.0 + r, 1000 * (r + 1)) for r in range(world)]
+    obss = []
+    for r in range(world):
+        rng = np.random.default_rng(100 + r)
+        rng.normal(r, 1.0 + r, 1000 * (r + 1))
+        obss.append(rng.normal(size=(200 * (r + 1), 20)) * (1 + r))
+    a, o = np.concatenate(advs), np.concatenate(obss)
+    for rank, mean, std, m, v, c in res:
+        assert abs(mean - a.mean()) < 1e-12 and abs(std - a.std()) < 1e-10
+        assert np.allclose(m, o.mean(0)) and np.allclose(v, o.var(0)) and c == o.shape[0]
+    # bitwise identical on every rank (fixed summation order)
+    assert res[0][1:3] == res[1][1:3] and np.array_equal(res[0][3], res[1][3])
+
+
+def test_single_process_passthrough():
+    from fpv_drone_rl_agent_amd import dist as D
+    p = torch.tensor([10.0, 5.0, 30.0], dtype=torch.float64)
+    g = D.allgather_payload(p)
+    assert g.shape == (1, 3)
+    mean, std = D.merge_advantage_stats(g)
+    assert float(mean) == 0.5 and abs(float(std) - (3.0 - 0.25) ** 0.5) < 1e-12

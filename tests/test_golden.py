@@ -1,0 +1,73 @@
+"""Committed golden vectors (tests/golden/hover_step_v1.npz, made by tests/golden/make_golden.py from
+the oracle): the oracle must keep reproducing them (CPU), and the HIP path must match them (GPU).
+They pin the build's SPEC; parity with PyFlyt/pybullet is unpinned."""
+import os
+
+import numpy as np
+import pytest
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "hover_step_v1.npz"))
+
+
+def test_oracle_reproduces_golden_single_step(oracle):
+    st = G["a_state_in"].copy()
+    noise, seed, off, tick = G["a_meta"]
+    cfg = oracle.make_cfg(noise_ratio=float(noise), seed=int(seed), id_offset=int(off))
+    obs, rew, term, trunc, led = oracle.step_batch(cfg, st, G["a_action"], int(tick))
+    assert (term == G["a_term"]).all() and (trunc == G["a_trunc"]).all()
+    assert term.sum() >= 16 and trunc.sum() >= 8
+    assert np.allclose(st, G["a_state_out"], rtol=1e-12, atol=1e-12)
+    assert np.allclose(obs, G["a_obs"], rtol=1e-12, atol=1e-12)
+    assert np.allclose(rew, G["a_reward"], rtol=1e-12, atol=1e-12)
+    assert (led.rows()[0] == G["a_led_idx"]).all() and (led.rows()[1] == G["a_led_info"]).all()
+
+
+def test_oracle_reproduces_golden_trajectory(oracle):
+    st, obs0 = oracle.reset_states(8)
+    assert np.allclose(obs0, G["b_obs0"], atol=1e-12)
+    cfg = oracle.make_cfg(noise_ratio=0.0, seed=0)
+    for t in range(G["b_actions"].shape[0]):
+        o, r, te, tu, _ = oracle.step_batch(cfg, st, G["b_actions"][t], t)
+        assert ((te | (tu << 1)) == G["b_flags"][t]).all()
+        assert np.allclose(o, G["b_obs"][t], rtol=1e-10, atol=1e-10)
+        assert np.allclose(r, G["b_reward"][t], rtol=1e-10, atol=1e-10)
+    assert G["b_flags"].any()  # the trajectory contains episode ends and auto-resets
+    assert np.allclose(st, G["b_state_out"], rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.gpu
+def test_hip_matches_golden_single_step():
+    import torch
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    noise, seed, off, tick = G["a_meta"]
+    eng = FpvEngine(256, 0, noise_ratio=float(noise), seed=int(seed), id_offset=int(off))
+    eng.set_state(torch.from_numpy(G["a_state_in"].astype(np.float32)))
+    eng.set_tick(int(tick))
+    obs, rew, term, trunc = eng.step(torch.from_numpy(G["a_action"].astype(np.float32)).cuda())
+    assert (term.cpu().numpy() == G["a_term"]).all() and (trunc.cpu().numpy() == G["a_trunc"]).all()
+    st, ref = eng.get_state().cpu().numpy(), G["a_state_out"]
+    assert (np.abs(st - ref) <= 1e-5 * np.maximum(1, np.abs(ref))).all()
+    tol = np.full(20, 1e-5); tol[0:3] = 4e-4
+    o, oref = obs.cpu().numpy(), G["a_obs"]
+    assert (np.abs(o - oref) <= tol * np.maximum(1, np.abs(oref))).all()
+    led = eng.ledger_read()
+    assert (led["idx"] == G["a_led_idx"]).all() and (led["info"] == G["a_led_info"]).all()
+    assert np.allclose(led["obs"], G["a_led_obs"], atol=4e-4, rtol=1e-5)
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_hip_fp64_matches_golden_trajectory():
+    import torch
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    eng = FpvEngine(8, 0, noise_ratio=0.0, precision="f64")
+    obs0 = eng.reset()
+    assert np.allclose(obs0.cpu().numpy(), G["b_obs0"], atol=1e-12)
+    for t in range(G["b_actions"].shape[0]):
+        o, r, te, tu = eng.step(torch.from_numpy(G["b_actions"][t]).cuda())
+        flags = te.cpu().numpy() | (tu.cpu().numpy() << 1)
+        assert (flags == G["b_flags"][t]).all(), t
+        assert np.allclose(o.cpu().numpy(), G["b_obs"][t], rtol=1e-9, atol=1e-9), t
+        assert np.allclose(r.cpu().numpy(), G["b_reward"][t], rtol=1e-9, atol=1e-9), t
+    assert np.allclose(eng.get_state().cpu().numpy(), G["b_state_out"], rtol=1e-9, atol=1e-9)
+    eng.close()
