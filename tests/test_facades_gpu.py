@@ -1,0 +1,167 @@
+"""GPU tests of the reference-shaped surfaces and of the whole on-device rollout
+against an oracle replay (env via oracle/fpv_oracle.c, VecNormalize/GAE via the numpy/C restatements,
+policy via the same torch module on the CPU)."""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def test_single_env_protocol(oracle):
+    from fpv_drone_rl_agent_amd.hover import QuadXHoverEnv
+    env = QuadXHoverEnv(noise_ratio=0.0)
+    obs, info = env.reset(seed=1)
+    assert obs.shape == (20,) and obs.dtype == np.float64
+    assert info == {"out_of_bounds": False, "collision": False, "env_complete": False, "on_floor": False}
+    st_ref, obs_ref = oracle.reset_states(1)
+    assert np.allclose(obs, obs_ref[0], atol=1e-5)
+    cfg = oracle.make_cfg(noise_ratio=0.0)
+    a = np.array([0.0, 0.0, 0.0, -1.0])
+    for call in range(1, 33):
+        o, r, term, trunc, info = env.step(a)
+        o_ref, r_ref, bits = oracle.step_one(cfg, st_ref[0], a, 0, call - 1)
+        assert isinstance(r, float) and isinstance(term, bool) and isinstance(trunc, bool)
+        assert np.allclose(o, o_ref, atol=4e-4) and abs(r - r_ref) < 1e-4
+        assert term == bool(bits & 1) and trunc == bool(bits & 2)
+    assert term and info["on_floor"] and not info["out_of_bounds"] and call == 32
+    obs, info = env.reset()
+    assert not info["on_floor"] and np.allclose(obs, obs_ref[0], atol=1e-5)
+    with pytest.raises(ValueError):
+        QuadXHoverEnv(flight_mode=6)
+    env.close()
+
+
+def test_vec_env_host_mode_matches_oracle(oracle):
+    from fpv_drone_rl_agent_amd.vec_env import make_vec_env
+    n = 16  # train_hover.py:41
+    env = make_vec_env(None, n_envs=n, noise_ratio=0.0)
+    obs = env.reset()
+    st, obs_ref = oracle.reset_states(n)
+    assert obs.shape == (n, 20) and obs.dtype == np.float32 and np.allclose(obs, obs_ref, atol=1e-5)
+    cfg = oracle.make_cfg(noise_ratio=0.0)
+    rng = np.random.default_rng(0)
+    saw_done = False
+    for t in range(45):
+        a = rng.uniform(-1, 1, (n, 4))
+        a[:, 3] = -1.0 if t < 35 else 0.9
+        o, r, d, infos = env.step(a)
+        o_ref, r_ref, te, tr, led = oracle.step_batch(cfg, st, a.astype(np.float32).astype(np.float64), t)
+        assert o.dtype == np.float32 and r.dtype == np.float32 and d.dtype == bool and len(infos) == n
+        assert (d == ((te | tr) > 0)).all()
+        assert np.allclose(o, o_ref, atol=4e-4) and np.allclose(r, r_ref, atol=1e-4)
+        for k, i in enumerate(led.rows()[0]):
+            saw_done = True
+            inf = infos[i]
+            assert np.allclose(inf["terminal_observation"], led.rows()[3][k], atol=4e-4)
+            assert inf["TimeLimit.truncated"] is False and inf["episode"]["l"] == 32 and inf["on_floor"]
+            assert abs(inf["episode"]["r"] - led.rows()[2][k]) < 1e-2
+        for i in np.nonzero(~d)[0]:
+            assert infos[i] == {}
+    assert saw_done
+    assert env.get_attr("max_steps") == [400] * n and env.env_is_wrapped(object) == [False] * n
+    env.close()
+
+
+def test_vecnormalize_matches_sb3_arithmetic_and_roundtrips(oracle, tmp_path):
+    from fpv_drone_rl_agent_amd.vec_env import FpvVecEnv, VecNormalize
+    n = 32
+    venv = VecNormalize(FpvVecEnv(n, noise_ratio=0.0), norm_obs=True, norm_reward=True)
+    ref = oracle.VecNormalizeRef(n)
+    st, obs_ref = oracle.reset_states(n)
+    o = venv.reset()
+    assert np.allclose(o, ref.reset(obs_ref), atol=1e-4)
+    cfg = oracle.make_cfg(noise_ratio=0.0)
+    rng = np.random.default_rng(1)
+    for t in range(40):
+        a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
+        o, r, d, infos = venv.step(a)
+        o_raw, r_raw, te, tr, _ = oracle.step_batch(cfg, st, a.astype(np.float64), t)
+        o_ref, r_ref = ref.step(o_raw, r_raw, (te | tr) > 0)
+        assert np.allclose(o, o_ref, atol=2e-3) and np.allclose(r, r_ref, atol=1e-4), t
+    path = os.path.join(tmp_path, "hover.pkl")            # train_hover.py:27 naming
+    venv.save(path)
+    loaded = VecNormalize.load(path, venv.venv)            # test_hover.py:8
+    loaded.training = False                                # test_hover.py:9-10
+    loaded.norm_reward = False
+    assert torch.equal(loaded.obs_rms.rms, venv.obs_rms.rms)
+    before = loaded.obs_rms.rms.clone()
+    o2, r2, d2, _ = loaded.step(np.zeros((n, 4), np.float32))
+    assert torch.equal(before, loaded.obs_rms.rms)         # frozen statistics
+    assert np.allclose(r2, venv.venv.engine.reward.cpu().numpy())  # raw rewards
+    venv.close()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_rollout_collector_matches_oracle_replay(oracle, use_graph):
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    from fpv_drone_rl_agent_amd.rollout import RolloutCollector
+    n, T, gamma, lam = 256, 8, 0.99, 0.95
+    torch.manual_seed(3)
+    pol = ActorCritic().cuda()
+    pol_cpu = copy.deepcopy(pol).cpu().double()
+    eng = FpvEngine(n, 0, noise_ratio=0.0)
+    col = RolloutCollector(eng, pol, n_steps=T, gamma=gamma, lam=lam, use_graph=use_graph)
+    col.start()
+    ref_norm = oracle.VecNormalizeRef(n, gamma=gamma)
+    _, obs_reset = oracle.reset_states(n)
+    ref_norm.reset(obs_reset)
+    st = oracle.synthetic_states(n, seed=9)
+    st[:40, 34] = np.random.default_rng(0).integers(395, 402, 40)   # truncations inside the rollout
+    st[40:60, 2] = 0.12; st[40:60, 9] = -1.0; st[40:60, 34] = 100   # floor terminations
+    st = st.astype(np.float32).astype(np.float64)
+    if use_graph:
+        col._capture()          # the capture warm-up consumes one env step; load the test state after it
+        tick0 = eng.get_tick()
+    eng.set_state(torch.from_numpy(st.astype(np.float32)))
+    if use_graph:
+        # statistics were touched by the warm-up step: re-sync the reference normaliser to the device state
+        rms = col.obs_norm.rms.cpu().numpy()
+        ref_norm.obs_rms.mean, ref_norm.obs_rms.var, ref_norm.obs_rms.count = rms[:20].copy(), rms[20:40].copy(), float(rms[40])
+        rr = col.rew_norm.rms.cpu().numpy()
+        ref_norm.ret_rms.mean, ref_norm.ret_rms.var, ref_norm.ret_rms.count = float(rr[0]), float(rr[1]), float(rr[2])
+        ref_norm.returns = col.rew_norm.ret.cpu().numpy().astype(np.float64)
+    else:
+        tick0 = eng.get_tick()
+    start0 = col.episode_start.cpu().numpy().copy()
+    out = col.collect()
+    torch.cuda.synchronize()
+
+    cfg = oracle.make_cfg(noise_ratio=0.0)
+    acts = col.buf_act.cpu().numpy().astype(np.float64)
+    rew_ref = np.zeros((T, n)); starts_ref = np.zeros((T, n), np.uint8); obs_n_ref = []
+    starts = start0
+    for t in range(T):
+        starts_ref[t] = starts
+        o_raw, r_raw, te, tr, led = oracle.step_batch(cfg, st, np.clip(acts[t], -1, 1), tick0 + t)
+        done = (te | tr) > 0
+        o_n, r_n = ref_norm.step(o_raw, r_raw, done)
+        idx, info, _, tobs = led.rows()
+        for k in range(len(idx)):                       # SB3 timeout bootstrap
+            if (info[k] & 2) and not (info[k] & 1):
+                tn = ref_norm.normalize_obs(tobs[k][None])
+                r_n[idx[k]] += gamma * float(pol_cpu.value(torch.from_numpy(tn))[0])
+        rew_ref[t] = r_n
+        obs_n_ref.append(o_n)
+        starts = done.astype(np.uint8)
+    assert starts_ref[1:].any() and (rew_ref != 0).all()
+    assert (col.buf_start.cpu().numpy() == starts_ref).all()
+    got_obs = col.buf_obs.cpu().numpy()
+    for t in range(1, T):
+        assert np.allclose(got_obs[t], obs_n_ref[t - 1], atol=3e-3), t
+    assert np.allclose(col.cur_obs.cpu().numpy(), obs_n_ref[-1], atol=3e-3)
+    assert np.allclose(col.buf_rew.cpu().numpy(), rew_ref, atol=2e-3)
+    # values / log-probs are the policy's; GAE and the advantage statistics through the oracle
+    with torch.no_grad():
+        v_cpu = pol_cpu.value(torch.from_numpy(got_obs.astype(np.float64))).numpy()
+    assert np.allclose(col.buf_val.cpu().numpy(), v_cpu, atol=1e-4)
+    adv_ref, ret_ref = oracle.gae(col.buf_rew.cpu().numpy(), col.buf_val.cpu().numpy(), starts_ref,
+                                  col.last_val.cpu().numpy(), starts, gamma, lam)
+    assert np.allclose(out["advantages"].cpu().numpy(), adv_ref, atol=1e-4)
+    assert np.allclose(out["returns"].cpu().numpy(), ret_ref, atol=1e-4)
+    assert abs(float(out["adv_mean"]) - adv_ref.mean()) < 1e-5 and abs(float(out["adv_std"]) - adv_ref.std()) < 1e-5
+    eng.close()

@@ -1,0 +1,43 @@
+"""Turn gpurun_out rocprofv3 outputs into the small tracked summaries under profiles/.
+usage: python tools/summarize_prof.py <tag> <kernel_stats_dir> [<pmc_fetch_dir> <pmc_write_dir>]"""
+import collections
+import csv
+import glob
+import json
+import shutil
+import sys
+
+
+def main():
+    tag, stats_dir = sys.argv[1], sys.argv[2]
+    src = glob.glob(f"{stats_dir}/**/*kernel_stats.csv", recursive=True)[0]
+    shutil.copy(src, f"profiles/{tag}_kernel_stats.csv")
+    out = {"tag": tag, "kernel_stats_csv": f"profiles/{tag}_kernel_stats.csv"}
+    rows = list(csv.DictReader(open(src)))
+    out["top"] = [{"name": r["Name"][:100], "calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 2),
+                   "pct": float(r["Percentage"])} for r in rows[:12]]
+    if len(sys.argv) >= 5:
+        pmc = {}
+        for name, d in (("FETCH_SIZE", sys.argv[3]), ("WRITE_SIZE", sys.argv[4])):
+            f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0]
+            acc = collections.defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] == name:
+                    acc[r["Kernel_Name"].split("(")[0][-60:]].append(float(r["Counter_Value"]))
+            pmc[name] = {k: {"launches": len(v), "mean_KB": round(sum(v) / len(v), 1)} for k, v in acc.items()
+                         if "fpv::" in k}
+        out["pmc_raw_KB_per_launch"] = pmc
+        out["pmc_note"] = ("rocprofv3 units are KB. MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reads exactly half the "
+                           "bytes of a wide coalesced streaming read -> doubled below; WRITE_SIZE is exact for 16-B-per-lane "
+                           "streaming stores.")
+        for k in pmc["FETCH_SIZE"]:
+            if "step_kernel" in k:
+                rd = 2 * pmc["FETCH_SIZE"][k]["mean_KB"] * 1024
+                wr = pmc["WRITE_SIZE"].get(k, {"mean_KB": 0})["mean_KB"] * 1024
+                out["step_kernel_hbm_bytes_per_launch"] = {"read_corrected": rd, "write": wr, "total": rd + wr}
+    json.dump(out, open(f"profiles/{tag}_summary.json", "w"), indent=1)
+    print(json.dumps(out, indent=1)[:1500])
+
+
+if __name__ == "__main__":
+    main()
