@@ -49,14 +49,13 @@ def cpu_baseline(n: int, seed: int, budget_s: float = 12.0):
     act = rng.uniform(-1, 1, (n, 4))
     cfg = orc.make_cfg(noise_ratio=0.02, seed=seed)
     orc.step_batch(cfg, st, act, 0, nthreads=threads)           # warms the thread pool
-    t0 = time.perf_counter()
-    orc.step_batch(cfg, st, act, 1, nthreads=threads)           # calibration step
-    one = time.perf_counter() - t0
-    steps = int(max(2, min(5000, budget_s / max(one, 1e-4))))
-    t0 = time.perf_counter()
-    for t in range(steps):
-        orc.step_batch(cfg, st, act, 2 + t, nthreads=threads)
-    dt = time.perf_counter() - t0
+    steps, t0 = 0, time.perf_counter()
+    while True:                                                 # bounded sample: ~budget_s of CPU work
+        orc.step_batch(cfg, st, act, 1 + steps, nthreads=threads)
+        steps += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or steps >= 100000:
+            break
     return {"value": n * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
             "sample": f"oracle/fpv_oracle.c env-step only (no policy), {n} drones x {steps} steps, "
                       f"OpenMP {threads} threads of {cores} host cores, {dt:.1f} s"}

@@ -25,7 +25,7 @@ class FpvConfig(C.Structure):
 
 class FpvLedger(C.Structure):
     _fields_ = [
-        ("capacity", C.c_int64), ("count", C.c_void_p), ("idx", C.c_void_p), ("info", C.c_void_p),
+        ("capacity", C.c_int64), ("rows_per_tile", C.c_int64), ("count", C.c_void_p), ("idx", C.c_void_p), ("info", C.c_void_p),
         ("tag", C.c_void_p), ("ep_return", C.c_void_p), ("obs", C.c_void_p),
     ]
 

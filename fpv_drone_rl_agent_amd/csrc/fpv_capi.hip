@@ -43,7 +43,8 @@ struct fpv_env {
     uint32_t* led_tag;
     void* led_ret;
     void* led_obs;
-    int64_t led_cap;
+    int64_t led_cap;     // tiles * led_rows
+    int64_t led_rows;    // rows per tile
     bool led_owned;
 };
 
@@ -74,7 +75,7 @@ static int step_impl(fpv_env* e, const T* actions, T* obs, T* reward, uint8_t* t
     a.tick = e->tick;
     a.tmpl = (const T*)e->tmpl;
     a.led_count = e->led_count; a.led_idx = e->led_idx; a.led_info = e->led_info; a.led_tag = e->led_tag;
-    a.led_ret = (T*)e->led_ret; a.led_obs = (T*)e->led_obs; a.led_cap = e->led_cap;
+    a.led_ret = (T*)e->led_ret; a.led_obs = (T*)e->led_obs; a.led_rows = e->led_rows;
     a.n = e->cfg.num_envs;
     a.seed = e->cfg.seed;
     a.id_offset = e->cfg.id_offset;
@@ -106,7 +107,11 @@ int fpv_create(const fpv_config* cfg, fpv_env** out) {
     e->cfg = *cfg;
     e->tiles = (cfg->num_envs + kTile - 1) / kTile;
     e->word = cfg->precision == FPV_F64 ? sizeof(double) : sizeof(float);
-    e->led_cap = cfg->ledger_capacity > 0 ? cfg->ledger_capacity : 2 * cfg->num_envs;
+    {
+        const int64_t want = cfg->ledger_capacity > 0 ? cfg->ledger_capacity : 2 * cfg->num_envs;
+        e->led_rows = (want + e->tiles - 1) / e->tiles;
+        e->led_cap = e->led_rows * e->tiles;
+    }
     e->led_owned = true;
     hipError_t err = hipSuccess;
     auto alloc = [&](void** p, size_t bytes) {
@@ -115,14 +120,14 @@ int fpv_create(const fpv_config* cfg, fpv_env** out) {
     alloc(&e->state, (size_t)e->tiles * kGranules * kTile * 4 * e->word);
     alloc(&e->tmpl, (size_t)(kStateWords + kObsWords) * e->word);
     alloc((void**)&e->tick, (size_t)e->tiles * sizeof(uint64_t));
-    alloc((void**)&e->led_count, sizeof(uint32_t));
+    alloc((void**)&e->led_count, (size_t)e->tiles * sizeof(uint32_t));
     alloc((void**)&e->led_idx, (size_t)e->led_cap * sizeof(int32_t));
     alloc((void**)&e->led_info, (size_t)e->led_cap * sizeof(uint32_t));
     alloc((void**)&e->led_tag, (size_t)e->led_cap * sizeof(uint32_t));
     alloc(&e->led_ret, (size_t)e->led_cap * e->word);
     alloc(&e->led_obs, (size_t)e->led_cap * kObsWords * e->word);
     if (err == hipSuccess) err = hipMemset(e->tick, 0, (size_t)e->tiles * sizeof(uint64_t));
-    if (err == hipSuccess) err = hipMemset(e->led_count, 0, sizeof(uint32_t));
+    if (err == hipSuccess) err = hipMemset(e->led_count, 0, (size_t)e->tiles * sizeof(uint32_t));
     if (err == hipSuccess)
         err = cfg->precision == FPV_F64 ? launch_init<double>(e->state, e->tmpl, cfg->num_envs, nullptr)
                                         : launch_init<float>(e->state, e->tmpl, cfg->num_envs, nullptr);
@@ -200,6 +205,7 @@ int fpv_get_tick(fpv_env* e, uint64_t* tick_host, void* stream) {
 int fpv_ledger_view(fpv_env* e, fpv_ledger* out) {
     if (!e || !out) return fail(FPV_ERR_ARG, "fpv_ledger_view: null argument");
     out->capacity = e->led_cap;
+    out->rows_per_tile = e->led_rows;
     out->count = e->led_count;
     out->idx = e->led_idx;
     out->info = e->led_info;
@@ -213,6 +219,8 @@ int fpv_ledger_bind(fpv_env* e, const fpv_ledger* b) {
     if (!e || !b) return fail(FPV_ERR_ARG, "fpv_ledger_bind: null argument");
     if (b->capacity <= 0 || !b->count || !b->idx || !b->info || !b->tag || !b->ep_return || !b->obs)
         return fail(FPV_ERR_ARG, "fpv_ledger_bind: every buffer and a positive capacity are required");
+    if (b->rows_per_tile <= 0 || b->capacity != b->rows_per_tile * e->tiles)
+        return fail(FPV_ERR_ARG, "fpv_ledger_bind: capacity must be rows_per_tile * %lld tiles", (long long)e->tiles);
     if (e->led_owned) {
         FPV_HIP(hipDeviceSynchronize());
         void* led[] = {e->led_count, e->led_idx, e->led_info, e->led_tag, e->led_ret, e->led_obs};
@@ -221,6 +229,7 @@ int fpv_ledger_bind(fpv_env* e, const fpv_ledger* b) {
         e->led_owned = false;
     }
     e->led_cap = b->capacity;
+    e->led_rows = b->rows_per_tile;
     e->led_count = b->count; e->led_idx = b->idx; e->led_info = b->info; e->led_tag = b->tag;
     e->led_ret = b->ep_return; e->led_obs = b->obs;
     return FPV_OK;
@@ -228,7 +237,7 @@ int fpv_ledger_bind(fpv_env* e, const fpv_ledger* b) {
 
 int fpv_ledger_clear(fpv_env* e, void* stream) {
     if (!e) return fail(FPV_ERR_ARG, "fpv_ledger_clear: null handle");
-    FPV_HIP(hipMemsetAsync(e->led_count, 0, sizeof(uint32_t), (hipStream_t)stream));
+    FPV_HIP(hipMemsetAsync(e->led_count, 0, (size_t)e->tiles * sizeof(uint32_t), (hipStream_t)stream));
     return FPV_OK;
 }
 

@@ -68,7 +68,7 @@ __device__ __forceinline__ float rcp_(float x) { return __builtin_amdgcn_rcpf(x)
 __device__ __forceinline__ double rcp_(double x) { return 1.0 / x; }
 __device__ __forceinline__ float rsqrt_(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ double rsqrt_(double x) { return 1.0 / sqrt(x); }
-__device__ __forceinline__ float sqrt_(float x) { return __fsqrt_rn(x); }
+__device__ __forceinline__ float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }  // v_sqrt_f32, 1 ulp
 __device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
 __device__ __forceinline__ float abs_(float x) { return fabsf(x); }
 __device__ __forceinline__ double abs_(double x) { return fabs(x); }
@@ -84,6 +84,29 @@ __device__ __forceinline__ float asin_(float x) { return asinf(x); }
 __device__ __forceinline__ double asin_(double x) { return asin(x); }
 __device__ __forceinline__ void sincos_(float x, float* s, float* c) { sincosf(x, s, c); }
 __device__ __forceinline__ void sincos_(double x, double* s, double* c) { sincos(x, s, c); }
+
+// sin and cos of a half Euler angle: |x| <= pi/2, so a branch-free odd/even polynomial (Taylor to
+// x^15 / x^14, truncation < 1e-9) replaces sincosf and its large-argument reduction path.
+__device__ __forceinline__ void sincos_half_(float x, float* s, float* c) {
+    const float x2 = x * x;
+    float ps = -1.0f / 1307674368000.0f;
+    ps = ps * x2 + 1.0f / 6227020800.0f;
+    ps = ps * x2 - 1.0f / 39916800.0f;
+    ps = ps * x2 + 1.0f / 362880.0f;
+    ps = ps * x2 - 1.0f / 5040.0f;
+    ps = ps * x2 + 1.0f / 120.0f;
+    ps = ps * x2 - 1.0f / 6.0f;
+    *s = x + x * (x2 * ps);
+    float pc = -1.0f / 87178291200.0f;
+    pc = pc * x2 + 1.0f / 479001600.0f;
+    pc = pc * x2 - 1.0f / 3628800.0f;
+    pc = pc * x2 + 1.0f / 40320.0f;
+    pc = pc * x2 - 1.0f / 720.0f;
+    pc = pc * x2 + 1.0f / 24.0f;
+    pc = pc * x2 - 0.5f;
+    *c = pc * x2 + 1.0f;
+}
+__device__ __forceinline__ void sincos_half_(double x, double* s, double* c) { sincos(x, s, c); }
 
 // sin(x)/x and cos(x) as even polynomials in x2 = x^2 for |x| <= 0.37 (|omega| <= 173 rad/s
 // after the state clamp => x = |omega| dt / 2 <= 0.361): no sqrt, no division, no branch.
@@ -147,36 +170,40 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// four N(0,1) draws for (seed, global drone id, sub-step tick)
-__device__ __forceinline__ void normal4(uint64_t seed, uint32_t drone, uint64_t tick, float (&g)[4]) {
+// eight N(0,1) draws for (seed, global drone id, sub-step pair): ga for the even sub-step, gb for the odd
+__device__ __forceinline__ void normal8(uint64_t seed, uint32_t drone, uint64_t pair, float (&ga)[4], float (&gb)[4]) {
     uint32_t x[4];
-    philox4x32_10(drone, (uint32_t)tick, (uint32_t)(tick >> 32), 0x46505631u, (uint32_t)seed,
+    philox4x32_10(drone, (uint32_t)pair, (uint32_t)(pair >> 32), 0x46505631u, (uint32_t)seed,
                   (uint32_t)(seed >> 32), x);
-    const float u0 = ((float)(x[0] >> 8) + 0.5f) * 5.9604644775390625e-8f;
-    const float u1 = ((float)(x[1] >> 8) + 0.5f) * 5.9604644775390625e-8f;
-    const float u2 = ((float)(x[2] >> 8) + 0.5f) * 5.9604644775390625e-8f;
-    const float u3 = ((float)(x[3] >> 8) + 0.5f) * 5.9604644775390625e-8f;
+    constexpr float k = 1.0f / 65536.0f;
     // -2 ln u = -2 ln2 log2 u ; v_sin_f32 / v_cos_f32 take their argument in revolutions
-    const float ra = __fsqrt_rn(-1.3862943611198906f * __log2f(u0));
-    const float rb = __fsqrt_rn(-1.3862943611198906f * __log2f(u2));
-    g[0] = ra * __builtin_amdgcn_cosf(u1);
-    g[1] = ra * __builtin_amdgcn_sinf(u1);
-    g[2] = rb * __builtin_amdgcn_cosf(u3);
-    g[3] = rb * __builtin_amdgcn_sinf(u3);
+    constexpr float m2ln2 = -1.3862943611198906f;
+    const float u0 = ((float)(x[0] & 0xFFFFu) + 0.5f) * k, u1 = ((float)(x[0] >> 16) + 0.5f) * k;
+    const float u2 = ((float)(x[1] & 0xFFFFu) + 0.5f) * k, u3 = ((float)(x[1] >> 16) + 0.5f) * k;
+    const float u4 = ((float)(x[2] & 0xFFFFu) + 0.5f) * k, u5 = ((float)(x[2] >> 16) + 0.5f) * k;
+    const float u6 = ((float)(x[3] & 0xFFFFu) + 0.5f) * k, u7 = ((float)(x[3] >> 16) + 0.5f) * k;
+    const float r0 = __builtin_amdgcn_sqrtf(m2ln2 * __log2f(u0)), r1 = __builtin_amdgcn_sqrtf(m2ln2 * __log2f(u2));
+    const float r2 = __builtin_amdgcn_sqrtf(m2ln2 * __log2f(u4)), r3 = __builtin_amdgcn_sqrtf(m2ln2 * __log2f(u6));
+    ga[0] = r0 * __builtin_amdgcn_cosf(u1); ga[1] = r0 * __builtin_amdgcn_sinf(u1);
+    ga[2] = r1 * __builtin_amdgcn_cosf(u3); ga[3] = r1 * __builtin_amdgcn_sinf(u3);
+    gb[0] = r2 * __builtin_amdgcn_cosf(u5); gb[1] = r2 * __builtin_amdgcn_sinf(u5);
+    gb[2] = r3 * __builtin_amdgcn_cosf(u7); gb[3] = r3 * __builtin_amdgcn_sinf(u7);
 }
-__device__ __forceinline__ void normal4(uint64_t seed, uint32_t drone, uint64_t tick, double (&g)[4]) {
+__device__ __forceinline__ void normal8(uint64_t seed, uint32_t drone, uint64_t pair, double (&ga)[4], double (&gb)[4]) {
     uint32_t x[4];
-    philox4x32_10(drone, (uint32_t)tick, (uint32_t)(tick >> 32), 0x46505631u, (uint32_t)seed,
+    philox4x32_10(drone, (uint32_t)pair, (uint32_t)(pair >> 32), 0x46505631u, (uint32_t)seed,
                   (uint32_t)(seed >> 32), x);
-    double u[4];
+    double u[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) u[j] = ((double)(x[j] >> 8) + 0.5) * (1.0 / 16777216.0);
-    const double ra = sqrt(-2.0 * log(u[0])), rb = sqrt(-2.0 * log(u[2]));
-    double s, c;
-    sincospi(2.0 * u[1], &s, &c);
-    g[0] = ra * c; g[1] = ra * s;
-    sincospi(2.0 * u[3], &s, &c);
-    g[2] = rb * c; g[3] = rb * s;
+    for (int j = 0; j < 4; ++j) {
+        u[2 * j] = ((double)(x[j] & 0xFFFFu) + 0.5) * (1.0 / 65536.0);
+        u[2 * j + 1] = ((double)(x[j] >> 16) + 0.5) * (1.0 / 65536.0);
+    }
+    double s, c, r;
+    r = sqrt(-2.0 * log(u[0])); sincospi(2.0 * u[1], &s, &c); ga[0] = r * c; ga[1] = r * s;
+    r = sqrt(-2.0 * log(u[2])); sincospi(2.0 * u[3], &s, &c); ga[2] = r * c; ga[3] = r * s;
+    r = sqrt(-2.0 * log(u[4])); sincospi(2.0 * u[5], &s, &c); gb[0] = r * c; gb[1] = r * s;
+    r = sqrt(-2.0 * log(u[6])); sincospi(2.0 * u[7], &s, &c); gb[2] = r * c; gb[3] = r * s;
 }
 
 // ---------------------------------------------------------------- per-drone registers
@@ -252,16 +279,13 @@ __device__ __forceinline__ void control_tick(Drone<T>& d, T spx, T spy, T spz, T
 
 // ---------------------------------------------------------------- physics sub-step (SPEC §4.2-6)
 template <typename T, bool NOISE>
-__device__ __forceinline__ void physics_substep(Drone<T>& d, const T (&pwm)[4], T sigma, uint64_t seed,
-                                                uint32_t drone_id, uint64_t tick) {
+__device__ __forceinline__ void physics_substep(Drone<T>& d, const T (&pwm)[4], T sigma, const T (&g)[4]) {
     // motors: first-order lag, multiplicative noise, thrust = thr^2 * f_max (f_max = 1 N)
     d.t0 += C<T>::alpha * (pwm[0] - d.t0);
     d.t1 += C<T>::alpha * (pwm[1] - d.t1);
     d.t2 += C<T>::alpha * (pwm[2] - d.t2);
     d.t3 += C<T>::alpha * (pwm[3] - d.t3);
     if constexpr (NOISE) {
-        T g[4];
-        normal4(seed, drone_id, tick, g);
         d.t0 += g[0] * d.t0 * sigma;
         d.t1 += g[1] * d.t1 * sigma;
         d.t2 += g[2] * d.t2 * sigma;
@@ -316,7 +340,9 @@ __device__ __forceinline__ void physics_substep(Drone<T>& d, const T (&pwm)[4], 
     const T ny = d.qw * dy - d.qx * dz + d.qy * dw + d.qz * dx;
     const T nz = d.qw * dz + d.qx * dy - d.qy * dx + d.qz * dw;
     const T nw = d.qw * dw - d.qx * dx - d.qy * dy - d.qz * dz;
-    const T inv = rsqrt_(nx * nx + ny * ny + nz * nz + nw * nw);
+    // |n|^2 = 1 + e with |e| ~ 1e-7 (product of two unit quaternions): one Newton step of 1/sqrt
+    // around 1 is exact to O(e^2), i.e. identical to the normalisation of SPEC §4.5 at this precision
+    const T inv = T(1.5) - T(0.5) * (nx * nx + ny * ny + nz * nz + nw * nw);
     d.qx = nx * inv; d.qy = ny * inv; d.qz = nz * inv; d.qw = nw * inv;
     // ground: stick contact
     if (d.pz < C<T>::z_rest) {
@@ -379,7 +405,7 @@ __device__ __forceinline__ bool camera_features(const Drone<T>& d, T& cx, T& cy,
         const T up = up_c + sy * up_y + sz * up_z;
         const T rt = rt_c + sy * rt_y + sz * rt_z;
         if (!(dep > T(0.1))) { ok = false; dep = T(1); }
-        const T k = T(64) / dep;
+        const T k = T(64) * rcp_(dep);
         u[j] = T(64) + k * rt;
         v[j] = T(64) - k * up;
         ok = ok && (u[j] >= T(1)) && (u[j] <= T(127)) && (v[j] >= T(1)) && (v[j] <= T(127));
@@ -394,7 +420,7 @@ __device__ __forceinline__ bool camera_features(const Drone<T>& d, T& cx, T& cy,
     cx = ok ? T(0.25) * ((u[0] + u[1]) + (u[2] + u[3])) * T(1.0 / 64.0) - T(1) : T(0);
     cy = ok ? T(0.25) * ((v[0] + v[1]) + (v[2] + v[3])) * T(1.0 / 64.0) - T(1) : T(0);
     area = ok ? apx * T(1.0 / 16384.0) : T(0);
-    ratio = (ok && h > T(0)) ? (umax - umin) / h : T(0);
+    ratio = (ok && h > T(0)) ? (umax - umin) * rcp_(h) : T(0);
     return ok;
 }
 
@@ -406,9 +432,9 @@ __device__ __forceinline__ bool observe(Drone<T>& d, T roll, T pitch, T yaw, T a
     o[1] = wrap_angle(pitch - d.ep) * C<T>::inv_agent_dt;
     o[2] = wrap_angle(yaw - d.eyaw) * C<T>::inv_agent_dt;
     T sr, cr, sp, cp, sy, cy;                              // hover.py:233
-    sincos_(T(0.5) * roll, &sr, &cr);
-    sincos_(T(0.5) * pitch, &sp, &cp);
-    sincos_(T(0.5) * yaw, &sy, &cy);
+    sincos_half_(T(0.5) * roll, &sr, &cr);
+    sincos_half_(T(0.5) * pitch, &sp, &cp);
+    sincos_half_(T(0.5) * yaw, &sy, &cy);
     o[3] = sr * cp * cy - cr * sp * sy;
     o[4] = cr * sp * cy + sr * cp * sy;
     o[5] = cr * cp * sy - sr * sp * cy;

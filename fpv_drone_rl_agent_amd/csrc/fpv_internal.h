@@ -21,13 +21,13 @@ struct StepArgs {
     uint8_t* truncated;    // [n]
     uint64_t* tick;        // [tiles] device agent-tick counters (all equal; one per wave)
     const T* tmpl;         // reset template: 36 state words (storage-slot order) + 20 obs words
-    uint32_t* led_count;
+    uint32_t* led_count;   // [tiles]
     int32_t* led_idx;
     uint32_t* led_info;
     uint32_t* led_tag;
     T* led_ret;
     T* led_obs;
-    int64_t led_cap;
+    int64_t led_rows;      // ledger rows per tile
     int64_t n;
     uint64_t seed;
     uint64_t id_offset;

@@ -41,18 +41,21 @@ __device__ __forceinline__ T reward_and_flags(const Drone<T>& d, T roll, T pitch
     return reward;
 }
 
+// The reset template (36 state words in storage-slot order + 20 observation words) is fetched once
+// per wave at kernel start, lane j holding word j, so that a finished drone takes it from registers
+// (v_readlane) instead of waiting on memory at the end of the kernel.
 template <typename T>
-__device__ __forceinline__ void drone_from_template(Drone<T>& d, const T* __restrict__ tm) {
-    // tm is in storage-slot order; prev_action (slots 32..35) is deliberately not taken:
-    // hover.py:101 resets only self.action, prev_action survives reset()
-    d.px = tm[0]; d.py = tm[1]; d.pz = tm[2]; d.steps = tm[3];
-    d.qx = tm[4]; d.qy = tm[5]; d.qz = tm[6]; d.qw = tm[7];
-    d.vx = tm[8]; d.vy = tm[9]; d.vz = tm[10]; d.ep_ret = tm[11];
-    d.wx = tm[12]; d.wy = tm[13]; d.wz = tm[14]; d.prev_area = tm[15];
-    d.t0 = tm[16]; d.t1 = tm[17]; d.t2 = tm[18]; d.t3 = tm[19];
-    d.ix = tm[20]; d.iy = tm[21]; d.iz = tm[22]; d.prev_ratio = tm[23];
-    d.ex = tm[24]; d.ey = tm[25]; d.ez = tm[26]; d.prev_cx = tm[27];
-    d.er = tm[28]; d.ep = tm[29]; d.eyaw = tm[30]; d.prev_cy = tm[31];
+__device__ __forceinline__ void drone_from_template(Drone<T>& d, T tv) {
+    // prev_action (slots 32..35) is deliberately not taken: hover.py:101 resets only self.action,
+    // prev_action survives reset()
+    d.px = __shfl(tv, 0); d.py = __shfl(tv, 1); d.pz = __shfl(tv, 2); d.steps = __shfl(tv, 3);
+    d.qx = __shfl(tv, 4); d.qy = __shfl(tv, 5); d.qz = __shfl(tv, 6); d.qw = __shfl(tv, 7);
+    d.vx = __shfl(tv, 8); d.vy = __shfl(tv, 9); d.vz = __shfl(tv, 10); d.ep_ret = __shfl(tv, 11);
+    d.wx = __shfl(tv, 12); d.wy = __shfl(tv, 13); d.wz = __shfl(tv, 14); d.prev_area = __shfl(tv, 15);
+    d.t0 = __shfl(tv, 16); d.t1 = __shfl(tv, 17); d.t2 = __shfl(tv, 18); d.t3 = __shfl(tv, 19);
+    d.ix = __shfl(tv, 20); d.iy = __shfl(tv, 21); d.iz = __shfl(tv, 22); d.prev_ratio = __shfl(tv, 23);
+    d.ex = __shfl(tv, 24); d.ey = __shfl(tv, 25); d.ez = __shfl(tv, 26); d.prev_cx = __shfl(tv, 27);
+    d.er = __shfl(tv, 28); d.ep = __shfl(tv, 29); d.eyaw = __shfl(tv, 30); d.prev_cy = __shfl(tv, 31);
 }
 
 // stage a wave's [64][20] observation tile through LDS and write it out row-major
@@ -87,6 +90,8 @@ __global__ __launch_bounds__(kTile) void step_kernel(StepArgs<T> p) {
     // per-tile copy of the agent tick: read and advanced by its own wave only, so the step stays
     // one kernel and is graph-replayable without host-side argument updates
     const uint64_t agent_tick = p.tick[tile];
+    const uint32_t led_fill = p.led_count[tile];
+    const T tmpl_lane = p.tmpl[lane < kStateWords + kObsWords ? lane : 0];
     const uint32_t gid = (uint32_t)(p.id_offset + (uint64_t)i);
 
     // hover.py:337-341 action scaling; the mode-0 thrust setpoint is clipped to [0,1] (SPEC §4.1)
@@ -98,9 +103,10 @@ __global__ __launch_bounds__(kTile) void step_kernel(StepArgs<T> p) {
 #pragma unroll 1
     for (int k = 0; k < kSubstepPairs; ++k) {
         control_tick(d, spx, spy, spz, thrust, pwm);
-        const uint64_t t0 = agent_tick * (uint64_t)(2 * kSubstepPairs) + (uint64_t)(2 * k);
-        physics_substep<T, NOISE>(d, pwm, p.sigma, p.seed, gid, t0);
-        physics_substep<T, NOISE>(d, pwm, p.sigma, p.seed, gid, t0 + 1);
+        T ga[4] = {}, gb[4] = {};
+        if constexpr (NOISE) normal8(p.seed, gid, agent_tick * (uint64_t)kSubstepPairs + (uint64_t)k, ga, gb);
+        physics_substep<T, NOISE>(d, pwm, p.sigma, ga);
+        physics_substep<T, NOISE>(d, pwm, p.sigma, gb);
     }
 
     // hover.py:351-357
@@ -115,29 +121,34 @@ __global__ __launch_bounds__(kTile) void step_kernel(StepArgs<T> p) {
     d.a0 = act.x; d.a1 = act.y; d.a2 = act.z; d.a3 = act.w;
     d.ep_ret += reward;
 
-    // episode ends -> done ledger (wave-ballot compaction), then constant-template reset
+    // episode ends -> this tile's region of the done ledger (wave-ballot compaction, no atomics),
+    // then constant-template reset
     const bool done = live && (bits & (kInfoTerm | kInfoTrunc)) != 0;
     const unsigned long long m = __ballot(done);
     if (m != 0ull) {
-        const int leader = __ffsll((long long)m) - 1;
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(p.led_count, (uint32_t)__popcll(m));
-        base = __shfl(base, leader);
+        Drone<T> r = d;
+        drone_from_template(r, tmpl_lane);
+        T ro[kObsWords];
+#pragma unroll
+        for (int j = 0; j < kObsWords; ++j) ro[j] = __shfl(tmpl_lane, kStateWords + j);
         if (done) {
-            const uint32_t slot = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if ((int64_t)slot < p.led_cap) {
+            const int64_t row = (int64_t)led_fill + (int64_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (row < p.led_rows) {
+                const int64_t slot = tile * p.led_rows + row;
                 p.led_idx[slot] = (int32_t)i;
                 p.led_info[slot] = bits | ((uint32_t)d.steps << 8);
                 p.led_tag[slot] = (uint32_t)agent_tick;
                 p.led_ret[slot] = d.ep_ret;
-                T* lo = p.led_obs + (int64_t)slot * kObsWords;
+                Vec4<T>* lo = reinterpret_cast<Vec4<T>*>(p.led_obs + slot * kObsWords);
 #pragma unroll
-                for (int j = 0; j < kObsWords; ++j) lo[j] = o[j];
+                for (int g = 0; g < kObsWords / 4; ++g)
+                    lo[g] = Vec4<T>{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
             }
-            drone_from_template(d, p.tmpl);
+            d = r;
 #pragma unroll
-            for (int j = 0; j < kObsWords; ++j) o[j] = p.tmpl[kStateWords + j];
+            for (int j = 0; j < kObsWords; ++j) o[j] = ro[j];
         }
+        if (lane == 0) p.led_count[tile] = led_fill + (uint32_t)__popcll(m);
     }
 
     store_drone(d, p.state, tile, lane);
@@ -161,7 +172,15 @@ __global__ __launch_bounds__(kTile) void reset_kernel(Vec4<T>* state, const T* t
     if (mask && !mask[i]) return;
     Drone<T> d;
     load_drone(d, state, tile, lane);
-    drone_from_template(d, tmpl);
+    const T* tm = tmpl;
+    d.px = tm[0]; d.py = tm[1]; d.pz = tm[2]; d.steps = tm[3];
+    d.qx = tm[4]; d.qy = tm[5]; d.qz = tm[6]; d.qw = tm[7];
+    d.vx = tm[8]; d.vy = tm[9]; d.vz = tm[10]; d.ep_ret = tm[11];
+    d.wx = tm[12]; d.wy = tm[13]; d.wz = tm[14]; d.prev_area = tm[15];
+    d.t0 = tm[16]; d.t1 = tm[17]; d.t2 = tm[18]; d.t3 = tm[19];
+    d.ix = tm[20]; d.iy = tm[21]; d.iz = tm[22]; d.prev_ratio = tm[23];
+    d.ex = tm[24]; d.ey = tm[25]; d.ez = tm[26]; d.prev_cx = tm[27];
+    d.er = tm[28]; d.ep = tm[29]; d.eyaw = tm[30]; d.prev_cy = tm[31];
     store_drone(d, state, tile, lane);
     if (obs) {
         T* o = obs + i * kObsWords;

@@ -48,16 +48,20 @@ class FpvEngine:
             self.reward = torch.empty((n,), dtype=self.dtype, device=dev)
             self.terminated = torch.empty((n,), dtype=torch.uint8, device=dev)
             self.truncated = torch.empty((n,), dtype=torch.uint8, device=dev)
-            cap = int(ledger_capacity) if ledger_capacity > 0 else 2 * n
-            # caller-owned done ledger (fpv_ledger_bind): torch can view it without copies
-            self.led_count = torch.zeros((1,), dtype=torch.int32, device=dev)
+            # caller-owned done ledger (fpv_ledger_bind): partitioned per 64-drone tile, see fpv_env.h
+            tiles = (n + 63) // 64
+            want = int(ledger_capacity) if ledger_capacity > 0 else 2 * n
+            rows = (want + tiles - 1) // tiles
+            cap = rows * tiles
+            self.led_count = torch.zeros((tiles,), dtype=torch.int32, device=dev)
             self.led_idx = torch.zeros((cap,), dtype=torch.int32, device=dev)
             self.led_info = torch.zeros((cap,), dtype=torch.int32, device=dev)
             self.led_tag = torch.zeros((cap,), dtype=torch.int32, device=dev)
             self.led_ret = torch.zeros((cap,), dtype=self.dtype, device=dev)
             self.led_obs = torch.zeros((cap, L.OBS_WORDS), dtype=self.dtype, device=dev)
-        self.ledger_capacity = cap
-        led = L.FpvLedger(cap, self.led_count.data_ptr(), self.led_idx.data_ptr(), self.led_info.data_ptr(),
+            self._led_row = torch.arange(rows, dtype=torch.int32, device=dev).unsqueeze(0)
+        self.ledger_capacity, self.ledger_rows_per_tile, self.tiles = cap, rows, tiles
+        led = L.FpvLedger(cap, rows, self.led_count.data_ptr(), self.led_idx.data_ptr(), self.led_info.data_ptr(),
                           self.led_tag.data_ptr(), self.led_ret.data_ptr(), self.led_obs.data_ptr())
         L.check(self.lib.fpv_ledger_bind(self._h, C.byref(led)), "fpv_ledger_bind")
 
@@ -123,16 +127,23 @@ class FpvEngine:
     def ledger_clear(self) -> None:
         L.check(self.lib.fpv_ledger_clear(self._h, _stream(self.device)), "fpv_ledger_clear")
 
+    def ledger_rows(self):
+        """Device-side compaction of the per-tile ledger: (total_appended, flat row indices [k]) — one
+        synchronising nonzero over a [tiles, rows_per_tile] mask."""
+        counts = self.led_count
+        valid = self._led_row < counts.clamp(max=self.ledger_rows_per_tile).unsqueeze(1)
+        rows = torch.nonzero(valid.view(-1), as_tuple=False).squeeze(1)
+        return counts.sum(), rows
+
     def ledger_read(self):
         """Synchronising read of the ledger: dict of host numpy arrays sorted by (tag, drone)."""
         import numpy as np
-        total = int(self.led_count.item())
-        c = min(total, self.ledger_capacity)
-        idx = self.led_idx[:c].cpu().numpy()
-        info = self.led_info[:c].cpu().numpy().view(np.uint32)
-        tag = self.led_tag[:c].cpu().numpy().view(np.uint32)
-        ret = self.led_ret[:c].cpu().numpy()
-        obs = self.led_obs[:c].cpu().numpy()
+        total, rows = self.ledger_rows()
+        idx = self.led_idx[rows].cpu().numpy()
+        info = self.led_info[rows].cpu().numpy().view(np.uint32)
+        tag = self.led_tag[rows].cpu().numpy().view(np.uint32)
+        ret = self.led_ret[rows].cpu().numpy()
+        obs = self.led_obs[rows].cpu().numpy()
         order = np.lexsort((idx, tag))
-        return {"count": total, "idx": idx[order], "info": info[order], "tag": tag[order],
+        return {"count": int(total.item()), "idx": idx[order], "info": info[order], "tag": tag[order],
                 "ep_return": ret[order], "obs": obs[order]}

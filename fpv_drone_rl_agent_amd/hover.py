@@ -41,7 +41,7 @@ class QuadXHoverEnv(_EnvBase):
         self.target_area, self.target_ratio = 0.013, 1.53                        # hover.py:49-51
         self.action_space = spaces.hover_action_space()
         self.observation_space = spaces.hover_observation_space()
-        self._engine = FpvEngine(1, device, render=render, noise_ratio=noise_ratio, seed=seed, ledger_capacity=8)
+        self._engine = FpvEngine(1, device, render=render, noise_ratio=noise_ratio, seed=seed, ledger_capacity=4)
         self._act = torch.zeros((1, 4), dtype=torch.float32, device=self._engine.device)
         self.info = {"out_of_bounds": False, "collision": False, "env_complete": False, "on_floor": False}
         self.termination = self.truncation = False

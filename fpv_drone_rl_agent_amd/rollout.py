@@ -139,16 +139,15 @@ class RolloutCollector:
 
     def _bootstrap_timeouts(self) -> None:
         """r_t += gamma * V(terminal obs) for truncated-but-not-terminated episode ends; also harvests
-        the Monitor-style episode statistics from the done ledger.  One host read of the row count."""
+        the Monitor-style episode statistics from the done ledger.  One synchronising compaction per rollout."""
         eng = self.engine
-        total = int(eng.led_count.item())
-        c = min(total, eng.ledger_capacity)
-        self.episodes = {"count": total, "ep_return": eng.led_ret[:c], "ep_len": eng.led_info[:c] >> 8}
-        if c == 0:
+        total, all_rows = eng.ledger_rows()
+        self.episodes = {"count": int(total.item()), "ep_return": eng.led_ret[all_rows],
+                         "ep_len": eng.led_info[all_rows] >> 8}
+        if all_rows.numel() == 0:
             return
-        info = eng.led_info[:c]
-        sel = ((info & 2) != 0) & ((info & 1) == 0)
-        rows = torch.nonzero(sel, as_tuple=False).squeeze(1)
+        info = eng.led_info[all_rows]
+        rows = all_rows[((info & 2) != 0) & ((info & 1) == 0)]
         if rows.numel() == 0:
             return
         t_idx = (eng.led_tag[rows].to(torch.int64) - (self._tick0 & 0xFFFFFFFF)) & 0xFFFFFFFF

@@ -133,8 +133,10 @@ class LedgerInfos:
     """Device-mode stand-in for the `infos` list: exposes the done ledger as device tensors."""
 
     def __init__(self, engine: FpvEngine):
-        self.count, self.idx, self.info = engine.led_count, engine.led_idx, engine.led_info
+        self.tile_count, self.rows_per_tile = engine.led_count, engine.ledger_rows_per_tile
+        self.idx, self.info = engine.led_idx, engine.led_info
         self.ep_return, self.terminal_observation = engine.led_ret, engine.led_obs
+        self.rows = engine.ledger_rows  # () -> (total, flat row indices); synchronises
 
 
 def make_vec_env(env_fn=None, n_envs: int = 16, vec_env_cls=None, **kw) -> FpvVecEnv:

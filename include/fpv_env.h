@@ -59,20 +59,24 @@ typedef struct {
     double noise_ratio;      /* cf2x.yaml:5 motor noise (0.02); 0 = noise-free */
     uint64_t seed;           /* Philox key (docs/SPEC.md §9) */
     uint64_t id_offset;      /* global id of drone 0: rank * num_envs */
-    int64_t ledger_capacity; /* done-ledger rows; 0 = 2 * num_envs */
+    int64_t ledger_capacity; /* done-ledger rows (rounded up to a multiple of the tile count); 0 = 2 * num_envs */
 } fpv_config;
 
 /* Device-side view of the done ledger (SB3 VecEnv `infos[i]["terminal_observation"]`,
- * `["TimeLimit.truncated"]`, Monitor `["episode"] = {r, l}` — SURVEY.md §8a A11).  Rows
- * are appended by fpv_step in unspecified order with wave-ballot compaction. */
+ * `["TimeLimit.truncated"]`, Monitor `["episode"] = {r, l}` — SURVEY.md §8a A11).
+ * The ledger is partitioned per 64-drone tile (= one wavefront of fpv_step): tile t owns rows
+ * [t * rows_per_tile, (t + 1) * rows_per_tile) and its own counter count[t], so a wave that sees
+ * episode ends compacts them with one ballot and no global atomic.  Rows of a tile are appended in
+ * lane order; count[t] keeps counting past rows_per_tile (overflow rows are dropped). */
 typedef struct {
-    int64_t capacity;
-    uint32_t* count; /* device: rows appended since the last fpv_ledger_clear (may exceed capacity: overflow rows are dropped) */
-    int32_t* idx;    /* [capacity] local drone index */
-    uint32_t* info;  /* [capacity] FPV_INFO_* | ep_len << 8 */
-    uint32_t* tag;   /* [capacity] low 32 bits of the agent tick of the step that ended the episode */
-    void* ep_return; /* [capacity] float or double by precision */
-    void* obs;       /* [capacity][FPV_OBS_WORDS] terminal observation */
+    int64_t capacity;      /* tiles * rows_per_tile */
+    int64_t rows_per_tile;
+    uint32_t* count;       /* [tiles] rows appended per tile since the last fpv_ledger_clear */
+    int32_t* idx;          /* [capacity] local drone index */
+    uint32_t* info;        /* [capacity] FPV_INFO_* | ep_len << 8 */
+    uint32_t* tag;         /* [capacity] low 32 bits of the agent tick of the step that ended the episode */
+    void* ep_return;       /* [capacity] float or double by precision */
+    void* obs;             /* [capacity][FPV_OBS_WORDS] terminal observation */
 } fpv_ledger;
 
 /* ---- lifecycle ---- */
@@ -108,7 +112,8 @@ int fpv_get_tick(fpv_env* env, uint64_t* tick_host, void* stream);
 int fpv_ledger_view(fpv_env* env, fpv_ledger* out);
 int fpv_ledger_clear(fpv_env* env, void* stream);
 /* Replace the handle-owned ledger by caller-owned device buffers (same layout as fpv_ledger;
- * ep_return / obs in the handle's precision).  The caller keeps them alive until
+ * ep_return / obs in the handle's precision; count has ceil(num_envs / 64) entries and capacity
+ * must equal that tile count times rows_per_tile).  The caller keeps them alive until
  * fpv_destroy or the next bind.  Lets a host runtime view the ledger without copies. */
 int fpv_ledger_bind(fpv_env* env, const fpv_ledger* buffers);
 

@@ -66,12 +66,17 @@ void fpv_oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint
 }
 
 void fpv_oracle_normal4(uint64_t seed, uint64_t drone_id, uint64_t tick, double g[4]) {
-    uint32_t ctr[4] = {(uint32_t)drone_id, (uint32_t)tick, (uint32_t)(tick >> 32), 0x46505631u};
+    /* SPEC §9: one Philox call per sub-step pair, eight 16-bit uniforms; tick = agent_tick*12 + k */
+    uint64_t pair = tick >> 1;
+    uint32_t ctr[4] = {(uint32_t)drone_id, (uint32_t)pair, (uint32_t)(pair >> 32), 0x46505631u};
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     uint32_t x[4];
     fpv_oracle_philox4x32_10(ctr, key, x);
+    uint32_t h[8];
+    for (int j = 0; j < 4; ++j) { h[2 * j] = x[j] & 0xFFFFu; h[2 * j + 1] = x[j] >> 16; }
+    const uint32_t* hh = h + 4 * (tick & 1);
     double u[4];
-    for (int j = 0; j < 4; ++j) u[j] = ((double)(x[j] >> 8) + 0.5) * (1.0 / 16777216.0);
+    for (int j = 0; j < 4; ++j) u[j] = ((double)hh[j] + 0.5) * (1.0 / 65536.0);
     double ra = sqrt(-2.0 * log(u[0])), rb = sqrt(-2.0 * log(u[2]));
     g[0] = ra * cos(2.0 * M_PI * u[1]);
     g[1] = ra * sin(2.0 * M_PI * u[1]);

@@ -95,7 +95,7 @@ def test_fp64_trajectory_matches_oracle(oracle, noise):
     n, steps = 1000, 40  # n deliberately not a multiple of the 64-drone tile
     st_ref = _with_edge_cases(oracle.synthetic_states(n, seed=3), 3)
     cfg = oracle.make_cfg(noise_ratio=noise, seed=99, id_offset=5000)
-    eng = _engine(n, noise_ratio=noise, seed=99, id_offset=5000, precision="f64")
+    eng = _engine(n, noise_ratio=noise, seed=99, id_offset=5000, precision="f64", ledger_capacity=16 * n)
     eng.set_state(torch.from_numpy(st_ref))
     led_ref = oracle.Ledger(4 * n)
     for t in range(steps):
@@ -107,6 +107,7 @@ def test_fp64_trajectory_matches_oracle(oracle, noise):
         assert _close(rew.cpu().numpy(), rew_r, 1e-9).all(), t
     assert _close(eng.get_state().cpu().numpy(), st_ref, 1e-9).all()
     got = eng.ledger_read()
+    assert int(eng.led_count.max()) <= eng.ledger_rows_per_tile  # no tile overflowed its ledger region
     idx_r, info_r, ret_r, tobs_r = led_ref.rows()
     assert got["count"] == len(idx_r) > 0
     assert (got["idx"] == idx_r).all() and (got["info"] == info_r).all()
@@ -203,3 +204,18 @@ def test_noise_is_shard_independent(oracle):
         assert np.array_equal(part.get_state().cpu().numpy(), ref[128 * r:128 * (r + 1)])
         part.close()
     whole.close()
+
+
+def test_ledger_overflow_is_counted_not_written(oracle):
+    """A tile whose ledger region is full keeps counting but drops rows (fpv_env.h)."""
+    n = 64
+    eng = _engine(n, noise_ratio=0.0, ledger_capacity=8)   # one tile, 8 rows
+    st = oracle.synthetic_states(n, seed=2)
+    st[:, 34] = 401                                        # every drone truncates on this step
+    eng.set_state(torch.from_numpy(st.astype(np.float32)))
+    eng.step(torch.zeros(n, 4, device="cuda"))
+    got = eng.ledger_read()
+    assert got["count"] == 64 and len(got["idx"]) == 8 and list(got["idx"]) == list(range(8))
+    eng.ledger_clear()
+    assert eng.ledger_read()["count"] == 0
+    eng.close()
