@@ -30,6 +30,23 @@ class FpvLedger(C.Structure):
     ]
 
 
+class FpvStepExtras(C.Structure):
+    _fields_ = [("done", C.c_void_p), ("ret", C.c_void_p), ("partials", C.c_void_p), ("gamma", C.c_float),
+                ("reserved", C.c_int32)]
+
+
+PARTIAL_WORDS = 44
+
+
+class FpvPolicyIo(C.Structure):
+    _fields_ = [
+        ("n", C.c_int64), ("obs", C.c_void_p), ("rms", C.c_void_p), ("eps_in", C.c_void_p), ("tick", C.c_void_p),
+        ("obs_n", C.c_void_p), ("action", C.c_void_p), ("clipped", C.c_void_p), ("value", C.c_void_p),
+        ("logp", C.c_void_p), ("eps_out", C.c_void_p), ("seed", C.c_uint64), ("id_offset", C.c_uint64),
+        ("clip_obs", C.c_float), ("eps_norm", C.c_float), ("deterministic", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
 # every symbol of include/fpv_env.h: name -> (restype, argtypes)
 _vp, _i64, _i32, _f32, _u64 = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_uint64
 SIGNATURES = {
@@ -37,6 +54,10 @@ SIGNATURES = {
     "fpv_destroy": (C.c_int, [_vp]),
     "fpv_reset": (C.c_int, [_vp, _vp, _vp, _vp]),
     "fpv_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fpv_step_fused": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(FpvStepExtras), _vp]),
+    "fpv_moments_merge": (C.c_int, [_i64, _vp, C.c_double, _vp, _vp, _vp, _vp]),
+    "fpv_reward_finalize": (C.c_int, [_i64, _i64, _vp, _vp, _f32, _f32, _vp, _vp]),
+    "fpv_tick_ptr": (C.c_int, [_vp, C.POINTER(_vp)]),
     "fpv_step_f64": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fpv_get_state": (C.c_int, [_vp, _vp, _vp]),
     "fpv_set_state": (C.c_int, [_vp, _vp, _vp]),
@@ -48,6 +69,10 @@ SIGNATURES = {
     "fpv_gae": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp]),
     "fpv_normalize": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _i32, _f32, _f32, _vp]),
     "fpv_normalize_reward": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _vp]),
+    "fpv_policy_create": (C.c_int, [_i32, C.POINTER(_vp)]),
+    "fpv_policy_destroy": (C.c_int, [_vp]),
+    "fpv_policy_load": (C.c_int, [_vp, C.POINTER(_vp), _vp]),
+    "fpv_policy_forward": (C.c_int, [_vp, C.POINTER(FpvPolicyIo), _vp]),
     "fpv_last_error": (C.c_char_p, []),
     "fpv_version": (C.c_int, []),
 }

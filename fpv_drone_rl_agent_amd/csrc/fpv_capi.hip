@@ -48,6 +48,12 @@ struct fpv_env {
     bool led_owned;
 };
 
+struct fpv_policy {
+    int device;
+    int cus;
+    float* image;
+};
+
 // per-device reduction scratch for the handle-less rollout primitives
 static std::mutex g_scratch_mu;
 static double* g_scratch[64] = {};
@@ -62,7 +68,8 @@ static int scratch_for_current_device(double** out) {
 }
 
 template <typename T>
-static int step_impl(fpv_env* e, const T* actions, T* obs, T* reward, uint8_t* term, uint8_t* trunc, void* stream) {
+static int step_impl(fpv_env* e, const T* actions, T* obs, T* reward, uint8_t* term, uint8_t* trunc, void* stream,
+                     const fpv_step_extras* ex = nullptr) {
     if (!e) return fail(FPV_ERR_ARG, "fpv_step: null handle");
     if (!actions || !obs || !reward || !term || !trunc) return fail(FPV_ERR_ARG, "fpv_step: null buffer");
     if ((e->cfg.precision == FPV_F64) != (sizeof(T) == 8))
@@ -81,6 +88,10 @@ static int step_impl(fpv_env* e, const T* actions, T* obs, T* reward, uint8_t* t
     a.id_offset = e->cfg.id_offset;
     a.sigma = (T)e->cfg.noise_ratio;
     a.floor_check = e->cfg.floor_check;
+    a.done = ex ? ex->done : nullptr;
+    a.ret = ex ? ex->ret : nullptr;
+    a.partials = ex ? ex->partials : nullptr;
+    a.gamma = ex ? ex->gamma : 0.0f;
     FPV_HIP(launch_step<T>(a, e->cfg.noise_ratio != 0.0, (hipStream_t)stream));
     return FPV_OK;
 }
@@ -165,6 +176,35 @@ int fpv_reset(fpv_env* e, const uint8_t* mask, void* obs, void* stream) {
 int fpv_step(fpv_env* e, const float* actions, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated,
              void* stream) {
     return step_impl<float>(e, actions, obs, reward, terminated, truncated, stream);
+}
+
+int fpv_step_fused(fpv_env* e, const float* actions, float* obs, float* reward, uint8_t* terminated, uint8_t* truncated,
+                   const fpv_step_extras* extras, void* stream) {
+    if (e && e->cfg.precision != FPV_F32) return fail(FPV_ERR_UNSUPPORTED, "fpv_step_fused: fp32 handles only");
+    return step_impl<float>(e, actions, obs, reward, terminated, truncated, stream, extras);
+}
+
+int fpv_moments_merge(int64_t tiles, const double* partials, double batch_count, double* obs_rms, double* ret_rms,
+                      double* snapshot, void* stream) {
+    if (tiles <= 0 || !partials || batch_count <= 0.0) return fail(FPV_ERR_ARG, "fpv_moments_merge: bad arguments");
+    double* scratch = nullptr;
+    if (int rc = scratch_for_current_device(&scratch)) return rc;
+    FPV_HIP(launch_moments_merge_tiles(tiles, partials, batch_count, obs_rms, ret_rms, snapshot, scratch,
+                                       (hipStream_t)stream));
+    return FPV_OK;
+}
+
+int fpv_reward_finalize(int64_t T, int64_t n, const float* raw, const double* snapshots, float clip, float eps,
+                        float* out, void* stream) {
+    if (T <= 0 || n <= 0 || !raw || !snapshots || !out) return fail(FPV_ERR_ARG, "fpv_reward_finalize: bad arguments");
+    FPV_HIP(launch_reward_finalize(T, n, raw, snapshots, clip, eps, out, (hipStream_t)stream));
+    return FPV_OK;
+}
+
+int fpv_tick_ptr(fpv_env* e, const uint64_t** out) {
+    if (!e || !out) return fail(FPV_ERR_ARG, "fpv_tick_ptr: null argument");
+    *out = e->tick;
+    return FPV_OK;
 }
 
 int fpv_step_f64(fpv_env* e, const double* actions, double* obs, double* reward, uint8_t* terminated,
@@ -272,6 +312,54 @@ int fpv_normalize_reward(int64_t n, const float* r, const uint8_t* done, float* 
     if (int rc = scratch_for_current_device(&scratch)) return rc;
     FPV_HIP(launch_normalize_reward(n, r, done, ret, r_out, rms, update, gamma, clip, eps, scratch,
                                     (hipStream_t)stream));
+    return FPV_OK;
+}
+
+int fpv_policy_create(int32_t device, fpv_policy** out) {
+    if (!out) return fail(FPV_ERR_ARG, "fpv_policy_create: null argument");
+    int ndev = 0;
+    FPV_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(FPV_ERR_ARG, "fpv_policy_create: device %d not present", device);
+    FPV_HIP(hipSetDevice(device));
+    fpv_policy* p = new (std::nothrow) fpv_policy();
+    if (!p) return fail(FPV_ERR_ALLOC, "fpv_policy_create: host allocation failed");
+    p->device = device;
+    hipDeviceProp_t prop;
+    FPV_HIP(hipGetDeviceProperties(&prop, device));
+    p->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    hipError_t e = hipMalloc((void**)&p->image, sizeof(float) * (size_t)policy_image_floats());
+    if (e != hipSuccess) {
+        delete p;
+        return fail(FPV_ERR_HIP, "fpv_policy_create: %s", hipGetErrorString(e));
+    }
+    *out = p;
+    return FPV_OK;
+}
+
+int fpv_policy_destroy(fpv_policy* p) {
+    if (!p) return FPV_OK;
+    if (p->image) (void)hipFree(p->image);
+    delete p;
+    return FPV_OK;
+}
+
+int fpv_policy_load(fpv_policy* p, const float* const* weights, void* stream) {
+    if (!p || !weights) return fail(FPV_ERR_ARG, "fpv_policy_load: null argument");
+    for (int i = 0; i < 13; ++i)
+        if (!weights[i]) return fail(FPV_ERR_ARG, "fpv_policy_load: weight pointer %d is null", i);
+    FPV_HIP(launch_policy_pack(weights, p->image, (hipStream_t)stream));
+    return FPV_OK;
+}
+
+int fpv_policy_forward(fpv_policy* p, const fpv_policy_io* io, void* stream) {
+    if (!p || !io) return fail(FPV_ERR_ARG, "fpv_policy_forward: null argument");
+    if (io->n <= 0 || !io->obs || !io->value) return fail(FPV_ERR_ARG, "fpv_policy_forward: n, obs and value are required");
+    if (((uintptr_t)io->obs | (uintptr_t)io->obs_n | (uintptr_t)io->action | (uintptr_t)io->clipped |
+         (uintptr_t)io->eps_in | (uintptr_t)io->eps_out) & 15)
+        return fail(FPV_ERR_ARG, "fpv_policy_forward: row buffers must be 16-byte aligned");
+    FPV_HIP(launch_policy_forward(p->image, io->obs, io->rms, io->eps_in, io->tick, io->obs_n, io->action, io->clipped,
+                                  io->value, io->logp, io->eps_out, io->n, io->seed, io->id_offset, io->clip_obs,
+                                  io->eps_norm, io->deterministic, p->cus, (hipStream_t)stream));
     return FPV_OK;
 }
 

@@ -33,7 +33,14 @@ struct StepArgs {
     uint64_t id_offset;
     T sigma;
     int32_t floor_check;
+    // fused VecNormalize bookkeeping (all optional, fp32 handles only; see fpv_step_fused)
+    uint8_t* done;       // [n] terminated | truncated
+    float* ret;          // [n] discounted-return accumulator, updated in place
+    double* partials;    // [tiles][kPartialWords] per-tile sums
+    float gamma;
 };
+
+constexpr int kPartialWords = 44;  // sum obs[20], sum obs^2[20], sum ret, sum ret^2, 2 pad
 
 template <typename T>
 hipError_t launch_step(const StepArgs<T>& a, bool noise, hipStream_t s);
@@ -52,9 +59,21 @@ hipError_t launch_gae(int64_t T, int64_t n, const float* rewards, const float* v
                       float* returns, double* stats, double* scratch, hipStream_t s);
 hipError_t launch_normalize(int64_t n, int32_t d, const float* x, float* y, double* rms, int32_t update, float clip,
                             float eps, double* scratch, hipStream_t s);
+hipError_t launch_moments_merge_tiles(int64_t tiles, const double* partials, double batch_count, double* obs_rms,
+                                      double* ret_rms, double* snapshot, double* scratch, hipStream_t s);
+hipError_t launch_reward_finalize(int64_t T, int64_t n, const float* raw, const double* snapshots, float clip, float eps,
+                                  float* out, hipStream_t s);
 hipError_t launch_normalize_reward(int64_t n, const float* r, const uint8_t* done, float* ret, float* r_out,
                                    double* rms, int32_t update, float gamma, float clip, float eps, double* scratch,
                                    hipStream_t s);
+// fpv_policy.hip
+hipError_t launch_policy_pack(const float* const* w, float* image, hipStream_t s);
+hipError_t launch_policy_forward(const float* image, const float* obs, const double* rms, const float* eps_in,
+                                 const uint64_t* tick, float* obs_n, float* action, float* clipped, float* value,
+                                 float* logp, float* eps_out, int64_t n, uint64_t seed, uint64_t id_offset,
+                                 float clip_obs, float eps_norm, int deterministic, int max_blocks, hipStream_t s);
+int policy_image_floats();
+
 constexpr int kScratchDoubles = 1024 * 80;  // per-device reduction scratch (partials)
 
 }  // namespace fpv

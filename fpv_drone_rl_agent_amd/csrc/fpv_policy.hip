@@ -1,0 +1,316 @@
+// fpv_policy.hip — fused actor-critic forward of the PPO rollout (gfx950, exact-fp32 MFMA).
+//
+// One kernel does what SB3's MlpPolicy.forward + VecNormalize.normalize_obs + Box clip do per
+// rollout step (simulation/train_hover.py:43-58, net_arch=[128,128]):
+//   raw obs [N][20] -> (x - mean) / sqrt(var + eps), clip        (VecNormalize statistics, fp64 in)
+//   pi: 20 -> 128 -> 128 -> 4 (tanh), V: 20 -> 128 -> 128 -> 1 (tanh)
+//   a = mu + exp(log_std) * eps,  log pi(a),  clip(a, -1, 1),  V
+// Layout: everything is computed TRANSPOSED, H^T = W . X^T, on v_mfma_f32_32x32x2_f32 (bit-exact
+// fp32 fma chains, MI355X_MICROARCH.md): drones sit on the MFMA column (= lane & 31), the 32x32
+// accumulator tile of one layer has its hidden index in the 16 registers, so it is the next layer's
+// B operand as it stands — no LDS round trip, no lane movement between layers.  The K order that
+// this induces is baked into the weight image by pack_kernel.  A 512-thread workgroup keeps the
+// whole 160 KB weight image in LDS and walks over 256-drone chunks (32 drones per wave).
+#include "fpv_internal.h"
+
+namespace fpv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kHid = 128, kIn = 20, kInPad = 24, kAct = 4;
+constexpr int kNetFloats = 4 * 12 * 64 + 128 + 4 * 4 * 4 * 64 * 4 + 128;  // 19712
+constexpr int kOffW1 = 0, kOffB1 = 3072, kOffW2 = 3200, kOffB2 = 19584;
+constexpr int kHeadBase = 2 * kNetFloats;                                   // 39424
+constexpr int kOffWa = kHeadBase, kOffWv = kHeadBase + 512, kOffBa = kHeadBase + 640, kOffBv = kHeadBase + 644,
+              kOffLogStd = kHeadBase + 648, kOffStd = kHeadBase + 652, kOffLogpConst = kHeadBase + 656;
+constexpr int kImageFloats = kHeadBase + 660;                               // packed image
+constexpr int kOffMean = kImageFloats, kOffInv = kImageFloats + 20;
+constexpr int kLdsFloats = kImageFloats + 40;                               // 40124 floats = 160 496 B
+constexpr int kPolicyThreads = 512;
+
+__host__ __device__ constexpr int tile_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---------------------------------------------------------------- weight image
+// nn.Linear layouts: w1 [128][20], w2 [128][128], wa [4][128], wv [1][128] (row = output).
+struct PolicyParams {
+    const float *pi_w1, *pi_b1, *pi_w2, *pi_b2, *wa, *ba, *log_std;
+    const float *vf_w1, *vf_b1, *vf_w2, *vf_b2, *wv, *bv;
+};
+
+__global__ void policy_pack_kernel(PolicyParams p, float* __restrict__ img) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= kImageFloats) return;
+    float v = 0.0f;
+    if (e < kHeadBase) {
+        const int net = e / kNetFloats, o = e % kNetFloats;
+        const float* w1 = net ? p.vf_w1 : p.pi_w1;
+        const float* b1 = net ? p.vf_b1 : p.pi_b1;
+        const float* w2 = net ? p.vf_w2 : p.pi_w2;
+        const float* b2 = net ? p.vf_b2 : p.pi_b2;
+        if (o < kOffB1) {                       // W1p[m][s][lane] = W1[m*32 + i][s + 12 h]
+            const int lane = o % 64, s = (o / 64) % 12, m = o / (64 * 12);
+            const int k = s + 12 * (lane >> 5);
+            v = k < kIn ? w1[(m * 32 + (lane & 31)) * kIn + k] : 0.0f;
+        } else if (o < kOffW2) {                // b1p[m][h][r]
+            const int q = o - kOffB1, r = q % 16, h = (q / 16) % 2, m = q / 32;
+            v = b1[m * 32 + tile_row(r, h)];
+        } else if (o < kOffB2) {                // W2p[m][kt][r4][lane][rr] = W2[m*32 + i][kt*32 + row(4 r4 + rr, h)]
+            const int q = o - kOffW2, rr = q % 4, lane = (q / 4) % 64, r4 = (q / 256) % 4, kt = (q / 1024) % 4, m = q / 4096;
+            v = w2[(m * 32 + (lane & 31)) * kHid + kt * 32 + tile_row(4 * r4 + rr, lane >> 5)];
+        } else {
+            const int q = o - kOffB2, r = q % 16, h = (q / 16) % 2, m = q / 32;
+            v = b2[m * 32 + tile_row(r, h)];
+        }
+    } else {
+        const int q = e - kHeadBase;
+        if (q < 512) {                          // Wa[h][kt][r][o]
+            const int o = q % 4, r = (q / 4) % 16, kt = (q / 64) % 4, h = q / 256;
+            v = p.wa[o * kHid + kt * 32 + tile_row(r, h)];
+        } else if (q < 640) {                   // Wv[h][kt][r]
+            const int z = q - 512, r = z % 16, kt = (z / 16) % 4, h = z / 64;
+            v = p.wv[kt * 32 + tile_row(r, h)];
+        } else if (q < 644) v = p.ba[q - 640];
+        else if (q == 644) v = p.bv[0];
+        else if (q >= 648 && q < 652) v = p.log_std[q - 648];
+        else if (q >= 652 && q < 656) v = expf(p.log_std[q - 652]);
+        else if (q == 656)
+            v = -(p.log_std[0] + p.log_std[1] + p.log_std[2] + p.log_std[3]) - 2.0f * 1.8378770664093453f;  // 4 * 0.5 ln 2 pi
+    }
+    img[e] = v;
+}
+
+// ---------------------------------------------------------------- device helpers
+__device__ __forceinline__ float fast_tanh(float x) {
+    // 1 - 2 / (1 + e^{2x}); v_exp_f32 is 2^x.  |error| < 3e-7 absolute.
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+__device__ __forceinline__ void philox_pol(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                           uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+struct PolicyArgs {
+    const float* image;      // packed weights (kImageFloats)
+    const float* obs;        // [n][20] raw observations
+    const double* rms;       // mean[20], var[20], count — or null: observations are used as they are
+    const float* eps_in;     // [n][4] standard normal draws, or null: Philox in-kernel
+    const uint64_t* tick;    // device counter keying the in-kernel RNG (the env's per-tile tick), or null
+    float* obs_n;            // [n][20] normalised observation (rollout buffer), may be null
+    float* action;           // [n][4] sampled action (unclipped), may be null
+    float* clipped;          // [n][4] clip(action, -1, 1) — what the env receives, may be null
+    float* value;            // [n]
+    float* logp;             // [n], may be null
+    float* eps_out;          // [n][4], may be null
+    int64_t n;
+    uint64_t seed, id_offset;
+    float clip_obs, eps_norm;
+    int32_t deterministic;   // 1: action = mean (SB3 predict(deterministic=True), test_hover.py:17)
+};
+
+// one hidden layer's 64 values per lane: 4 accumulator tiles
+struct Hidden {
+    f32x16 t[4];
+};
+
+__device__ __forceinline__ void bias_init(Hidden& a, const float* __restrict__ lb, int h) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const f32x4* b = reinterpret_cast<const f32x4*>(lb + (m * 2 + h) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = b[q];
+            a.t[m][4 * q] = v.x; a.t[m][4 * q + 1] = v.y; a.t[m][4 * q + 2] = v.z; a.t[m][4 * q + 3] = v.w;
+        }
+    }
+}
+
+__device__ __forceinline__ void tanh_all(Hidden& a) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a.t[m][r] = fast_tanh(a.t[m][r]);
+}
+
+__global__ __launch_bounds__(kPolicyThreads) void policy_forward_kernel(PolicyArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    // ---- stage the weight image (L2-resident after the first workgroups) and the normaliser
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.image);
+        f32x4* dst = reinterpret_cast<f32x4*>(lds);
+        for (int q = threadIdx.x; q < kImageFloats / 4; q += kPolicyThreads) dst[q] = src[q];
+        if (threadIdx.x < kIn) {
+            const float mu = p.rms ? (float)p.rms[threadIdx.x] : 0.0f;
+            const float iv = p.rms ? (float)(1.0 / sqrt(p.rms[kIn + threadIdx.x] + (double)p.eps_norm)) : 1.0f;
+            lds[kOffMean + threadIdx.x] = mu;
+            lds[kOffInv + threadIdx.x] = iv;
+        }
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const float clip = p.rms ? p.clip_obs : 3.0e38f;
+
+    for (int64_t base = (int64_t)blockIdx.x * 256; base < p.n; base += (int64_t)gridDim.x * 256) {
+        const int64_t d = base + wave * 32 + col;   // this lane's drone (both halves of the wave share it)
+        const bool live = d < p.n;
+        // ---- observation: half 0 holds k = 0..11, half 1 holds k = 12..23 (20..23 are zero padding)
+        float x[12];
+        {
+            const f32x4* row = reinterpret_cast<const f32x4*>(p.obs + (live ? d : 0) * kIn);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const bool have = live && (h == 0 || q < 2);
+                const f32x4 v = have ? row[3 * h + q] : f32x4{0.f, 0.f, 0.f, 0.f};
+                x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                const int k = 12 * h + j;
+                if (k < kIn) x[j] = fminf(fmaxf((x[j] - lds[kOffMean + k]) * lds[kOffInv + k], -clip), clip);
+            }
+            if (p.obs_n && live) {
+                f32x4* out = reinterpret_cast<f32x4*>(p.obs_n + d * kIn);
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (h == 0 || q < 2) out[3 * h + q] = f32x4{x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+            }
+        }
+
+        float head[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // 4 action means + value (partial sums of this lane half)
+#pragma unroll 1
+        for (int net = 0; net < 2; ++net) {
+            const float* nb = lds + net * kNetFloats;
+            // ---- layer 1: 20 (padded 24) -> 128
+            Hidden a;
+            bias_init(a, nb + kOffB1, h);
+#pragma unroll
+            for (int s = 0; s < 12; ++s)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    a.t[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(nb[kOffW1 + (m * 12 + s) * 64 + lane], x[s], a.t[m], 0, 0, 0);
+            tanh_all(a);
+            // ---- layer 2: 128 -> 128; the layer-1 tiles are the B operands as they stand
+            Hidden c;
+            bias_init(c, nb + kOffB2, h);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    f32x4 w[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        w[m] = *reinterpret_cast<const f32x4*>(nb + kOffW2 + ((((m * 4 + kt) * 4 + r4) * 64 + lane) * 4));
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+                            c.t[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[m][rr], a.t[kt][4 * r4 + rr], c.t[m], 0, 0, 0);
+                }
+            tanh_all(c);
+            // ---- heads on the VALU: this lane holds 64 of its drone's 128 hidden values
+            if (net == 0) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(lds + kOffWa + (((h * 4 + kt) * 16 + r) * 4));
+                        const float v = c.t[kt][r];
+                        head[0] += w.x * v; head[1] += w.y * v; head[2] += w.z * v; head[3] += w.w * v;
+                    }
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) head[4] += lds[kOffWv + (h * 4 + kt) * 16 + r] * c.t[kt][r];
+            }
+        }
+        // ---- combine the two lane halves, add biases
+#pragma unroll
+        for (int j = 0; j < 5; ++j) head[j] += __shfl_xor(head[j], 32);
+        const float mu[4] = {head[0] + lds[kOffBa], head[1] + lds[kOffBa + 1], head[2] + lds[kOffBa + 2],
+                             head[3] + lds[kOffBa + 3]};
+        const float value = head[4] + lds[kOffBv];
+
+        // ---- sample: eps from memory, or Philox4x32-10 keyed like the env noise (stream tag 'POL1')
+        float eps[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!p.deterministic) {
+            if (p.eps_in) {
+                const f32x4 e = live ? reinterpret_cast<const f32x4*>(p.eps_in)[d] : f32x4{0.f, 0.f, 0.f, 0.f};
+                eps[0] = e.x; eps[1] = e.y; eps[2] = e.z; eps[3] = e.w;
+            } else {
+                const uint64_t t = p.tick ? p.tick[0] : 0ull;
+                uint32_t xr[4];
+                philox_pol((uint32_t)(p.id_offset + (uint64_t)d), (uint32_t)t, (uint32_t)(t >> 32), 0x504F4C31u,
+                           (uint32_t)p.seed, (uint32_t)(p.seed >> 32), xr);
+                constexpr float k24 = 5.9604644775390625e-8f, m2ln2 = -1.3862943611198906f;
+                const float u0 = ((float)(xr[0] >> 8) + 0.5f) * k24, u1 = ((float)(xr[1] >> 8) + 0.5f) * k24;
+                const float u2 = ((float)(xr[2] >> 8) + 0.5f) * k24, u3 = ((float)(xr[3] >> 8) + 0.5f) * k24;
+                const float ra = __builtin_amdgcn_sqrtf(m2ln2 * __log2f(u0)), rb = __builtin_amdgcn_sqrtf(m2ln2 * __log2f(u2));
+                eps[0] = ra * __builtin_amdgcn_cosf(u1); eps[1] = ra * __builtin_amdgcn_sinf(u1);
+                eps[2] = rb * __builtin_amdgcn_cosf(u3); eps[3] = rb * __builtin_amdgcn_sinf(u3);
+            }
+        }
+        float act[4], lp = lds[kOffLogpConst];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            act[j] = mu[j] + lds[kOffStd + j] * eps[j];
+            lp -= 0.5f * eps[j] * eps[j];
+        }
+        if (live) {
+            if (h == 0) {
+                if (p.action) reinterpret_cast<f32x4*>(p.action)[d] = f32x4{act[0], act[1], act[2], act[3]};
+                if (p.clipped)
+                    reinterpret_cast<f32x4*>(p.clipped)[d] =
+                        f32x4{fminf(fmaxf(act[0], -1.f), 1.f), fminf(fmaxf(act[1], -1.f), 1.f),
+                              fminf(fmaxf(act[2], -1.f), 1.f), fminf(fmaxf(act[3], -1.f), 1.f)};
+            } else {
+                p.value[d] = value;
+                if (p.logp) p.logp[d] = lp;
+                if (p.eps_out) reinterpret_cast<f32x4*>(p.eps_out)[d] = f32x4{eps[0], eps[1], eps[2], eps[3]};
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- launchers
+hipError_t launch_policy_pack(const float* const* w /* 13 device pointers in PolicyParams order */, float* image,
+                              hipStream_t s) {
+    PolicyParams p{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12]};
+    hipLaunchKernelGGL(policy_pack_kernel, dim3((kImageFloats + 255) / 256), dim3(256), 0, s, p, image);
+    return hipGetLastError();
+}
+
+hipError_t launch_policy_forward(const float* image, const float* obs, const double* rms, const float* eps_in,
+                                 const uint64_t* tick, float* obs_n, float* action, float* clipped, float* value,
+                                 float* logp, float* eps_out, int64_t n, uint64_t seed, uint64_t id_offset,
+                                 float clip_obs, float eps_norm, int deterministic, int max_blocks, hipStream_t s) {
+    static bool attr_set = false;
+    const size_t lds_bytes = (size_t)kLdsFloats * sizeof(float);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)policy_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    PolicyArgs p{image, obs, rms, eps_in, tick, obs_n, action, clipped, value, logp, eps_out,
+                 n, seed, id_offset, clip_obs, eps_norm, deterministic};
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > max_blocks) blocks = max_blocks;
+    hipLaunchKernelGGL(policy_forward_kernel, dim3((unsigned)blocks), dim3(kPolicyThreads), lds_bytes, s, p);
+    return hipGetLastError();
+}
+
+int policy_image_floats() { return kImageFloats; }
+
+}  // namespace fpv

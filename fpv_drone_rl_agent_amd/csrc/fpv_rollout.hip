@@ -221,6 +221,100 @@ __global__ __launch_bounds__(kRedBlock) void reward_apply_kernel(int64_t n, cons
     }
 }
 
+// ---------------------------------------------------------------- fused-step moment merge
+// Stage 1 (only when there are many tiles): G workgroups each fold a contiguous range of tile rows.
+__global__ __launch_bounds__(256) void tile_partials_reduce_kernel(const double* __restrict__ partials, int64_t tiles,
+                                                                   int64_t per_group, double* __restrict__ group) {
+    __shared__ double l[4][kPartialWords];
+    const int c = threadIdx.x % 64, j = threadIdx.x / 64;   // 4 ways x 64 lanes (44 used)
+    const int64_t t0 = (int64_t)blockIdx.x * per_group, t1 = t0 + per_group < tiles ? t0 + per_group : tiles;
+    double acc = 0.0;
+    if (c < kPartialWords)
+        for (int64_t t = t0 + j; t < t1; t += 4) acc += partials[t * kPartialWords + c];
+    if (c < kPartialWords) l[j][c] = acc;
+    __syncthreads();
+    if (j == 0 && c < kPartialWords) group[(int64_t)blockIdx.x * kPartialWords + c] = (l[0][c] + l[1][c]) + (l[2][c] + l[3][c]);
+}
+
+// Stage 2: one workgroup merges the rows into the running statistics of SB3's RunningMeanStd (obs: 20
+// channels, ret: 1 channel) and snapshots {obs mean[20], obs var[20], obs count, ret mean, ret var, ret count}.
+__global__ __launch_bounds__(64 * kMergeWays) void tile_partials_merge_kernel(const double* __restrict__ rows, int nrows,
+                                                                              double batch_count, double* obs_rms,
+                                                                              double* ret_rms, double* snapshot) {
+    __shared__ double l[kMergeWays][64];
+    const int c = threadIdx.x % 64, j = threadIdx.x / 64;
+    double acc = 0.0;
+    if (c < kPartialWords)
+        for (int b = j; b < nrows; b += kMergeWays) acc += rows[(int64_t)b * kPartialWords + c];
+    l[j][c] = acc;
+    const double obs_count = obs_rms ? obs_rms[40] : 0.0, ret_count = ret_rms ? ret_rms[2] : 0.0;
+    __syncthreads();
+    if (j == 0) {
+        acc = 0.0;
+        for (int w = 0; w < kMergeWays; ++w) acc += l[w][c];
+        l[0][c] = acc;
+    }
+    __syncthreads();
+    if (j != 0) return;
+    if (c < 20 && obs_rms) {
+        const double bm = l[0][c] / batch_count;
+        double bv = l[0][20 + c] / batch_count - bm * bm;
+        if (bv < 0.0) bv = 0.0;
+        const double mean = obs_rms[c], var = obs_rms[20 + c], delta = bm - mean, tot = obs_count + batch_count;
+        const double nm = mean + delta * batch_count / tot;
+        const double nv = (var * obs_count + bv * batch_count + delta * delta * obs_count * batch_count / tot) / tot;
+        obs_rms[c] = nm; obs_rms[20 + c] = nv;
+        if (snapshot) { snapshot[c] = nm; snapshot[20 + c] = nv; }
+        if (c == 0) { obs_rms[40] = tot; if (snapshot) snapshot[40] = tot; }
+    }
+    if (c == 40 && ret_rms) {
+        const double bm = l[0][40] / batch_count;
+        double bv = l[0][41] / batch_count - bm * bm;
+        if (bv < 0.0) bv = 0.0;
+        const double mean = ret_rms[0], var = ret_rms[1], delta = bm - mean, tot = ret_count + batch_count;
+        const double nm = mean + delta * batch_count / tot;
+        const double nv = (var * ret_count + bv * batch_count + delta * delta * ret_count * batch_count / tot) / tot;
+        ret_rms[0] = nm; ret_rms[1] = nv; ret_rms[2] = tot;
+        if (snapshot) { snapshot[41] = nm; snapshot[42] = nv; snapshot[43] = tot; }
+    }
+}
+
+hipError_t launch_moments_merge_tiles(int64_t tiles, const double* partials, double batch_count, double* obs_rms,
+                                      double* ret_rms, double* snapshot, double* scratch, hipStream_t s) {
+    const double* rows = partials;
+    int nrows = (int)tiles;
+    if (tiles > 1024) {
+        const int groups = 256;
+        const int64_t per_group = (tiles + groups - 1) / groups;
+        hipLaunchKernelGGL(tile_partials_reduce_kernel, dim3(groups), dim3(256), 0, s, partials, tiles, per_group, scratch);
+        rows = scratch;
+        nrows = (int)((tiles + per_group - 1) / per_group);
+    }
+    hipLaunchKernelGGL(tile_partials_merge_kernel, dim3(1), dim3(64 * kMergeWays), 0, s, rows, nrows, batch_count, obs_rms,
+                       ret_rms, snapshot);
+    return hipGetLastError();
+}
+
+// r_norm[t][i] = clip(r[t][i] / sqrt(var_t + eps)) with the return variance as it stood after step t
+__global__ __launch_bounds__(256) void reward_finalize_kernel(int64_t T, int64_t n, const float* __restrict__ raw,
+                                                              const double* __restrict__ snapshots, float clip, float eps,
+                                                              float* __restrict__ out) {
+    const int64_t t = blockIdx.y;
+    const float inv = (float)(1.0 / sqrt(snapshots[t * kPartialWords + 42] + (double)eps));
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[t * n + i] = fminf(fmaxf(raw[t * n + i] * inv, -clip), clip);
+}
+
+hipError_t launch_reward_finalize(int64_t T, int64_t n, const float* raw, const double* snapshots, float clip, float eps,
+                                  float* out, hipStream_t s) {
+    int64_t bx = (n + 256 * 4 - 1) / (256 * 4);
+    if (bx > 1024) bx = 1024;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(reward_finalize_kernel, dim3((unsigned)bx, (unsigned)T), dim3(256), 0, s, T, n, raw, snapshots, clip,
+                       eps, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_normalize_reward(int64_t n, const float* r, const uint8_t* done, float* ret, float* r_out,
                                    double* rms, int32_t update, float gamma, float clip, float eps, double* scratch,
                                    hipStream_t s) {

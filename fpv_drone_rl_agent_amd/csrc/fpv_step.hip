@@ -76,9 +76,9 @@ __device__ __forceinline__ void store_obs_tile(const T (&o)[kObsWords], T* __res
 }
 
 // ---------------------------------------------------------------- K1
-template <typename T, bool NOISE>
+template <typename T, bool NOISE, bool FUSED>
 __global__ __launch_bounds__(kTile) void step_kernel(StepArgs<T> p) {
-    __shared__ Vec4<T> lds[kTile * kObsWords / 4];
+    __shared__ Vec4<T> lds[kTile * kObsWords / 4 + (FUSED ? kTile / 4 : 0)];
     const int lane = threadIdx.x;
     const int64_t tile = blockIdx.x;
     const int64_t i = tile * kTile + lane;
@@ -158,7 +158,39 @@ __global__ __launch_bounds__(kTile) void step_kernel(StepArgs<T> p) {
         p.terminated[i] = (bits & kInfoTerm) ? 1 : 0;
         p.truncated[i] = (bits & kInfoTrunc) ? 1 : 0;
     }
-    store_obs_tile(o, p.obs, tile, lane, p.n, lds);
+    if constexpr (FUSED) {
+        // VecNormalize bookkeeping in the same pass (train_hover.py:43): done mask, discounted return
+        // ret = ret * gamma + r (cleared at episode ends), and this tile's fp64 moment sums of the
+        // returned observations and of ret — merged across tiles by moments_merge_tiles.
+        T* lds_w = reinterpret_cast<T*>(lds);
+        if (live && p.done) p.done[i] = done ? 1 : 0;
+        T ret = T(0);
+        if (p.ret) {
+            ret = live ? p.ret[i] * (T)p.gamma + reward : T(0);
+            if (live) p.ret[i] = done ? T(0) : ret;
+        }
+        lds_w[kTile * kObsWords + lane] = ret;
+        store_obs_tile(o, p.obs, tile, lane, p.n, lds);   // writes the tile and barriers before reading it back
+        if (p.partials) {
+            const int rows = (int)((p.n - tile * kTile) < kTile ? (p.n - tile * kTile) : kTile);
+            double acc = 0.0;
+            if (lane < 2 * kObsWords) {
+                const int c = lane < kObsWords ? lane : lane - kObsWords;
+                for (int r = 0; r < rows; ++r) {
+                    const double v = (double)lds_w[r * kObsWords + c];
+                    acc += lane < kObsWords ? v : v * v;
+                }
+            } else if (lane < 2 * kObsWords + 2) {
+                for (int r = 0; r < rows; ++r) {
+                    const double v = (double)lds_w[kTile * kObsWords + r];
+                    acc += lane == 2 * kObsWords ? v : v * v;
+                }
+            }
+            if (lane < kPartialWords) p.partials[tile * kPartialWords + lane] = acc;
+        }
+    } else {
+        store_obs_tile(o, p.obs, tile, lane, p.n, lds);
+    }
 }
 
 // ---------------------------------------------------------------- K2 masked reset
@@ -242,8 +274,16 @@ __global__ void tick_fill_kernel(uint64_t* tick, int64_t tiles, uint64_t v) {
 template <typename T>
 hipError_t launch_step(const StepArgs<T>& a, bool noise, hipStream_t s) {
     const int64_t tiles = (a.n + kTile - 1) / kTile;
-    if (noise) hipLaunchKernelGGL((step_kernel<T, true>), dim3((unsigned)tiles), dim3(kTile), 0, s, a);
-    else hipLaunchKernelGGL((step_kernel<T, false>), dim3((unsigned)tiles), dim3(kTile), 0, s, a);
+    const bool fused = a.done || a.ret || a.partials;
+    if constexpr (sizeof(T) == 4) {
+        if (fused) {
+            if (noise) hipLaunchKernelGGL((step_kernel<T, true, true>), dim3((unsigned)tiles), dim3(kTile), 0, s, a);
+            else hipLaunchKernelGGL((step_kernel<T, false, true>), dim3((unsigned)tiles), dim3(kTile), 0, s, a);
+            return hipGetLastError();
+        }
+    }
+    if (noise) hipLaunchKernelGGL((step_kernel<T, true, false>), dim3((unsigned)tiles), dim3(kTile), 0, s, a);
+    else hipLaunchKernelGGL((step_kernel<T, false, false>), dim3((unsigned)tiles), dim3(kTile), 0, s, a);
     return hipGetLastError();
 }
 template hipError_t launch_step<float>(const StepArgs<float>&, bool, hipStream_t);

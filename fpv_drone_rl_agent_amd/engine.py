@@ -35,6 +35,7 @@ class FpvEngine:
             raise ValueError("FpvEngine runs on a HIP device only")
         self.device = dev
         self.num_envs = int(num_envs)
+        self.id_offset = int(id_offset)
         self.dtype = torch.float64 if precision == "f64" else torch.float32
         self._f64 = precision == "f64"
         cfg = L.FpvConfig(self.num_envs, dev.index or 0, L.FPV_F64 if self._f64 else L.FPV_F32,
@@ -64,6 +65,9 @@ class FpvEngine:
         led = L.FpvLedger(cap, rows, self.led_count.data_ptr(), self.led_idx.data_ptr(), self.led_info.data_ptr(),
                           self.led_tag.data_ptr(), self.led_ret.data_ptr(), self.led_obs.data_ptr())
         L.check(self.lib.fpv_ledger_bind(self._h, C.byref(led)), "fpv_ledger_bind")
+        tp = C.c_void_p()
+        L.check(self.lib.fpv_tick_ptr(self._h, C.byref(tp)), "fpv_tick_ptr")
+        self.tick_ptr = tp.value  # device address of the agent-tick counter (keys in-kernel RNG streams)
 
     # -- lifecycle -----------------------------------------------------------------
     def close(self):
@@ -101,6 +105,22 @@ class FpvEngine:
         L.check(fn(self._h, _ptr(actions), _ptr(obs), _ptr(reward), _ptr(terminated), _ptr(truncated),
                    _stream(self.device)), "fpv_step")
         return obs, reward, terminated, truncated
+
+    def step_fused(self, actions, *, done=None, ret=None, partials=None, gamma: float = 0.99, obs=None, reward=None):
+        """fpv_step_fused: the env step plus VecNormalize's per-step bookkeeping (done mask, discounted-return
+        accumulator, per-tile moment sums) in the same kernel.  fp32 engines only."""
+        if self._f64:
+            raise ValueError("step_fused runs on fp32 engines")
+        if actions.dtype != self.dtype or actions.device != self.device or not actions.is_contiguous() \
+                or actions.shape != (self.num_envs, L.ACT_WORDS):
+            raise ValueError("actions must be a contiguous [num_envs, 4] device tensor of the engine's dtype")
+        obs = self.obs if obs is None else obs
+        reward = self.reward if reward is None else reward
+        ex = L.FpvStepExtras(done.data_ptr() if done is not None else None, ret.data_ptr() if ret is not None else None,
+                             partials.data_ptr() if partials is not None else None, float(gamma), 0)
+        L.check(self.lib.fpv_step_fused(self._h, _ptr(actions), _ptr(obs), _ptr(reward), _ptr(self.terminated),
+                                        _ptr(self.truncated), C.byref(ex), _stream(self.device)), "fpv_step_fused")
+        return obs, reward, self.terminated, self.truncated
 
     # -- state blobs ----------------------------------------------------------------
     def get_state(self) -> torch.Tensor:

@@ -106,3 +106,22 @@ class RewardNorm:
                                               _ptr(self.rms), 1 if update else 0, self.gamma, self.clip, self.eps,
                                               _stream(r.device)), "fpv_normalize_reward")
         return out
+
+
+def moments_merge(partials, batch_count, obs_rms=None, ret_rms=None, snapshot=None):
+    """Fold the per-tile sums written by FpvEngine.step_fused into the running statistics (fpv_moments_merge)."""
+    _need(partials, torch.float64, "partials")
+    L.check(L.load().fpv_moments_merge(partials.shape[0], _ptr(partials), float(batch_count), _ptr(obs_rms),
+                                       _ptr(ret_rms), _ptr(snapshot), _stream(partials.device)), "fpv_moments_merge")
+
+
+def reward_finalize(raw, snapshots, clip=10.0, eps=1e-8, out=None):
+    """out[t] = clip(raw[t] / sqrt(ret_var_t + eps)) with ret_var_t = snapshots[t, 42] (fpv_reward_finalize)."""
+    _need(raw, torch.float32, "raw")
+    _need(snapshots, torch.float64, "snapshots")
+    T, n = raw.shape
+    if out is None:
+        out = torch.empty_like(raw)
+    L.check(L.load().fpv_reward_finalize(T, n, _ptr(raw), _ptr(snapshots), float(clip), float(eps), _ptr(out),
+                                         _stream(raw.device)), "fpv_reward_finalize")
+    return out

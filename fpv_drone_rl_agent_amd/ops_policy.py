@@ -1,0 +1,80 @@
+"""FusedPolicy — the rollout-time forward of policy.ActorCritic as ONE HIP kernel (fpv_policy_forward):
+VecNormalize.normalize_obs -> pi and V MLPs on exact-fp32 MFMA -> Gaussian sample -> log-prob -> Box clip.
+The torch module keeps owning the parameters; call load() after every optimiser step."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .policy import ActorCritic
+
+
+def _ptr(t):
+    """device address of a tensor, a raw integer address, or None"""
+    if t is None:
+        return None
+    return t if isinstance(t, int) else t.data_ptr()
+
+
+class FusedPolicy:
+    def __init__(self, module: ActorCritic, device=None, seed: int = 0, id_offset: int = 0):
+        if (module.obs_dim, module.act_dim, module.hidden) != (20, 4, 128):
+            raise ValueError("the fused kernel is built for obs 20, act 4, hidden 128 (train_hover.py:57)")
+        self.module = module
+        p = next(module.parameters())
+        if not p.is_cuda:
+            raise RuntimeError("FusedPolicy needs the module on a HIP device: there is no CPU fallback")
+        self.device = p.device if device is None else torch.device(device)
+        self.seed, self.id_offset = int(seed), int(id_offset)
+        self.lib = L.load()
+        h = C.c_void_p()
+        L.check(self.lib.fpv_policy_create(self.device.index or 0, C.byref(h)), "fpv_policy_create")
+        self._h = h
+        self.load()
+
+    def _params(self):
+        m = self.module
+        ps = [m.pi[0].weight, m.pi[0].bias, m.pi[2].weight, m.pi[2].bias, m.action_net.weight, m.action_net.bias,
+              m.log_std, m.vf[0].weight, m.vf[0].bias, m.vf[2].weight, m.vf[2].bias, m.value_net.weight,
+              m.value_net.bias]
+        for t in ps:
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
+                raise ValueError("policy parameters must be contiguous fp32 tensors on the policy's device")
+        return ps
+
+    def load(self) -> None:
+        """Repack the module's current parameters into the kernel's MFMA-ordered weight image."""
+        ps = self._params()
+        arr = (C.c_void_p * 13)(*[t.data_ptr() for t in ps])
+        L.check(self.lib.fpv_policy_load(self._h, arr, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+                "fpv_policy_load")
+
+    def forward(self, obs, *, rms=None, eps_in=None, tick=None, obs_n=None, action=None, clipped=None, value=None,
+                logp=None, eps_out=None, clip_obs: float = 10.0, eps_norm: float = 1e-8, deterministic: bool = False):
+        """obs [n,20] fp32 raw observations; rms = fp64[41] VecNormalize statistics or None.  Output tensors
+        are written in place when given; value is always produced.  Returns dict of the outputs."""
+        n = obs.shape[0]
+        if obs.dtype != torch.float32 or not obs.is_contiguous() or obs.shape[1] != 20:
+            raise ValueError("obs must be a contiguous [n,20] fp32 device tensor")
+        if value is None:
+            value = torch.empty((n,), dtype=torch.float32, device=obs.device)
+        io = L.FpvPolicyIo(n, _ptr(obs), _ptr(rms), _ptr(eps_in), _ptr(tick), _ptr(obs_n), _ptr(action), _ptr(clipped),
+                           _ptr(value), _ptr(logp), _ptr(eps_out), self.seed, self.id_offset, float(clip_obs),
+                           float(eps_norm), 1 if deterministic else 0, 0)
+        L.check(self.lib.fpv_policy_forward(self._h, C.byref(io),
+                                            C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)),
+                "fpv_policy_forward")
+        return {"obs_n": obs_n, "action": action, "clipped": clipped, "value": value, "logp": logp, "eps": eps_out}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.fpv_policy_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

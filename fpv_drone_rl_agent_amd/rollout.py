@@ -12,6 +12,15 @@ stack simulation/train_hover.py:42-60 builds — as restated in SURVEY.md §3.5:
 
 Every per-step operation is asynchronous device work on one stream; the T-step loop is
 captured once into a HIP graph and replayed, so the host issues one launch per rollout.
+
+Two step implementations:
+  * fused (default): THREE kernels per step — fpv_policy_forward (normalise -> pi, V on fp32 MFMA ->
+    sample -> log-prob -> clip, writing straight into the rollout buffer), fpv_step_fused (env step +
+    done mask + discounted return + per-tile moment sums), fpv_moments_merge (both running statistics
+    + a snapshot).  Reward scaling is applied once per rollout (fpv_reward_finalize) with each step's
+    own statistics snapshot, which is arithmetically what VecNormalize does step by step.
+  * unfused (`fused=False`): the same semantics through torch ops + the stand-alone normaliser
+    kernels; kept as the readable reference of the fused path (tests compare both to the oracle).
 """
 from __future__ import annotations
 
@@ -20,13 +29,14 @@ import torch
 from . import dist as D
 from . import ops
 from .engine import FpvEngine
+from .ops_policy import FusedPolicy
 from .policy import ActorCritic
 
 
 class RolloutCollector:
     def __init__(self, engine: FpvEngine, policy: ActorCritic, n_steps: int = 32, gamma: float = 0.99,
                  lam: float = 0.95, norm_obs: bool = True, norm_reward: bool = True, use_graph: bool = True,
-                 clip_obs: float = 10.0, clip_reward: float = 10.0):
+                 clip_obs: float = 10.0, clip_reward: float = 10.0, fused: bool = True, policy_seed: int = 0):
         if engine.dtype != torch.float32:
             raise ValueError("the rollout collector runs on an fp32 engine")
         self.engine, self.policy = engine, policy
@@ -42,17 +52,24 @@ class RolloutCollector:
         self.buf_obs = torch.zeros((T, N, 20), dtype=f32, device=dev)
         self.buf_act = torch.zeros((T, N, 4), dtype=f32, device=dev)
         self.buf_rew = torch.zeros((T, N), dtype=f32, device=dev)
-        self.buf_start = torch.zeros((T, N), dtype=u8, device=dev)
+        self._starts = torch.zeros((T + 1, N), dtype=u8, device=dev)   # row t: episode_start before step t
+        self._starts[T].fill_(1)
+        self.buf_start = self._starts[:T]
         self.buf_val = torch.zeros((T, N), dtype=f32, device=dev)
         self.buf_logp = torch.zeros((T, N), dtype=f32, device=dev)
         self.adv = torch.zeros((T, N), dtype=f32, device=dev)
         self.ret = torch.zeros((T, N), dtype=f32, device=dev)
         self.cur_obs = torch.zeros((N, 20), dtype=f32, device=dev)       # normalised s_t
-        self.episode_start = torch.ones((N,), dtype=u8, device=dev)
+        self.episode_start = self._starts[T]                                # carried into the next rollout
         self.done = torch.zeros((N,), dtype=u8, device=dev)
         self.clipped = torch.zeros((N, 4), dtype=f32, device=dev)
         self.last_val = torch.zeros((N,), dtype=f32, device=dev)
-        self.rms_hist = torch.zeros((T, 41), dtype=torch.float64, device=dev)
+        self.snap = torch.zeros((T, 44), dtype=torch.float64, device=dev)   # {obs_rms[41], ret_rms[3]} after step t
+        self.fused = bool(fused)
+        if self.fused:
+            self.fp = FusedPolicy(policy, seed=policy_seed, id_offset=engine.id_offset)
+            self.partials = torch.zeros((engine.tiles, 44), dtype=torch.float64, device=dev)
+            self.raw_rew = torch.zeros((T, N), dtype=f32, device=dev)
         self.stats = torch.zeros((3,), dtype=torch.float64, device=dev)
         self._graph = None
         self._tick0 = 0
@@ -68,9 +85,24 @@ class RolloutCollector:
             out.copy_(raw)
 
     def _step(self, t: int) -> None:
+        if self.fused:
+            self._step_fused(t)
+        else:
+            self._step_torch(t)
+
+    def _step_fused(self, t: int) -> None:
+        eng = self.engine
+        self.fp.forward(eng.obs, rms=self.obs_norm.rms if self.norm_obs else None, tick=eng.tick_ptr,
+                        obs_n=self.buf_obs[t], action=self.buf_act[t], clipped=self.clipped, value=self.buf_val[t],
+                        logp=self.buf_logp[t], clip_obs=self.obs_norm.clip, eps_norm=self.obs_norm.eps)
+        eng.step_fused(self.clipped, done=self._starts[t + 1], ret=self.rew_norm.ret, partials=self.partials,
+                       gamma=self.gamma, reward=self.raw_rew[t])
+        ops.moments_merge(self.partials, self.N, obs_rms=self.obs_norm.rms if self.norm_obs else None,
+                          ret_rms=self.rew_norm.rms if self.norm_reward else None, snapshot=self.snap[t])
+
+    def _step_torch(self, t: int) -> None:
         eng, pol = self.engine, self.policy
         self.buf_obs[t].copy_(self.cur_obs)
-        self.buf_start[t].copy_(self.episode_start)
         eps = torch.randn((self.N, 4), dtype=torch.float32, device=self.device)
         action, value, logp = pol.act(self.cur_obs, eps)
         self.buf_act[t].copy_(action)
@@ -80,14 +112,15 @@ class RolloutCollector:
         eng.step(self.clipped)
         torch.bitwise_or(eng.terminated, eng.truncated, out=self.done)
         self._normalise_obs(eng.obs, self.cur_obs)
-        self.rms_hist[t].copy_(self.obs_norm.rms)
+        self.snap[t, :41].copy_(self.obs_norm.rms)
         if self.norm_reward:
             self.rew_norm(eng.reward, self.done, out=self.buf_rew[t])
         else:
             self.buf_rew[t].copy_(eng.reward)
-        self.episode_start.copy_(self.done)
+        self._starts[t + 1].copy_(self.done)
 
     def _all_steps(self) -> None:
+        self._starts[0].copy_(self._starts[self.T])
         for t in range(self.T):
             self._step(t)
 
@@ -97,7 +130,7 @@ class RolloutCollector:
         self.engine.reset()
         self._normalise_obs(self.engine.obs, self.cur_obs)
         self.rew_norm.ret.zero_()
-        self.episode_start.fill_(1)
+        self._starts[self.T].fill_(1)
         self._tick0 = self.engine.get_tick()
         self._started = True
 
@@ -114,6 +147,11 @@ class RolloutCollector:
             self._all_steps()
         self._graph = g
 
+    def sync_policy(self) -> None:
+        """Repack the torch parameters into the fused kernel's weight image (after every optimiser step)."""
+        if self.fused:
+            self.fp.load()
+
     def collect(self) -> dict:
         """Collect T steps from every drone, compute GAE and the global advantage statistics."""
         if not self._started:
@@ -126,8 +164,18 @@ class RolloutCollector:
             self._graph.replay()
         else:
             self._all_steps()
-        with torch.no_grad():
-            self.last_val.copy_(self.policy.value(self.cur_obs))
+        if self.fused:
+            self.fp.forward(eng.obs, rms=self.obs_norm.rms if self.norm_obs else None, obs_n=self.cur_obs,
+                            value=self.last_val, deterministic=True, clip_obs=self.obs_norm.clip,
+                            eps_norm=self.obs_norm.eps)
+            if self.norm_reward:
+                ops.reward_finalize(self.raw_rew, self.snap, clip=self.rew_norm.clip, eps=self.rew_norm.eps,
+                                    out=self.buf_rew)
+            else:
+                self.buf_rew.copy_(self.raw_rew)
+        else:
+            with torch.no_grad():
+                self.last_val.copy_(self.policy.value(self.cur_obs))
         self._bootstrap_timeouts()
         ops.gae(self.buf_rew, self.buf_val, self.buf_start, self.last_val, self.episode_start, self.gamma,
                 self.lam, advantages=self.adv, returns=self.ret, stats=self.stats)
@@ -156,10 +204,13 @@ class RolloutCollector:
         d_idx = eng.led_idx[rows].to(torch.int64)
         tobs = eng.led_obs[rows]
         if self.norm_obs:
-            rms = self.rms_hist[t_idx]                      # statistics as they were at that step
+            rms = self.snap[t_idx]                          # statistics as they were at that step
             mean, var = rms[:, :20], rms[:, 20:40]
             tobs = torch.clamp((tobs.double() - mean) / torch.sqrt(var + self.obs_norm.eps), -self.obs_norm.clip,
                                self.obs_norm.clip).float()
-        with torch.no_grad():
-            v = self.policy.value(tobs)
+        if self.fused:
+            v = self.fp.forward(tobs.contiguous(), deterministic=True)["value"]
+        else:
+            with torch.no_grad():
+                v = self.policy.value(tobs)
         self.buf_rew.index_put_((t_idx, d_idx), self.gamma * v, accumulate=True)

@@ -98,6 +98,37 @@ int fpv_step(fpv_env* env, const float* actions, float* obs, float* reward, uint
 int fpv_step_f64(fpv_env* env, const double* actions, double* obs, double* reward,
                  uint8_t* terminated, uint8_t* truncated, void* stream);
 
+/* fpv_step plus SB3 VecNormalize's per-step bookkeeping in the same kernel (simulation/train_hover.py:43):
+ * extras.done [num_envs] = terminated | truncated; extras.ret [num_envs] is VecNormalize's discounted-return
+ * accumulator (ret = ret * gamma + reward, cleared where an episode ended); extras.partials
+ * [ceil(num_envs/64)][FPV_PARTIAL_WORDS] receives, per 64-drone tile, the fp64 sums
+ * {sum obs[20], sum obs^2[20], sum ret, sum ret^2, 0, 0} of the returned observations and of ret, to be
+ * folded into the running statistics by fpv_moments_merge.  Any of the three may be NULL.  fp32 handles. */
+#define FPV_PARTIAL_WORDS 44
+typedef struct {
+    uint8_t* done;
+    float* ret;
+    double* partials;
+    float gamma;
+    int32_t reserved;
+} fpv_step_extras;
+int fpv_step_fused(fpv_env* env, const float* actions, float* obs, float* reward, uint8_t* terminated,
+                   uint8_t* truncated, const fpv_step_extras* extras, void* stream);
+
+/* RunningMeanStd.update for both VecNormalize statistics from the per-tile sums of fpv_step_fused:
+ * obs_rms = double[41] {mean[20], var[20], count}, ret_rms = double[3] {mean, var, count} (either may be
+ * NULL); snapshot (optional double[FPV_PARTIAL_WORDS]) receives {obs_rms[41], ret_rms[3]} after the merge. */
+int fpv_moments_merge(int64_t tiles, const double* partials, double batch_count, double* obs_rms,
+                      double* ret_rms, double* snapshot, void* stream);
+
+/* VecNormalize.normalize_reward applied after the fact: out[t][i] = clip(raw[t][i] / sqrt(var_t + eps)) with
+ * var_t = snapshots[t][42], the return variance as it stood after step t.  raw/out are [T][n]; out may alias raw. */
+int fpv_reward_finalize(int64_t T, int64_t n, const float* raw, const double* snapshots, float clip, float eps,
+                        float* out, void* stream);
+
+/* Device address of the handle's agent-tick counter (uint64; keys in-kernel RNG streams, e.g. fpv_policy_io.tick). */
+int fpv_tick_ptr(fpv_env* env, const uint64_t** out);
+
 /* Canonical state blobs [num_envs][36] in the handle's precision (docs/SPEC.md §2); used by
  * parity tests and the synthetic random-init benchmark. */
 int fpv_get_state(fpv_env* env, void* state_out, void* stream);
@@ -141,6 +172,40 @@ int fpv_normalize(int64_t n, int32_t d, const float* x, float* y, double* rms, i
 int fpv_normalize_reward(int64_t n, const float* r, const uint8_t* done, float* ret, float* r_out,
                          double* rms, int32_t update, float gamma, float clip, float eps,
                          void* stream);
+
+/* ---- fused actor-critic forward (SB3 MlpPolicy, net_arch pi/vf [128,128], tanh) ----
+ * Stands under model.policy.forward(obs) / model.predict(obs, deterministic) of the SB3 learner in
+ * simulation/train_hover.py:47-60 and simulation/test_hover.py:17 during rollout collection; the
+ * parameters stay torch tensors owned by the caller (the PPO update differentiates through torch). */
+typedef struct fpv_policy fpv_policy;
+
+int fpv_policy_create(int32_t device, fpv_policy** out);
+int fpv_policy_destroy(fpv_policy* pol);
+/* weights: HOST array of 13 DEVICE pointers to contiguous fp32 nn.Linear tensors, in this order:
+ * pi.0.weight[128][20], pi.0.bias[128], pi.2.weight[128][128], pi.2.bias[128], action_net.weight[4][128],
+ * action_net.bias[4], log_std[4], vf.0.weight, vf.0.bias, vf.2.weight, vf.2.bias, value_net.weight[1][128],
+ * value_net.bias[1].  Repacks them into the kernel's MFMA-ordered image (call after every update). */
+int fpv_policy_load(fpv_policy* pol, const float* const* weights, void* stream);
+
+typedef struct {
+    int64_t n;               /* rows */
+    const float* obs;        /* [n][20] raw observations */
+    const double* rms;       /* VecNormalize statistics {mean[20], var[20], count} or NULL (obs used as is) */
+    const float* eps_in;     /* [n][4] N(0,1) draws, or NULL: Philox4x32-10 in-kernel */
+    const uint64_t* tick;    /* device counter keying the in-kernel draws (NULL = 0) */
+    float* obs_n;            /* [n][20] normalised observations out (may be NULL) */
+    float* action;           /* [n][4] a = mu + sigma * eps (may be NULL) */
+    float* clipped;          /* [n][4] clip(a, -1, 1): what fpv_step receives (may be NULL) */
+    float* value;            /* [n] */
+    float* logp;             /* [n] log pi(a) (may be NULL) */
+    float* eps_out;          /* [n][4] the draws used (may be NULL) */
+    uint64_t seed, id_offset;
+    float clip_obs, eps_norm;
+    int32_t deterministic;   /* 1: a = mu */
+    int32_t reserved;
+} fpv_policy_io;
+
+int fpv_policy_forward(fpv_policy* pol, const fpv_policy_io* io, void* stream);
 
 const char* fpv_last_error(void);
 int fpv_version(void);

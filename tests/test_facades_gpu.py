@@ -96,8 +96,9 @@ def test_vecnormalize_matches_sb3_arithmetic_and_roundtrips(oracle, tmp_path):
     venv.close()
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("use_graph", [False, True])
-def test_rollout_collector_matches_oracle_replay(oracle, use_graph):
+def test_rollout_collector_matches_oracle_replay(oracle, use_graph, fused):
     from fpv_drone_rl_agent_amd.engine import FpvEngine
     from fpv_drone_rl_agent_amd.policy import ActorCritic
     from fpv_drone_rl_agent_amd.rollout import RolloutCollector
@@ -106,7 +107,7 @@ def test_rollout_collector_matches_oracle_replay(oracle, use_graph):
     pol = ActorCritic().cuda()
     pol_cpu = copy.deepcopy(pol).cpu().double()
     eng = FpvEngine(n, 0, noise_ratio=0.0)
-    col = RolloutCollector(eng, pol, n_steps=T, gamma=gamma, lam=lam, use_graph=use_graph)
+    col = RolloutCollector(eng, pol, n_steps=T, gamma=gamma, lam=lam, use_graph=use_graph, fused=fused)
     col.start()
     ref_norm = oracle.VecNormalizeRef(n, gamma=gamma)
     _, obs_reset = oracle.reset_states(n)

@@ -1,0 +1,90 @@
+"""Fused HIP actor-critic forward (exact-fp32 MFMA) versus the torch module it packs (fp32 reference of the
+same op): same eps in -> same action / value / log-prob / clip / normalised obs within fp32 tolerance."""
+import math
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _setup(seed=0):
+    from fpv_drone_rl_agent_amd.ops_policy import FusedPolicy
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    torch.manual_seed(seed)
+    m = ActorCritic().cuda()
+    with torch.no_grad():           # non-trivial biases / log_std so that every term of the image is exercised
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.3)
+        m.action_net.weight.mul_(30.0)
+    return m, FusedPolicy(m, seed=11)
+
+
+@pytest.mark.parametrize("n", [1, 31, 256, 5000, 65536])
+def test_fused_forward_matches_torch(n):
+    m, fp = _setup()
+    g = torch.Generator(device="cuda").manual_seed(n)
+    obs = torch.randn(n, 20, device="cuda", generator=g) * 3 + 1
+    eps = torch.randn(n, 4, device="cuda", generator=g)
+    rms = torch.cat([torch.randn(20, generator=g, device="cuda").double(),
+                     torch.rand(20, generator=g, device="cuda").double() * 4 + 0.1, torch.tensor([9.0], device="cuda").double()])
+    out = {k: torch.zeros(n, d, device="cuda") for k, d in (("obs_n", 20), ("action", 4), ("clipped", 4), ("eps_out", 4))}
+    value, logp = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    fp.forward(obs, rms=rms, eps_in=eps, value=value, logp=logp, **out)
+    with torch.no_grad():
+        obs_ref = torch.clamp((obs.double() - rms[:20]) / torch.sqrt(rms[20:40] + 1e-8), -10, 10).float()
+        a_ref, v_ref, lp_ref = m.act(obs_ref, eps)
+    assert torch.allclose(out["obs_n"], obs_ref, atol=1e-5, rtol=1e-5)
+    assert torch.allclose(out["action"], a_ref, atol=2e-4, rtol=1e-4), (out["action"] - a_ref).abs().max()
+    assert torch.allclose(value, v_ref, atol=2e-4, rtol=1e-4), (value - v_ref).abs().max()
+    assert torch.allclose(logp, lp_ref, atol=1e-4, rtol=1e-5)
+    assert torch.equal(out["clipped"], out["action"].clamp(-1, 1)) and torch.equal(out["eps_out"], eps)
+    assert (out["clipped"].abs() == 1).any() or n < 31   # the clip is exercised
+
+
+def test_raw_obs_path_and_deterministic():
+    m, fp = _setup(1)
+    obs = torch.randn(777, 20, device="cuda")
+    a = torch.zeros(777, 4, device="cuda")
+    r = fp.forward(obs, action=a, deterministic=True)
+    with torch.no_grad():
+        mu, v = m.mean_value(obs)
+    assert torch.allclose(a, mu, atol=2e-4, rtol=1e-4) and torch.allclose(r["value"], v, atol=2e-4, rtol=1e-4)
+
+
+def test_reload_after_parameter_update():
+    m, fp = _setup(2)
+    obs = torch.randn(300, 20, device="cuda")
+    v0 = fp.forward(obs, deterministic=True)["value"].clone()
+    with torch.no_grad():
+        m.value_net.bias.add_(1.5)
+        m.vf[2].weight.mul_(0.5)
+    fp.load()
+    v1 = fp.forward(obs, deterministic=True)["value"]
+    with torch.no_grad():
+        assert torch.allclose(v1, m.value(obs), atol=2e-4, rtol=1e-4) and not torch.allclose(v0, v1)
+
+
+def test_in_kernel_sampling_is_standard_normal_and_keyed():
+    m, fp = _setup(3)
+    n = 200000
+    obs = torch.randn(n, 20, device="cuda")
+    eps = torch.zeros(n, 4, device="cuda")
+    lp = torch.zeros(n, device="cuda")
+    a = torch.zeros(n, 4, device="cuda")
+    tick = torch.zeros(4, dtype=torch.int64, device="cuda")
+    fp.forward(obs, eps_out=eps, logp=lp, action=a, tick=tick)
+    e = eps.cpu().numpy()
+    assert abs(e.mean()) < 0.01 and abs(e.std() - 1) < 0.01 and abs((e ** 4).mean() - 3) < 0.1
+    assert abs(np.corrcoef(e[:, 0], e[:, 1])[0, 1]) < 0.01 and abs(np.corrcoef(e[:-1, 2], e[1:, 2])[0, 1]) < 0.01
+    with torch.no_grad():
+        mu, _ = m.mean_value(obs)
+        assert torch.allclose(lp, m.log_prob(mu, a), atol=2e-3, rtol=1e-4)
+    eps2 = torch.zeros(n, 4, device="cuda")
+    fp.forward(obs, eps_out=eps2, tick=tick)
+    assert torch.equal(eps, eps2)            # same (seed, id, tick) -> same draws
+    tick += 1
+    fp.forward(obs, eps_out=eps2, tick=tick)
+    assert not torch.equal(eps, eps2)

@@ -78,3 +78,42 @@ def test_reward_norm_matches_vecnormalize(oracle):
         assert np.allclose(out.cpu().numpy(), r_ref, atol=2e-5, rtol=1e-5)
         assert np.allclose(rw.ret.cpu().numpy(), ref.returns, atol=1e-4, rtol=1e-5)
         assert np.isclose(float(rw.rms[1]), ref.ret_rms.var, rtol=1e-6)
+
+
+@pytest.mark.parametrize("n", [64, 1000, 65536, 200000])
+def test_step_fused_bookkeeping_matches_unfused(oracle, n):
+    """fpv_step_fused + fpv_moments_merge + fpv_reward_finalize == fpv_step + fpv_normalize(+_reward)."""
+    from fpv_drone_rl_agent_amd import ops
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.synthetic import synthetic_states
+    st = synthetic_states(n, seed=1).astype(np.float32)
+    st[: n // 8, 34] = 401
+    a_eng, b_eng = FpvEngine(n, 0, seed=4), FpvEngine(n, 0, seed=4)
+    for e in (a_eng, b_eng):
+        e.set_state(torch.from_numpy(st))
+    obs_n_a, rn_a = ops.RunningNorm(20, "cuda"), ops.RewardNorm(n, "cuda")
+    obs_rms_b = obs_n_a.rms.clone()
+    ret_rms_b, ret_b = rn_a.rms.clone(), torch.zeros(n, device="cuda")
+    partials = torch.zeros((a_eng.tiles, 44), dtype=torch.float64, device="cuda")
+    T = 3
+    snap = torch.zeros((T, 44), dtype=torch.float64, device="cuda")
+    raw = torch.zeros((T, n), device="cuda")
+    done_b = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    rew_a = []
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for t in range(T):
+        act = torch.rand(n, 4, device="cuda", generator=g) * 2 - 1
+        o, r, te, tr = a_eng.step(act)
+        done_a = te | tr
+        obs_n_a.update_only(o)
+        rew_a.append(rn_a(r, done_a).clone())
+        b_eng.step_fused(act, done=done_b, ret=ret_b, partials=partials, gamma=0.99, reward=raw[t])
+        ops.moments_merge(partials, n, obs_rms=obs_rms_b, ret_rms=ret_rms_b, snapshot=snap[t])
+        assert torch.equal(b_eng.obs, o) and torch.equal(raw[t], r) and torch.equal(done_b, done_a)
+        assert torch.allclose(ret_b, rn_a.ret, atol=1e-5, rtol=1e-6)
+        assert torch.allclose(obs_rms_b, obs_n_a.rms, rtol=1e-9, atol=1e-9)
+        assert torch.allclose(ret_rms_b, rn_a.rms, rtol=1e-6, atol=1e-9)
+        assert torch.equal(snap[t, :41], obs_rms_b) and torch.equal(snap[t, 41:], ret_rms_b)
+    out = ops.reward_finalize(raw, snap)
+    assert torch.allclose(out, torch.stack(rew_a), atol=1e-5, rtol=1e-5)
+    a_eng.close(); b_eng.close()
