@@ -82,7 +82,11 @@ def main() -> None:
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    rank, world, local = D.init_from_env("nccl")
+    # FPV_DIST_BACKEND=gloo rehearses several ranks on a one-GPU box; the driver's runs use RCCL
+    backend = os.environ.get("FPV_DIST_BACKEND", "nccl")
+    rank, world, local = D.init_from_env(backend)
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local)
@@ -113,7 +117,7 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
         elapsed = float(tmax.item())
     episodes = int(col.episodes["count"])

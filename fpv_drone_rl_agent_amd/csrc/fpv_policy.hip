@@ -145,9 +145,22 @@ __global__ __launch_bounds__(kPolicyThreads) void policy_forward_kernel(PolicyAr
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // ---- stage the weight image (L2-resident after the first workgroups) and the normaliser
     {
+        // all of a thread's 20 image granules are requested before the first one is written to LDS, so the
+        // block pays one L2 round trip for the 160 KB image, not twenty
         const f32x4* src = reinterpret_cast<const f32x4*>(p.image);
         f32x4* dst = reinterpret_cast<f32x4*>(lds);
-        for (int q = threadIdx.x; q < kImageFloats / 4; q += kPolicyThreads) dst[q] = src[q];
+        constexpr int kGranules = kImageFloats / 4, kPer = (kGranules + kPolicyThreads - 1) / kPolicyThreads;
+        f32x4 stage[kPer];
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const int g = q * kPolicyThreads + threadIdx.x;
+            stage[q] = src[g < kGranules ? g : 0];
+        }
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const int g = q * kPolicyThreads + threadIdx.x;
+            if (g < kGranules) dst[g] = stage[q];
+        }
         if (threadIdx.x < kIn) {
             const float mu = p.rms ? (float)p.rms[threadIdx.x] : 0.0f;
             const float iv = p.rms ? (float)(1.0 / sqrt(p.rms[kIn + threadIdx.x] + (double)p.eps_norm)) : 1.0f;

@@ -238,20 +238,31 @@ __global__ __launch_bounds__(256) void tile_partials_reduce_kernel(const double*
 
 // Stage 2: one workgroup merges the rows into the running statistics of SB3's RunningMeanStd (obs: 20
 // channels, ret: 1 channel) and snapshots {obs mean[20], obs var[20], obs count, ret mean, ret var, ret count}.
-__global__ __launch_bounds__(64 * kMergeWays) void tile_partials_merge_kernel(const double* __restrict__ rows, int nrows,
-                                                                              double batch_count, double* obs_rms,
-                                                                              double* ret_rms, double* snapshot) {
-    __shared__ double l[kMergeWays][64];
-    const int c = threadIdx.x % 64, j = threadIdx.x / 64;
-    double acc = 0.0;
-    if (c < kPartialWords)
-        for (int b = j; b < nrows; b += kMergeWays) acc += rows[(int64_t)b * kPartialWords + c];
-    l[j][c] = acc;
+// 23 ways x 44 channels = 1012 of the 1024 threads; consecutive threads read consecutive doubles, and each
+// thread keeps four independent accumulators so that its loads overlap.
+constexpr int kTileMergeWays = 23;
+__global__ __launch_bounds__(1024) void tile_partials_merge_kernel(const double* __restrict__ rows, int nrows,
+                                                                   double batch_count, double* obs_rms,
+                                                                   double* ret_rms, double* snapshot) {
+    __shared__ double l[kTileMergeWays][64];
+    const int j = threadIdx.x / kPartialWords, c = threadIdx.x % kPartialWords;
+    if (j < kTileMergeWays) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        int b = j;
+        for (; b + 3 * kTileMergeWays < nrows; b += 4 * kTileMergeWays) {
+            a0 += rows[(int64_t)b * kPartialWords + c];
+            a1 += rows[(int64_t)(b + kTileMergeWays) * kPartialWords + c];
+            a2 += rows[(int64_t)(b + 2 * kTileMergeWays) * kPartialWords + c];
+            a3 += rows[(int64_t)(b + 3 * kTileMergeWays) * kPartialWords + c];
+        }
+        for (; b < nrows; b += kTileMergeWays) a0 += rows[(int64_t)b * kPartialWords + c];
+        l[j][c] = (a0 + a1) + (a2 + a3);
+    }
     const double obs_count = obs_rms ? obs_rms[40] : 0.0, ret_count = ret_rms ? ret_rms[2] : 0.0;
     __syncthreads();
     if (j == 0) {
-        acc = 0.0;
-        for (int w = 0; w < kMergeWays; ++w) acc += l[w][c];
+        double acc = 0.0;
+        for (int w = 0; w < kTileMergeWays; ++w) acc += l[w][c];
         l[0][c] = acc;
     }
     __syncthreads();
@@ -290,7 +301,7 @@ hipError_t launch_moments_merge_tiles(int64_t tiles, const double* partials, dou
         rows = scratch;
         nrows = (int)((tiles + per_group - 1) / per_group);
     }
-    hipLaunchKernelGGL(tile_partials_merge_kernel, dim3(1), dim3(64 * kMergeWays), 0, s, rows, nrows, batch_count, obs_rms,
+    hipLaunchKernelGGL(tile_partials_merge_kernel, dim3(1), dim3(1024), 0, s, rows, nrows, batch_count, obs_rms,
                        ret_rms, snapshot);
     return hipGetLastError();
 }

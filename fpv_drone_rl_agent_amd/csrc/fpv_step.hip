@@ -172,21 +172,46 @@ __global__ __launch_bounds__(kTile) void step_kernel(StepArgs<T> p) {
         lds_w[kTile * kObsWords + lane] = ret;
         store_obs_tile(o, p.obs, tile, lane, p.n, lds);   // writes the tile and barriers before reading it back
         if (p.partials) {
+            // 60 lanes = 3 row groups x 20 channels walk the staged tile; lanes 60..63 take ret.  Fixed trip
+            // counts + selects so that the LDS reads are issued back to back instead of one per round trip.
             const int rows = (int)((p.n - tile * kTile) < kTile ? (p.n - tile * kTile) : kTile);
-            double acc = 0.0;
-            if (lane < 2 * kObsWords) {
-                const int c = lane < kObsWords ? lane : lane - kObsWords;
-                for (int r = 0; r < rows; ++r) {
-                    const double v = (double)lds_w[r * kObsWords + c];
-                    acc += lane < kObsWords ? v : v * v;
+            double s1 = 0.0, s2 = 0.0;
+            if (lane < 3 * kObsWords) {
+                const int g = lane / kObsWords, c = lane - g * kObsWords;
+                float v[22];
+#pragma unroll
+                for (int q = 0; q < 22; ++q) {
+                    const int r = 3 * q + g;
+                    v[q] = r < rows ? (float)lds_w[(r < kTile ? r : 0) * kObsWords + c] : 0.0f;
                 }
-            } else if (lane < 2 * kObsWords + 2) {
-                for (int r = 0; r < rows; ++r) {
-                    const double v = (double)lds_w[kTile * kObsWords + r];
-                    acc += lane == 2 * kObsWords ? v : v * v;
+#pragma unroll
+                for (int q = 0; q < 22; ++q) { const double d = (double)v[q]; s1 += d; s2 += d * d; }
+            } else {
+                const int g = lane - 3 * kObsWords;
+                float v[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int r = 4 * q + g;
+                    v[q] = r < rows ? (float)lds_w[kTile * kObsWords + r] : 0.0f;
                 }
+#pragma unroll
+                for (int q = 0; q < 16; ++q) { const double d = (double)v[q]; s1 += d; s2 += d * d; }
             }
-            if (lane < kPartialWords) p.partials[tile * kPartialWords + lane] = acc;
+            // fold the row groups in a fixed order: lanes c, c+20, c+40 -> lane c ; lanes 60..63 -> lane 60
+            const double a1 = __shfl(s1, lane + kObsWords), a2 = __shfl(s1, lane + 2 * kObsWords);
+            const double b1 = __shfl(s2, lane + kObsWords), b2 = __shfl(s2, lane + 2 * kObsWords);
+            const double r1 = __shfl(s1, 61), r2 = __shfl(s1, 62), r3 = __shfl(s1, 63);
+            const double q1 = __shfl(s2, 61), q2 = __shfl(s2, 62), q3 = __shfl(s2, 63);
+            double* row = p.partials + tile * kPartialWords;
+            if (lane < kObsWords) {
+                row[lane] = (s1 + a1) + a2;
+                row[kObsWords + lane] = (s2 + b1) + b2;
+            } else if (lane == 60) {
+                row[2 * kObsWords] = (s1 + r1) + (r2 + r3);
+                row[2 * kObsWords + 1] = (s2 + q1) + (q2 + q3);
+                row[2 * kObsWords + 2] = 0.0;
+                row[2 * kObsWords + 3] = 0.0;
+            }
         }
     } else {
         store_obs_tile(o, p.obs, tile, lane, p.n, lds);

@@ -47,6 +47,12 @@ def allgather_payload(payload: torch.Tensor) -> torch.Tensor:
     w = world_size()
     if w == 1:
         return payload.unsqueeze(0)
+    if td.get_backend() == "gloo" and payload.is_cuda:
+        # rehearsal mode (several ranks on one GPU box over gloo): stage the few words through the host
+        host = payload.cpu()
+        out = torch.empty((w * host.numel(),), dtype=torch.float64)
+        td.all_gather_into_tensor(out, host.contiguous())
+        return out.view(w, host.numel()).to(payload.device)
     out = torch.empty((w * payload.numel(),), dtype=torch.float64, device=payload.device)
     td.all_gather_into_tensor(out, payload.contiguous())   # flat output: accepted by RCCL and gloo alike
     return out.view(w, payload.numel())
