@@ -1,0 +1,124 @@
+"""PPO update on top of the on-device rollout (SB3 PPO.train semantics).
+
+north_star replaces the reference's SAC learner (simulation/train_hover.py:47-58) by PPO.  SB3's
+defaults are kept where they make sense at this batch scale (clip_range 0.2, vf_coef 0.5,
+max_grad_norm 0.5, gamma 0.99, lambda 0.95, Adam); the rollout is n_steps x 65 536 transitions, so
+minibatches are large and few (SB3's 2048 x 64 defaults would be a pointless batch here).
+torch autograd does the backward (the nets are 39 049 parameters: the update is a negligible share
+of a training iteration); gradients are averaged across ranks with ONE all-reduce per minibatch
+(156 KB - latency-bound on xGMI, so no bucketing and no ring of our own).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as td
+
+from . import dist as D
+from .rollout import RolloutCollector
+
+
+class PPO:
+    def __init__(self, collector: RolloutCollector, learning_rate: float = 3e-4, n_epochs: int = 4,
+                 n_minibatches: int = 8, clip_range: float = 0.2, ent_coef: float = 0.0, vf_coef: float = 0.5,
+                 max_grad_norm: float = 0.5, normalize_advantage: bool = True, target_kl: float | None = None):
+        self.col = collector
+        self.policy = collector.policy
+        self.opt = torch.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5)
+        self.n_epochs, self.n_minibatches = n_epochs, n_minibatches
+        self.clip_range, self.ent_coef, self.vf_coef = clip_range, ent_coef, vf_coef
+        self.max_grad_norm, self.normalize_advantage, self.target_kl = max_grad_norm, normalize_advantage, target_kl
+        self.num_timesteps = 0
+        self.logger: dict[str, float] = {}
+        self._gen = torch.Generator(device=collector.device)
+        self._gen.manual_seed(1234 + D.rank())
+
+    def _allreduce_grads(self) -> None:
+        w = D.world_size()
+        if w == 1:
+            return
+        grads = [p.grad for p in self.policy.parameters() if p.grad is not None]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        if td.get_backend() == "gloo" and flat.is_cuda:
+            host = flat.cpu()
+            td.all_reduce(host)
+            flat = host.to(flat.device)
+        else:
+            td.all_reduce(flat)
+        flat /= w
+        o = 0
+        for g in grads:
+            g.copy_(flat[o:o + g.numel()].view_as(g))
+            o += g.numel()
+
+    def train_on(self, batch: dict) -> None:
+        T, N = self.col.T, self.col.N
+        obs = batch["obs"].reshape(T * N, -1)
+        act = batch["actions"].reshape(T * N, -1)
+        old_v = batch["values"].reshape(-1)
+        old_lp = batch["log_probs"].reshape(-1)
+        ret = batch["returns"].reshape(-1)
+        adv = batch["advantages"].reshape(-1)
+        if self.normalize_advantage:
+            # global statistics from the rollout's single all-gather (identical on every rank)
+            adv = (adv - batch["adv_mean"].float()) / (batch["adv_std"].float() + 1e-8)
+        total = T * N
+        mb = total // self.n_minibatches
+        stats = []
+        stop = False
+        for epoch in range(self.n_epochs):
+            perm = torch.randperm(total, device=obs.device, generator=self._gen)
+            for k in range(self.n_minibatches):
+                idx = perm[k * mb:(k + 1) * mb]
+                v, lp, ent = self.policy.evaluate(obs[idx], act[idx])
+                ratio = torch.exp(lp - old_lp[idx])
+                a = adv[idx]
+                pg = -torch.min(a * ratio, a * torch.clamp(ratio, 1 - self.clip_range, 1 + self.clip_range)).mean()
+                vl = torch.nn.functional.mse_loss(v, ret[idx])
+                loss = pg + self.vf_coef * vl - self.ent_coef * ent.mean()
+                self.opt.zero_grad(set_to_none=True)
+                loss.backward()
+                self._allreduce_grads()
+                torch.nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
+                self.opt.step()
+                with torch.no_grad():
+                    log_ratio = lp - old_lp[idx]
+                    kl = ((torch.exp(log_ratio) - 1) - log_ratio).mean()
+                    stats.append(torch.stack([pg.detach(), vl.detach(), kl, ((ratio - 1).abs() > self.clip_range).float().mean()]))
+            if self.target_kl is not None and float(stats[-1][2]) > 1.5 * self.target_kl:
+                stop = True
+            if stop:
+                break
+        s = torch.stack(stats).mean(0).tolist()
+        self.logger.update({"train/policy_gradient_loss": s[0], "train/value_loss": s[1], "train/approx_kl": s[2],
+                            "train/clip_fraction": s[3], "train/loss": s[0] + self.vf_coef * s[1],
+                            "train/std": float(torch.exp(self.policy.log_std.detach()).mean())})
+        self.col.sync_policy()
+
+    def learn(self, total_timesteps: int, callback=None, log_every: int = 0) -> "PPO":
+        """model.learn(total_timesteps, callback) of simulation/train_hover.py:60; timesteps count every drone on
+        every rank, as SB3 counts every env."""
+        per_iter = self.col.T * self.col.N * D.world_size()
+        it = 0
+        while self.num_timesteps < total_timesteps:
+            batch = self.col.collect()
+            self.num_timesteps += per_iter
+            ep = self.col.episodes
+            if ep["count"] > 0 and ep["ep_len"] is not None and ep["ep_len"].numel() > 0:
+                self.logger["rollout/ep_len_mean"] = float(ep["ep_len"].float().mean())
+                self.logger["rollout/ep_rew_mean"] = float(ep["ep_return"].float().mean())
+            self.train_on(batch)
+            it += 1
+            if callback is not None:
+                callback(self)
+            if log_every and it % log_every == 0 and D.rank() == 0:
+                print({"iter": it, "timesteps": self.num_timesteps, **{k: round(v, 4) for k, v in self.logger.items()}},
+                      flush=True)
+        return self
+
+    def predict(self, obs: torch.Tensor, deterministic: bool = True):
+        """model.predict(obs, deterministic=True) of simulation/test_hover.py:17 (obs already normalised)."""
+        with torch.no_grad():
+            mean, _ = self.policy.mean_value(obs)
+            if not deterministic:
+                mean = mean + torch.exp(self.policy.log_std) * torch.randn_like(mean)
+        return torch.clamp(mean, -1, 1), None
