@@ -131,3 +131,11 @@ def test_vec_auto_reset_semantics_on_oracle(oracle):
     assert np.allclose(obs[:10], obs_reset[0]) and (st[:10, 34] == 0).all() and np.allclose(st[:10, 30:34], 0.3)
     idx, info, ret, tobs = led.rows()
     assert list(idx) == list(range(10)) and ((info >> 8) == 402).all() and (tobs[:, 16:20] == 0.3).all()
+
+
+def test_checkpoint_naming_matches_reference():
+    from fpv_drone_rl_agent_amd.checkpoint import checkpoint_name
+    # train_hover.py:20-24 — round(x, 2), the literal "None" when a key is missing
+    assert checkpoint_name("ppo_hover", 240000, {}) == "ppo_hover_240000_steps_None_lenNone_rewNone.zip"  # test_hover.py:8
+    lg = {"train/loss": 0.12345, "rollout/ep_len_mean": 401.66159, "rollout/ep_rew_mean": -17.635}
+    assert checkpoint_name("ppo_hover", 20480, lg) == "ppo_hover_20480_steps_0.12_len401.66_rew-17.64.zip"

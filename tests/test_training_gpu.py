@@ -25,3 +25,44 @@ def test_ppo_learns_to_hover():
     assert early < 80, early                      # untrained: dies at the floor check (call 32) or earlier
     assert late > 300 and rew > 0, (late, rew)    # trained: survives to (near) the 402-step truncation
     eng.close()
+
+
+def test_checkpoint_cadence_roundtrip_and_playback(tmp_path):
+    """train_hover.py:8-34,62-63 cadence and naming; test_hover.py:8-22 style playback of the saved pair."""
+    import os
+    from fpv_drone_rl_agent_amd.checkpoint import CheckpointCallback, load_normalizer, load_policy_state, save_model
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    from fpv_drone_rl_agent_amd.ppo import PPO
+    from fpv_drone_rl_agent_amd.rollout import RolloutCollector
+    from fpv_drone_rl_agent_amd.vec_env import FpvVecEnv, VecNormalize
+    torch.manual_seed(1)
+    n = 1024
+    eng = FpvEngine(n, 0)
+    pol = ActorCritic(log_std_init=-2.0).cuda()
+    model = PPO(RolloutCollector(eng, pol, n_steps=8), n_epochs=1, n_minibatches=2)
+    cb = CheckpointCallback(save_path=str(tmp_path / "ppo_hover_checkpoint3"), name_prefix="ppo_hover", verbose=0,
+                            min_steps_between_checkpoints=20000)
+    model.learn(8 * n * 7, callback=cb)            # 7 iterations of 8192 steps: checkpoints after >= 20000 steps
+    assert len(cb.saved) == 2 and "_24576_steps_" in cb.saved[0] and "_49152_steps_" in cb.saved[1]
+    assert all(os.path.exists(p) and os.path.exists(p.replace(".zip", ".pkl")) for p in cb.saved)
+    save_model(str(tmp_path / "hover"), model)     # train_hover.py:62
+    state, data = load_policy_state(str(tmp_path / "hover"))
+    assert data["num_timesteps"] == model.num_timesteps and data["algo"] == "PPO"
+    pol2 = ActorCritic().cuda()
+    pol2.load_state_dict(state)
+    x = torch.randn(5, 20, device="cuda")
+    assert torch.equal(pol2.mean_value(x)[0], pol.mean_value(x)[0])
+    # the .pkl-named statistics load into the VecEnv-side normaliser (test_hover.py:8-10) and into a collector
+    env = FpvVecEnv(4, noise_ratio=0.0)
+    vn = VecNormalize.load(cb.saved[-1].replace(".zip", ".pkl"), venv=env)
+    vn.training, vn.norm_reward = False, False
+    col2 = RolloutCollector(FpvEngine(64, 0), pol2, n_steps=4)
+    load_normalizer(cb.saved[-1].replace(".zip", ".pkl"), col2)
+    assert torch.allclose(vn.obs_rms.rms, col2.obs_norm.rms)
+    obs = vn.reset()
+    for _ in range(5):                             # test_hover.py:15-26 loop shape
+        action, _ = model.predict(torch.from_numpy(obs).cuda(), deterministic=True)
+        obs, reward, done, info = vn.step(action.cpu().numpy())
+    assert obs.shape == (4, 20) and reward.shape == (4,)
+    env.close(); eng.close()
