@@ -69,6 +69,8 @@ def main() -> None:
     ap.add_argument("--drones", type=int, default=65536, help="drones per GPU (BASELINE.json configs[2])")
     ap.add_argument("--n-steps", type=int, default=32, help="rollout length between GAE passes")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--task", choices=["hover", "yaw"], default="hover",
+                    help="yaw = BASELINE configs[4] (yaw-setpoint task with domain randomisation); not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-launches", type=int, default=200)
     args = ap.parse_args()
@@ -97,11 +99,13 @@ def main() -> None:
     T = max(d for d in range(1, min(args.n_steps, K) + 1) if K % d == 0)
 
     torch.manual_seed(0)
-    policy = ActorCritic().to(dev)
-    eng = FpvEngine(n, dev, noise_ratio=0.02, seed=0, id_offset=rank * n)
+    yaw = args.task == "yaw"
+    policy = (ActorCritic(obs_dim=12, act_dim=1) if yaw else ActorCritic()).to(dev)
+    eng = FpvEngine(n, dev, noise_ratio=0.02, seed=0, id_offset=rank * n, task=args.task, domain_rand=yaw)
     col = RolloutCollector(eng, policy, n_steps=T, use_graph=not args.no_graph)
     col.start()
-    eng.set_state(torch.from_numpy(synthetic_states(n, seed=rank)))  # staggered step counts => staggered dones
+    if not yaw:
+        eng.set_state(torch.from_numpy(synthetic_states(n, seed=rank)))  # staggered step counts => staggered dones
 
     def barrier():
         if world > 1:
@@ -126,7 +130,7 @@ def main() -> None:
     roofline = None
     if rank == 0:
         L = args.kernel_launches
-        act = torch.rand((n, 4), device=dev) * 2 - 1
+        act = torch.rand((n, eng.act_words), device=dev) * 2 - 1
         for _ in range(20):
             eng.step(act)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -137,20 +141,21 @@ def main() -> None:
         e1.record()
         torch.cuda.synchronize(dev)
         us = e0.elapsed_time(e1) * 1e3 / L
-        achieved = ALG_BYTES_PER_STEP * n / us / 1e3  # GB/s
+        alg_bytes = 458 if yaw else ALG_BYTES_PER_STEP   # yaw: 44 words r+w, 4 B action, 48 B obs, 4 B reward, 2 B flags
+        achieved = alg_bytes * n / us / 1e3  # GB/s
         # HBM bytes per launch from the PMC passes recorded under profiles/ (cannot be collected from inside
         # the process); only reported when it was measured for this drone count
         traffic = None
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", "step_kernel_traffic.json")))
-            if int(rec["drones"]) == n:
+            if int(rec["drones"]) == n and not yaw:
                 traffic = int(rec["hbm_bytes_per_launch"])
         except (OSError, ValueError, KeyError):
             pass
-        roofline = {"bound": "hbm", "kernel": "fpv::step_kernel<float,true>", "achieved": round(achieved, 1),
+        roofline = {"bound": "hbm", "kernel": "fpv::yaw_step_kernel<float,true>" if yaw else "fpv::step_kernel<float,true>", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                     "traffic": traffic, "us_per_launch": round(us, 2), "launches": L,
-                    "algorithmic_bytes_per_launch": ALG_BYTES_PER_STEP * n}
+                    "algorithmic_bytes_per_launch": alg_bytes * n}
 
     if rank == 0:
         out = {
@@ -158,15 +163,17 @@ def main() -> None:
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (random-init policy, seeded random-init drone states, motor noise on)",
-            "config": {"workload": "BASELINE.json configs[2]: 65 536 hover drones per GPU, on-device PPO rollout "
-                                   "(policy MLP forward + sample, fused HIP env-step, VecNormalize, buffer) + GAE + "
-                                   "advantage-stat all-gather every n_steps",
+            "config": {"workload": ("BASELINE.json configs[4]: yaw-setpoint task with domain-randomised mass/drag, on-device "
+                                    "PPO rollout (torch policy 12->1, HIP env-step, VecNormalize) + GAE + all-gather" if yaw else
+                                    "BASELINE.json configs[2]: 65 536 hover drones per GPU, on-device PPO rollout "
+                                    "(fused fp32-MFMA policy forward + sample, fused HIP env-step + VecNormalize "
+                                    "bookkeeping, buffer) + GAE + advantage-stat all-gather every n_steps"),
                        "drones_per_gpu": n, "total_drones": n * world, "n_steps": T,
-                       "hip_graph": not args.no_graph, "policy": "MlpPolicy pi/vf [128,128] tanh (39 049 params)",
+                       "hip_graph": not args.no_graph, "policy": "MlpPolicy pi/vf [128,128] tanh" + ("" if yaw else " (39 049 params)"),
                        "episodes_in_last_rollout": episodes},
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not yaw:
             out["cpu_baseline"] = cpu_baseline(n, seed=0)
         print(json.dumps(out), flush=True)
     barrier()

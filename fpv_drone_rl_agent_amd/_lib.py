@@ -11,6 +11,7 @@ import os
 from .build import LIB_PATH, build_extension
 
 FPV_F32, FPV_F64 = 0, 1
+TASK_HOVER, TASK_YAW = 0, 1
 STATE_WORDS, OBS_WORDS, ACT_WORDS = 36, 20, 4
 INFO_TERMINATED, INFO_TRUNCATED, INFO_OUT_OF_BOUNDS, INFO_ON_FLOOR = 1, 2, 4, 8
 
@@ -18,8 +19,9 @@ INFO_TERMINATED, INFO_TRUNCATED, INFO_OUT_OF_BOUNDS, INFO_ON_FLOOR = 1, 2, 4, 8
 class FpvConfig(C.Structure):
     _fields_ = [
         ("num_envs", C.c_int64), ("device", C.c_int32), ("precision", C.c_int32),
-        ("floor_check", C.c_int32), ("reserved0", C.c_int32), ("noise_ratio", C.c_double),
+        ("floor_check", C.c_int32), ("task", C.c_int32), ("noise_ratio", C.c_double),
         ("seed", C.c_uint64), ("id_offset", C.c_uint64), ("ledger_capacity", C.c_int64),
+        ("domain_rand", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -57,6 +59,7 @@ SIGNATURES = {
     "fpv_step_fused": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(FpvStepExtras), _vp]),
     "fpv_moments_merge": (C.c_int, [_i64, _vp, C.c_double, _vp, _vp, _vp, _vp]),
     "fpv_reward_finalize": (C.c_int, [_i64, _i64, _vp, _vp, _f32, _f32, _vp, _vp]),
+    "fpv_dims": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "fpv_tick_ptr": (C.c_int, [_vp, C.POINTER(_vp)]),
     "fpv_step_f64": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fpv_get_state": (C.c_int, [_vp, _vp, _vp]),

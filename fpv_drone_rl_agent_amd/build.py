@@ -12,7 +12,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libfpv_env.so")
-SOURCES = ["fpv_step.hip", "fpv_rollout.hip", "fpv_policy.hip", "fpv_capi.hip"]
+SOURCES = ["fpv_step.hip", "fpv_yaw.hip", "fpv_rollout.hip", "fpv_policy.hip", "fpv_capi.hip"]
 HEADERS = ["fpv_dynamics.h", "fpv_internal.h", os.path.join("..", "..", "include", "fpv_env.h")]
 
 

@@ -33,6 +33,7 @@ static int fail(int code, const char* fmt, ...) {
 struct fpv_env {
     fpv_config cfg;
     int64_t tiles;
+    int granules, state_words, obs_words, act_words;  // by task
     size_t word;         // sizeof(real)
     void* state;         // [tiles][9][64] granules
     void* tmpl;          // 56 reals
@@ -74,8 +75,9 @@ static int step_impl(fpv_env* e, const T* actions, T* obs, T* reward, uint8_t* t
     if (!actions || !obs || !reward || !term || !trunc) return fail(FPV_ERR_ARG, "fpv_step: null buffer");
     if ((e->cfg.precision == FPV_F64) != (sizeof(T) == 8))
         return fail(FPV_ERR_ARG, "fpv_step: handle precision does not match this entry point");
-    if (((uintptr_t)actions | (uintptr_t)obs) & (sizeof(T) * 4 - 1))
+    if (((uintptr_t)obs | (e->act_words == 4 ? (uintptr_t)actions : 0)) & (sizeof(T) * 4 - 1))
         return fail(FPV_ERR_ARG, "fpv_step: actions/obs must be %zu-byte aligned", sizeof(T) * 4);
+    if (ex && e->cfg.task != FPV_TASK_HOVER) return fail(FPV_ERR_UNSUPPORTED, "fpv_step_fused: hover task only");
     StepArgs<T> a;
     a.state = (Vec4<T>*)e->state;
     a.actions = actions; a.obs = obs; a.reward = reward; a.terminated = term; a.truncated = trunc;
@@ -88,11 +90,13 @@ static int step_impl(fpv_env* e, const T* actions, T* obs, T* reward, uint8_t* t
     a.id_offset = e->cfg.id_offset;
     a.sigma = (T)e->cfg.noise_ratio;
     a.floor_check = e->cfg.floor_check;
+    a.domain_rand = e->cfg.domain_rand;
     a.done = ex ? ex->done : nullptr;
     a.ret = ex ? ex->ret : nullptr;
     a.partials = ex ? ex->partials : nullptr;
     a.gamma = ex ? ex->gamma : 0.0f;
-    FPV_HIP(launch_step<T>(a, e->cfg.noise_ratio != 0.0, (hipStream_t)stream));
+    if (e->cfg.task == FPV_TASK_YAW) FPV_HIP(launch_yaw_step<T>(a, e->cfg.noise_ratio != 0.0, (hipStream_t)stream));
+    else FPV_HIP(launch_step<T>(a, e->cfg.noise_ratio != 0.0, (hipStream_t)stream));
     return FPV_OK;
 }
 
@@ -108,6 +112,7 @@ int fpv_create(const fpv_config* cfg, fpv_env** out) {
     if (cfg->precision != FPV_F32 && cfg->precision != FPV_F64)
         return fail(FPV_ERR_ARG, "fpv_create: unknown precision %d", cfg->precision);
     if (cfg->noise_ratio < 0.0) return fail(FPV_ERR_ARG, "fpv_create: negative noise_ratio");
+    if (cfg->task != FPV_TASK_HOVER && cfg->task != FPV_TASK_YAW) return fail(FPV_ERR_ARG, "fpv_create: unknown task %d", cfg->task);
     int ndev = 0;
     FPV_HIP(hipGetDeviceCount(&ndev));
     if (cfg->device < 0 || cfg->device >= ndev)
@@ -118,6 +123,11 @@ int fpv_create(const fpv_config* cfg, fpv_env** out) {
     e->cfg = *cfg;
     e->tiles = (cfg->num_envs + kTile - 1) / kTile;
     e->word = cfg->precision == FPV_F64 ? sizeof(double) : sizeof(float);
+    const bool yaw = cfg->task == FPV_TASK_YAW;
+    e->granules = yaw ? kYawGranules : kGranules;
+    e->state_words = yaw ? kYawStateWords : kStateWords;
+    e->obs_words = yaw ? kYawObsWords : kObsWords;
+    e->act_words = yaw ? 1 : 4;
     {
         const int64_t want = cfg->ledger_capacity > 0 ? cfg->ledger_capacity : 2 * cfg->num_envs;
         e->led_rows = (want + e->tiles - 1) / e->tiles;
@@ -128,7 +138,7 @@ int fpv_create(const fpv_config* cfg, fpv_env** out) {
     auto alloc = [&](void** p, size_t bytes) {
         if (err == hipSuccess) err = hipMalloc(p, bytes);
     };
-    alloc(&e->state, (size_t)e->tiles * kGranules * kTile * 4 * e->word);
+    alloc(&e->state, (size_t)e->tiles * e->granules * kTile * 4 * e->word);
     alloc(&e->tmpl, (size_t)(kStateWords + kObsWords) * e->word);
     alloc((void**)&e->tick, (size_t)e->tiles * sizeof(uint64_t));
     alloc((void**)&e->led_count, (size_t)e->tiles * sizeof(uint32_t));
@@ -139,9 +149,17 @@ int fpv_create(const fpv_config* cfg, fpv_env** out) {
     alloc(&e->led_obs, (size_t)e->led_cap * kObsWords * e->word);
     if (err == hipSuccess) err = hipMemset(e->tick, 0, (size_t)e->tiles * sizeof(uint64_t));
     if (err == hipSuccess) err = hipMemset(e->led_count, 0, (size_t)e->tiles * sizeof(uint32_t));
-    if (err == hipSuccess)
-        err = cfg->precision == FPV_F64 ? launch_init<double>(e->state, e->tmpl, cfg->num_envs, nullptr)
-                                        : launch_init<float>(e->state, e->tmpl, cfg->num_envs, nullptr);
+    if (err == hipSuccess) {
+        if (yaw)
+            err = cfg->precision == FPV_F64
+                      ? launch_yaw_reset<double>(e->state, e->tick, nullptr, nullptr, cfg->num_envs, cfg->seed, cfg->id_offset,
+                                                 cfg->domain_rand, 1, nullptr)
+                      : launch_yaw_reset<float>(e->state, e->tick, nullptr, nullptr, cfg->num_envs, cfg->seed, cfg->id_offset,
+                                                cfg->domain_rand, 1, nullptr);
+        else
+            err = cfg->precision == FPV_F64 ? launch_init<double>(e->state, e->tmpl, cfg->num_envs, nullptr)
+                                            : launch_init<float>(e->state, e->tmpl, cfg->num_envs, nullptr);
+    }
     if (err == hipSuccess) err = hipDeviceSynchronize();
     if (err != hipSuccess) {
         fpv_destroy(e);
@@ -168,6 +186,14 @@ int fpv_destroy(fpv_env* e) {
 int fpv_reset(fpv_env* e, const uint8_t* mask, void* obs, void* stream) {
     if (!e) return fail(FPV_ERR_ARG, "fpv_reset: null handle");
     hipStream_t s = (hipStream_t)stream;
+    if (e->cfg.task == FPV_TASK_YAW) {
+        FPV_HIP(e->cfg.precision == FPV_F64
+                    ? launch_yaw_reset<double>(e->state, e->tick, mask, obs, e->cfg.num_envs, e->cfg.seed, e->cfg.id_offset,
+                                               e->cfg.domain_rand, 0, s)
+                    : launch_yaw_reset<float>(e->state, e->tick, mask, obs, e->cfg.num_envs, e->cfg.seed, e->cfg.id_offset,
+                                              e->cfg.domain_rand, 0, s));
+        return FPV_OK;
+    }
     FPV_HIP(e->cfg.precision == FPV_F64 ? launch_reset<double>(e->state, e->tmpl, mask, obs, e->cfg.num_envs, s)
                                         : launch_reset<float>(e->state, e->tmpl, mask, obs, e->cfg.num_envs, s));
     return FPV_OK;
@@ -201,6 +227,14 @@ int fpv_reward_finalize(int64_t T, int64_t n, const float* raw, const double* sn
     return FPV_OK;
 }
 
+int fpv_dims(fpv_env* e, int32_t* state_words, int32_t* obs_words, int32_t* act_words) {
+    if (!e) return fail(FPV_ERR_ARG, "fpv_dims: null handle");
+    if (state_words) *state_words = e->state_words;
+    if (obs_words) *obs_words = e->obs_words;
+    if (act_words) *act_words = e->act_words;
+    return FPV_OK;
+}
+
 int fpv_tick_ptr(fpv_env* e, const uint64_t** out) {
     if (!e || !out) return fail(FPV_ERR_ARG, "fpv_tick_ptr: null argument");
     *out = e->tick;
@@ -214,6 +248,11 @@ int fpv_step_f64(fpv_env* e, const double* actions, double* obs, double* reward,
 
 int fpv_get_state(fpv_env* e, void* state_out, void* stream) {
     if (!e || !state_out) return fail(FPV_ERR_ARG, "fpv_get_state: null argument");
+    if (e->cfg.task == FPV_TASK_YAW) {
+        FPV_HIP(e->cfg.precision == FPV_F64 ? launch_yaw_convert<double>(e->state, state_out, e->cfg.num_envs, true, (hipStream_t)stream)
+                                            : launch_yaw_convert<float>(e->state, state_out, e->cfg.num_envs, true, (hipStream_t)stream));
+        return FPV_OK;
+    }
     FPV_HIP(e->cfg.precision == FPV_F64
                 ? launch_convert<double>(e->state, state_out, e->cfg.num_envs, true, (hipStream_t)stream)
                 : launch_convert<float>(e->state, state_out, e->cfg.num_envs, true, (hipStream_t)stream));
@@ -222,6 +261,12 @@ int fpv_get_state(fpv_env* e, void* state_out, void* stream) {
 
 int fpv_set_state(fpv_env* e, const void* state_in, void* stream) {
     if (!e || !state_in) return fail(FPV_ERR_ARG, "fpv_set_state: null argument");
+    if (e->cfg.task == FPV_TASK_YAW) {
+        FPV_HIP(e->cfg.precision == FPV_F64
+                    ? launch_yaw_convert<double>(e->state, (void*)state_in, e->cfg.num_envs, false, (hipStream_t)stream)
+                    : launch_yaw_convert<float>(e->state, (void*)state_in, e->cfg.num_envs, false, (hipStream_t)stream));
+        return FPV_OK;
+    }
     FPV_HIP(e->cfg.precision == FPV_F64
                 ? launch_convert<double>(e->state, (void*)state_in, e->cfg.num_envs, false, (hipStream_t)stream)
                 : launch_convert<float>(e->state, (void*)state_in, e->cfg.num_envs, false, (hipStream_t)stream));

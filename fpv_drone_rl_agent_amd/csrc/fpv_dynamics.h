@@ -18,6 +18,7 @@ constexpr int kGranules = 9;    // 16-byte (fp32) granules of state per drone
 constexpr int kStateWords = 36;
 constexpr int kObsWords = 20;
 constexpr int kSubstepPairs = 6;  // hover.py:24 env_step_ratio; each aviary step = 2 sub-steps
+constexpr int kYawGranules = 11, kYawStateWords = 44, kYawObsWords = 12;  // docs/SPEC.md §10 (simulation/yaw.py)
 
 // storage slot (granule*4 + component) -> canonical word of docs/SPEC.md §2
 __host__ __device__ constexpr int canon_of_slot(int s) {
@@ -220,10 +221,10 @@ struct Drone {
     T a0, a1, a2, a3;          // granule 8: previous action
 };
 
-template <typename T>
+template <typename T, int G = kGranules>
 __device__ __forceinline__ void load_drone(Drone<T>& d, const Vec4<T>* __restrict__ st, int64_t tile,
                                            int lane) {
-    const Vec4<T>* p = st + tile * (kGranules * kTile) + lane;
+    const Vec4<T>* p = st + tile * (G * kTile) + lane;
     Vec4<T> g;
     g = p[0 * kTile]; d.px = g.x; d.py = g.y; d.pz = g.z; d.steps = g.w;
     g = p[1 * kTile]; d.qx = g.x; d.qy = g.y; d.qz = g.z; d.qw = g.w;
@@ -236,10 +237,10 @@ __device__ __forceinline__ void load_drone(Drone<T>& d, const Vec4<T>* __restric
     g = p[8 * kTile]; d.a0 = g.x; d.a1 = g.y; d.a2 = g.z; d.a3 = g.w;
 }
 
-template <typename T>
+template <typename T, int G = kGranules>
 __device__ __forceinline__ void store_drone(const Drone<T>& d, Vec4<T>* __restrict__ st, int64_t tile,
                                             int lane) {
-    Vec4<T>* p = st + tile * (kGranules * kTile) + lane;
+    Vec4<T>* p = st + tile * (G * kTile) + lane;
     p[0 * kTile] = Vec4<T>{d.px, d.py, d.pz, d.steps};
     p[1 * kTile] = Vec4<T>{d.qx, d.qy, d.qz, d.qw};
     p[2 * kTile] = Vec4<T>{d.vx, d.vy, d.vz, d.ep_ret};
@@ -278,8 +279,12 @@ __device__ __forceinline__ void control_tick(Drone<T>& d, T spx, T spy, T spz, T
 }
 
 // ---------------------------------------------------------------- physics sub-step (SPEC §4.2-6)
+// inv_mass / k_lin / k_pqr are compile-time constants for the hover task and per-drone values under the
+// yaw task's domain randomisation (SPEC §10)
 template <typename T, bool NOISE>
-__device__ __forceinline__ void physics_substep(Drone<T>& d, const T (&pwm)[4], T sigma, const T (&g)[4]) {
+__device__ __forceinline__ void physics_substep(Drone<T>& d, const T (&pwm)[4], T sigma, const T (&g)[4],
+                                                T inv_mass = C<T>::inv_mass, T k_lin = C<T>::k_lin,
+                                                T k_pqr = C<T>::k_pqr) {
     // motors: first-order lag, multiplicative noise, thrust = thr^2 * f_max (f_max = 1 N)
     d.t0 += C<T>::alpha * (pwm[0] - d.t0);
     d.t1 += C<T>::alpha * (pwm[1] - d.t1);
@@ -297,9 +302,9 @@ __device__ __forceinline__ void physics_substep(Drone<T>& d, const T (&pwm)[4], 
     T tx = C<T>::arm * ((f1 + f2) - (f0 + f3));
     T ty = C<T>::arm * ((f1 + f3) - (f0 + f2));
     T tz = C<T>::kq_over_kf * ((f2 + f3) - (f0 + f1));
-    tx -= C<T>::k_pqr * abs_(d.wx) * d.wx;
-    ty -= C<T>::k_pqr * abs_(d.wy) * d.wy;
-    tz -= C<T>::k_pqr * abs_(d.wz) * d.wz;
+    tx -= k_pqr * abs_(d.wx) * d.wx;
+    ty -= k_pqr * abs_(d.wy) * d.wy;
+    tz -= k_pqr * abs_(d.wz) * d.wz;
 
     // rotation matrix (columns = body axes in world)
     const T xx = d.qx * d.qx, yy = d.qy * d.qy, zz = d.qz * d.qz;
@@ -312,12 +317,12 @@ __device__ __forceinline__ void physics_substep(Drone<T>& d, const T (&pwm)[4], 
     const T vbx = r00 * d.vx + r10 * d.vy + r20 * d.vz;
     const T vby = r01 * d.vx + r11 * d.vy + r21 * d.vz;
     const T vbz = r02 * d.vx + r12 * d.vy + r22 * d.vz;
-    const T fbx = -C<T>::k_lin * abs_(vbx) * vbx;
-    const T fby = -C<T>::k_lin * abs_(vby) * vby;
-    const T fbz = fz - C<T>::k_lin * abs_(vbz) * vbz;
-    const T ax = (r00 * fbx + r01 * fby + r02 * fbz) * C<T>::inv_mass;
-    const T ay = (r10 * fbx + r11 * fby + r12 * fbz) * C<T>::inv_mass;
-    const T az = (r20 * fbx + r21 * fby + r22 * fbz) * C<T>::inv_mass - C<T>::grav;
+    const T fbx = -k_lin * abs_(vbx) * vbx;
+    const T fby = -k_lin * abs_(vby) * vby;
+    const T fbz = fz - k_lin * abs_(vbz) * vbz;
+    const T ax = (r00 * fbx + r01 * fby + r02 * fbz) * inv_mass;
+    const T ay = (r10 * fbx + r11 * fby + r12 * fbz) * inv_mass;
+    const T az = (r20 * fbx + r21 * fby + r22 * fbz) * inv_mass - C<T>::grav;
     // Euler's equation with I = diag(ixx, ixx, izz): omega x I omega = (wy wz (izz-iyy), wz wx (ixx-izz), 0)
     const T gx = d.wy * d.wz * C<T>::izz_minus_iyy;
     const T gy = d.wz * d.wx * C<T>::ixx_minus_izz;
@@ -449,6 +454,23 @@ __device__ __forceinline__ bool observe(Drone<T>& d, T roll, T pitch, T yaw, T a
     o[16] = a0; o[17] = a1; o[18] = a2; o[19] = a3;
     d.prev_cx = cx; d.prev_cy = cyy; d.prev_area = area; d.prev_ratio = ratio;  // hover.py:270-272
     return vis;
+}
+
+// stage a wave's [64][W] observation tile through LDS and write it out row-major (W a multiple of 4)
+template <typename T, int W = kObsWords>
+__device__ __forceinline__ void store_obs_tile(const T (&o)[W], T* __restrict__ obs, int64_t tile, int lane, int64_t n,
+                                               Vec4<T>* lds) {
+#pragma unroll
+    for (int g = 0; g < W / 4; ++g)
+        lds[lane * (W / 4) + g] = Vec4<T>{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+    __syncthreads();
+    Vec4<T>* out = reinterpret_cast<Vec4<T>*>(obs + tile * (kTile * W));
+    const int64_t rows_left = n - tile * kTile;  // rows of this tile that exist
+#pragma unroll
+    for (int r = 0; r < W / 4; ++r) {
+        const int f4 = r * kTile + lane;         // 16-byte granule index inside the tile
+        if (f4 / (W / 4) < rows_left) out[f4] = lds[f4];
+    }
 }
 
 }  // namespace fpv

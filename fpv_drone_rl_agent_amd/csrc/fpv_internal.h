@@ -33,6 +33,7 @@ struct StepArgs {
     uint64_t id_offset;
     T sigma;
     int32_t floor_check;
+    int32_t domain_rand;  // yaw task: resample the airframe at every reset
     // fused VecNormalize bookkeeping (all optional, fp32 handles only; see fpv_step_fused)
     uint8_t* done;       // [n] terminated | truncated
     float* ret;          // [n] discounted-return accumulator, updated in place
@@ -50,6 +51,15 @@ template <typename T>
 hipError_t launch_init(void* state, void* tmpl, int64_t n, hipStream_t s);
 template <typename T>
 hipError_t launch_convert(void* state, void* canon, int64_t n, bool to_canon, hipStream_t s);
+
+// fpv_yaw.hip
+template <typename T>
+hipError_t launch_yaw_step(const StepArgs<T>& a, bool noise, hipStream_t s);
+template <typename T>
+hipError_t launch_yaw_reset(void* state, const uint64_t* tick, const uint8_t* mask, void* obs, int64_t n, uint64_t seed,
+                            uint64_t id_offset, int domain_rand, int all_lanes, hipStream_t s);
+template <typename T>
+hipError_t launch_yaw_convert(void* state, void* canon, int64_t n, bool to_canon, hipStream_t s);
 
 hipError_t launch_tick_fill(uint64_t* tick, int64_t tiles, uint64_t v, hipStream_t s);
 

@@ -58,23 +58,6 @@ __device__ __forceinline__ void drone_from_template(Drone<T>& d, T tv) {
     d.er = __shfl(tv, 28); d.ep = __shfl(tv, 29); d.eyaw = __shfl(tv, 30); d.prev_cy = __shfl(tv, 31);
 }
 
-// stage a wave's [64][20] observation tile through LDS and write it out row-major
-template <typename T>
-__device__ __forceinline__ void store_obs_tile(const T (&o)[kObsWords], T* __restrict__ obs, int64_t tile,
-                                               int lane, int64_t n, Vec4<T>* lds) {
-#pragma unroll
-    for (int g = 0; g < kObsWords / 4; ++g)
-        lds[lane * (kObsWords / 4) + g] = Vec4<T>{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
-    __syncthreads();
-    Vec4<T>* out = reinterpret_cast<Vec4<T>*>(obs + tile * (kTile * kObsWords));
-    const int64_t rows_left = n - tile * kTile;  // rows of this tile that exist
-#pragma unroll
-    for (int r = 0; r < kObsWords / 4; ++r) {
-        const int f4 = r * kTile + lane;         // 16-byte granule index inside the tile
-        if (f4 / (kObsWords / 4) < rows_left) out[f4] = lds[f4];
-    }
-}
-
 // ---------------------------------------------------------------- K1
 template <typename T, bool NOISE, bool FUSED>
 __global__ __launch_bounds__(kTile) void step_kernel(StepArgs<T> p) {

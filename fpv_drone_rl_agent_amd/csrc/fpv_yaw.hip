@@ -1,0 +1,219 @@
+// fpv_yaw.hip — yaw-setpoint task (simulation/yaw.py skeleton + docs/SPEC.md §10), BASELINE cfg 5.
+//
+// Same machinery as the hover step (one lane per drone, 64-drone tiles of 16-byte granules, LDS-staged
+// observation rows, per-tile done ledger), with: a 1-D action, ONE aviary step (2 physics sub-steps) per
+// agent step, a 12-word observation, per-drone domain-randomised mass / drag (two extra granules of
+// state: action history and airframe parameters), and a reset that draws the initial heading and the
+// airframe from Philox inside the kernel.
+#include "fpv_dynamics.h"
+#include "fpv_internal.h"
+
+namespace fpv {
+
+template <typename T>
+struct YawExtra {
+    T h0, h1, h2, h3;        // granule 9: last four yaw actions, oldest first (yaw.py:53-55)
+    T mass, cd, kpqr, spare; // granule 10: airframe of this episode
+};
+
+template <typename T>
+__device__ __forceinline__ void yaw_uniforms(uint64_t seed, uint32_t gid, uint64_t tick, T (&u)[4]) {
+    uint32_t x[4];
+    philox4x32_10(gid, (uint32_t)tick, (uint32_t)(tick >> 32), 0x59415731u, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) u[j] = ((T)(x[j] >> 8) + T(0.5)) * T(1.0 / 16777216.0);
+}
+
+// observation of yaw.py:57-74 (SPEC §10.4); returns the target visibility
+template <typename T>
+__device__ __forceinline__ bool yaw_observe(const Drone<T>& d, const YawExtra<T>& e, T roll, T pitch, T yaw, T av0, T av1,
+                                            T av2, T (&o)[kYawObsWords]) {
+    constexpr T inv_pi = T(0.31830988618379067154);
+    T cx, cy, area, ratio;
+    const bool vis = camera_features(d, cx, cy, area, ratio);
+    o[0] = roll * inv_pi; o[1] = pitch * inv_pi; o[2] = yaw * inv_pi;   // yaw.py:59
+    o[3] = cx; o[4] = cy;                                               // yaw.py:62-63
+    o[5] = av0; o[6] = av1; o[7] = av2;                                 // yaw.py:66
+    o[8] = e.h0; o[9] = e.h1; o[10] = e.h2; o[11] = e.h3;               // yaw.py:69
+    return vis;
+}
+
+// SPEC §10 reset: resting on the floor, random heading, (optionally) a new airframe
+template <typename T>
+__device__ __forceinline__ void yaw_reset(Drone<T>& d, YawExtra<T>& e, T thr_warm, uint64_t seed, uint32_t gid,
+                                          uint64_t tick, bool domain_rand, T (&o)[kYawObsWords]) {
+    T u[4];
+    yaw_uniforms(seed, gid, tick, u);
+    const T psi = C<T>::pi * (T(2) * u[0] - T(1));                      // yaw.py:79
+    T s, c;
+    sincos_(T(0.5) * psi, &s, &c);
+    d = Drone<T>{};
+    d.pz = C<T>::z_rest;
+    d.qz = s; d.qw = c;
+    d.t0 = d.t1 = d.t2 = d.t3 = thr_warm;
+    d.eyaw = psi;
+    e.h0 = e.h1 = e.h2 = e.h3 = T(0);
+    e.mass = domain_rand ? T(0.08) + T(0.04) * u[1] : T(0.1);
+    e.cd = domain_rand ? T(1) + u[2] : T(1.5);
+    e.kpqr = domain_rand ? (T(0.5) + T(1.5) * u[3]) * T(1.0e-4) : T(1.0e-4);
+    e.spare = T(0);
+    yaw_observe(d, e, T(0), T(0), psi, T(0), T(0), T(0), o);
+}
+
+template <typename T>
+__device__ __forceinline__ T warm_throttle() {
+    T thr = T(0);
+    for (int k = 0; k < 20; ++k) thr += C<T>::alpha * (C<T>::pwm_idle - thr);  // hover.py:109-110, noise-free
+    return thr;
+}
+
+template <typename T, bool NOISE>
+__global__ __launch_bounds__(kTile) void yaw_step_kernel(StepArgs<T> p) {
+    __shared__ Vec4<T> lds[kTile * kYawObsWords / 4];
+    const int lane = threadIdx.x;
+    const int64_t tile = blockIdx.x;
+    const int64_t i = tile * kTile + lane;
+    const bool live = i < p.n;
+
+    Drone<T> d;
+    load_drone<T, kYawGranules>(d, p.state, tile, lane);
+    Vec4<T>* ext = p.state + tile * (kYawGranules * kTile) + lane;
+    Vec4<T> g9 = ext[9 * kTile], g10 = ext[10 * kTile];
+    YawExtra<T> e{g9.x, g9.y, g9.z, g9.w, g10.x, g10.y, g10.z, g10.w};
+    const T a = live ? p.actions[i] : T(0);
+    const uint64_t agent_tick = p.tick[tile];
+    const uint32_t led_fill = p.led_count[tile];
+    const uint32_t gid = (uint32_t)(p.id_offset + (uint64_t)i);
+
+    const T prev_a = e.h3;
+    e.h0 = e.h1; e.h1 = e.h2; e.h2 = e.h3; e.h3 = a;                   // yaw.py:107
+    // yaw.py:110-121: full action (0, 0, a, -1) -> setpoint (0, 0, -30 a, 0)
+    T pwm[4];
+    control_tick(d, T(0), T(0), a * T(-30), T(0), pwm);
+    T ga[4] = {}, gb[4] = {};
+    if constexpr (NOISE) normal8(p.seed, gid, agent_tick, ga, gb);
+    const T inv_mass = rcp_(e.mass), k_lin = T(0.5 * 1.225 * 3.0e-4) * e.cd;
+    physics_substep<T, NOISE>(d, pwm, p.sigma, ga, inv_mass, k_lin, e.kpqr);   // yaw.py:126-127: one aviary step
+    physics_substep<T, NOISE>(d, pwm, p.sigma, gb, inv_mass, k_lin, e.kpqr);
+
+    T roll, pitch, yaw;
+    euler_from_quat(d.qx, d.qy, d.qz, d.qw, roll, pitch, yaw);
+    uint32_t bits = 0;
+    if (d.steps >= T(400)) bits |= kInfoTrunc;                          // yaw.py:138
+    if (sqrt_(d.px * d.px + d.py * d.py + d.pz * d.pz) > T(3.0)) bits |= kInfoTerm | kInfoOob;  // yaw.py:141-143
+    d.steps += T(1);                                                    // yaw.py:145
+    const T av0 = clip_(wrap_angle(roll - d.er) * T(4), T(-1), T(1));   // * 120 / 30
+    const T av1 = clip_(wrap_angle(pitch - d.ep) * T(4), T(-1), T(1));
+    const T av2 = clip_(wrap_angle(yaw - d.eyaw) * T(4), T(-1), T(1));
+    T o[kYawObsWords];
+    const bool vis = yaw_observe(d, e, roll, pitch, yaw, av0, av1, av2, o);
+    const T target = vis ? -sqrt_(o[3] * o[3] + o[4] * o[4]) : T(-2);
+    const T reward = T(1) + target - T(0.01) * d.wz * d.wz - T(0.2) * abs_(a - prev_a);
+    d.er = roll; d.ep = pitch; d.eyaw = yaw;
+    d.ep_ret += reward;
+
+    const bool done = live && bits != 0;
+    const unsigned long long m = __ballot(done);
+    if (m != 0ull) {
+        if (done) {
+            const int64_t row = (int64_t)led_fill + (int64_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (row < p.led_rows) {
+                const int64_t slot = tile * p.led_rows + row;
+                p.led_idx[slot] = (int32_t)i;
+                p.led_info[slot] = bits | ((uint32_t)d.steps << 8);
+                p.led_tag[slot] = (uint32_t)agent_tick;
+                p.led_ret[slot] = d.ep_ret;
+                Vec4<T>* lo = reinterpret_cast<Vec4<T>*>(p.led_obs + slot * kYawObsWords);
+#pragma unroll
+                for (int g = 0; g < kYawObsWords / 4; ++g) lo[g] = Vec4<T>{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+            }
+            yaw_reset(d, e, warm_throttle<T>(), p.seed, gid, agent_tick, p.domain_rand != 0, o);
+        }
+        if (lane == 0) p.led_count[tile] = led_fill + (uint32_t)__popcll(m);
+    }
+
+    store_drone<T, kYawGranules>(d, p.state, tile, lane);
+    ext[9 * kTile] = Vec4<T>{e.h0, e.h1, e.h2, e.h3};
+    ext[10 * kTile] = Vec4<T>{e.mass, e.cd, e.kpqr, e.spare};
+    if (lane == 0) p.tick[tile] = agent_tick + 1ull;
+    if (live) {
+        p.reward[i] = reward;
+        p.terminated[i] = (bits & kInfoTerm) ? 1 : 0;
+        p.truncated[i] = (bits & kInfoTrunc) ? 1 : 0;
+    }
+    store_obs_tile<T, kYawObsWords>(o, p.obs, tile, lane, p.n, lds);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kTile) void yaw_reset_kernel(Vec4<T>* state, const uint64_t* tick, const uint8_t* mask, T* obs,
+                                                          int64_t n, uint64_t seed, uint64_t id_offset, int domain_rand,
+                                                          int all_lanes) {
+    const int lane = threadIdx.x;
+    const int64_t tile = blockIdx.x;
+    const int64_t i = tile * kTile + lane;
+    if (!all_lanes && i >= n) return;
+    if (mask && i < n && !mask[i]) return;
+    Drone<T> d;
+    YawExtra<T> e;
+    T o[kYawObsWords];
+    yaw_reset(d, e, warm_throttle<T>(), seed, (uint32_t)(id_offset + (uint64_t)i), tick[tile], domain_rand != 0, o);
+    store_drone<T, kYawGranules>(d, state, tile, lane);
+    Vec4<T>* ext = state + tile * (kYawGranules * kTile) + lane;
+    ext[9 * kTile] = Vec4<T>{e.h0, e.h1, e.h2, e.h3};
+    ext[10 * kTile] = Vec4<T>{e.mass, e.cd, e.kpqr, e.spare};
+    if (obs && i < n) {
+        T* row = obs + i * kYawObsWords;
+#pragma unroll
+        for (int j = 0; j < kYawObsWords; ++j) row[j] = o[j];
+    }
+}
+
+// canonical [n][44] <-> tiled granule storage (first 36 words as the hover map, the rest in place)
+template <typename T, bool TO_CANON>
+__global__ void yaw_convert_kernel(Vec4<T>* state, T* canon, int64_t n) {
+    const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n * kYawStateWords) return;
+    const int64_t i = q / kYawStateWords;
+    const int slot = (int)(q % kYawStateWords);
+    T* word = reinterpret_cast<T*>(state + (i / kTile) * (kYawGranules * kTile) + (slot / 4) * kTile + (i % kTile)) + (slot % 4);
+    T* c = canon + i * kYawStateWords + (slot < kStateWords ? canon_of_slot(slot) : slot);
+    if (TO_CANON) *c = *word;
+    else *word = *c;
+}
+
+// ---------------------------------------------------------------- launchers
+template <typename T>
+hipError_t launch_yaw_step(const StepArgs<T>& a, bool noise, hipStream_t s) {
+    const int64_t tiles = (a.n + kTile - 1) / kTile;
+    if (noise) hipLaunchKernelGGL((yaw_step_kernel<T, true>), dim3((unsigned)tiles), dim3(kTile), 0, s, a);
+    else hipLaunchKernelGGL((yaw_step_kernel<T, false>), dim3((unsigned)tiles), dim3(kTile), 0, s, a);
+    return hipGetLastError();
+}
+template hipError_t launch_yaw_step<float>(const StepArgs<float>&, bool, hipStream_t);
+template hipError_t launch_yaw_step<double>(const StepArgs<double>&, bool, hipStream_t);
+
+template <typename T>
+hipError_t launch_yaw_reset(void* state, const uint64_t* tick, const uint8_t* mask, void* obs, int64_t n, uint64_t seed,
+                            uint64_t id_offset, int domain_rand, int all_lanes, hipStream_t s) {
+    const int64_t tiles = (n + kTile - 1) / kTile;
+    hipLaunchKernelGGL(yaw_reset_kernel<T>, dim3((unsigned)tiles), dim3(kTile), 0, s, (Vec4<T>*)state, tick, mask, (T*)obs, n,
+                       seed, id_offset, domain_rand, all_lanes);
+    return hipGetLastError();
+}
+template hipError_t launch_yaw_reset<float>(void*, const uint64_t*, const uint8_t*, void*, int64_t, uint64_t, uint64_t, int,
+                                            int, hipStream_t);
+template hipError_t launch_yaw_reset<double>(void*, const uint64_t*, const uint8_t*, void*, int64_t, uint64_t, uint64_t, int,
+                                             int, hipStream_t);
+
+template <typename T>
+hipError_t launch_yaw_convert(void* state, void* canon, int64_t n, bool to_canon, hipStream_t s) {
+    const int64_t q = n * kYawStateWords;
+    const dim3 grid((unsigned)((q + 255) / 256)), block(256);
+    if (to_canon) hipLaunchKernelGGL((yaw_convert_kernel<T, true>), grid, block, 0, s, (Vec4<T>*)state, (T*)canon, n);
+    else hipLaunchKernelGGL((yaw_convert_kernel<T, false>), grid, block, 0, s, (Vec4<T>*)state, (T*)canon, n);
+    return hipGetLastError();
+}
+template hipError_t launch_yaw_convert<float>(void*, void*, int64_t, bool, hipStream_t);
+template hipError_t launch_yaw_convert<double>(void*, void*, int64_t, bool, hipStream_t);
+
+}  // namespace fpv

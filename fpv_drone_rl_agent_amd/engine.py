@@ -26,7 +26,7 @@ class FpvEngine:
 
     def __init__(self, num_envs: int, device: int | str | torch.device = 0, *, render: bool = False,
                  noise_ratio: float = 0.02, seed: int = 0, id_offset: int = 0, precision: str = "f32",
-                 ledger_capacity: int = 0):
+                 ledger_capacity: int = 0, task: str = "hover", domain_rand: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError("FpvEngine needs a HIP device: the MI355X extension has no CPU fallback")
         self.lib = L.load()
@@ -38,14 +38,21 @@ class FpvEngine:
         self.id_offset = int(id_offset)
         self.dtype = torch.float64 if precision == "f64" else torch.float32
         self._f64 = precision == "f64"
+        if task not in ("hover", "yaw"):
+            raise ValueError("task must be 'hover' (simulation/hover.py) or 'yaw' (simulation/yaw.py)")
+        self.task = task
         cfg = L.FpvConfig(self.num_envs, dev.index or 0, L.FPV_F64 if self._f64 else L.FPV_F32,
-                          0 if render else 1, 0, float(noise_ratio), int(seed), int(id_offset), int(ledger_capacity))
+                          0 if render else 1, L.TASK_YAW if task == "yaw" else L.TASK_HOVER, float(noise_ratio),
+                          int(seed), int(id_offset), int(ledger_capacity), 1 if domain_rand else 0, 0)
         h = C.c_void_p()
         L.check(self.lib.fpv_create(C.byref(cfg), C.byref(h)), "fpv_create")
         self._h = h
+        sw, ow, aw = C.c_int32(), C.c_int32(), C.c_int32()
+        L.check(self.lib.fpv_dims(self._h, C.byref(sw), C.byref(ow), C.byref(aw)), "fpv_dims")
+        self.state_words, self.obs_words, self.act_words = sw.value, ow.value, aw.value
         n = self.num_envs
         with torch.cuda.device(dev):
-            self.obs = torch.empty((n, L.OBS_WORDS), dtype=self.dtype, device=dev)
+            self.obs = torch.empty((n, self.obs_words), dtype=self.dtype, device=dev)
             self.reward = torch.empty((n,), dtype=self.dtype, device=dev)
             self.terminated = torch.empty((n,), dtype=torch.uint8, device=dev)
             self.truncated = torch.empty((n,), dtype=torch.uint8, device=dev)
@@ -59,7 +66,7 @@ class FpvEngine:
             self.led_info = torch.zeros((cap,), dtype=torch.int32, device=dev)
             self.led_tag = torch.zeros((cap,), dtype=torch.int32, device=dev)
             self.led_ret = torch.zeros((cap,), dtype=self.dtype, device=dev)
-            self.led_obs = torch.zeros((cap, L.OBS_WORDS), dtype=self.dtype, device=dev)
+            self.led_obs = torch.zeros((cap, self.obs_words), dtype=self.dtype, device=dev)
             self._led_row = torch.arange(rows, dtype=torch.int32, device=dev).unsqueeze(0)
         self.ledger_capacity, self.ledger_rows_per_tile, self.tiles = cap, rows, tiles
         led = L.FpvLedger(cap, rows, self.led_count.data_ptr(), self.led_idx.data_ptr(), self.led_info.data_ptr(),
@@ -95,8 +102,8 @@ class FpvEngine:
         — the engine's own buffers unless output tensors are given."""
         if actions.dtype != self.dtype or actions.device != self.device or not actions.is_contiguous():
             raise ValueError("actions must be a contiguous device tensor of the engine's dtype")
-        if actions.shape != (self.num_envs, L.ACT_WORDS):
-            raise ValueError(f"actions must have shape ({self.num_envs}, {L.ACT_WORDS})")
+        if actions.shape != (self.num_envs, self.act_words):
+            raise ValueError(f"actions must have shape ({self.num_envs}, {self.act_words})")
         obs = self.obs if obs is None else obs
         reward = self.reward if reward is None else reward
         terminated = self.terminated if terminated is None else terminated
@@ -112,7 +119,7 @@ class FpvEngine:
         if self._f64:
             raise ValueError("step_fused runs on fp32 engines")
         if actions.dtype != self.dtype or actions.device != self.device or not actions.is_contiguous() \
-                or actions.shape != (self.num_envs, L.ACT_WORDS):
+                or actions.shape != (self.num_envs, self.act_words) or self.task != "hover":
             raise ValueError("actions must be a contiguous [num_envs, 4] device tensor of the engine's dtype")
         obs = self.obs if obs is None else obs
         reward = self.reward if reward is None else reward
@@ -124,14 +131,14 @@ class FpvEngine:
 
     # -- state blobs ----------------------------------------------------------------
     def get_state(self) -> torch.Tensor:
-        out = torch.empty((self.num_envs, L.STATE_WORDS), dtype=self.dtype, device=self.device)
+        out = torch.empty((self.num_envs, self.state_words), dtype=self.dtype, device=self.device)
         L.check(self.lib.fpv_get_state(self._h, _ptr(out), _stream(self.device)), "fpv_get_state")
         return out
 
     def set_state(self, state: torch.Tensor) -> None:
         state = state.to(device=self.device, dtype=self.dtype).contiguous()
-        if state.shape != (self.num_envs, L.STATE_WORDS):
-            raise ValueError("state must be [num_envs, 36]")
+        if state.shape != (self.num_envs, self.state_words):
+            raise ValueError(f"state must be [num_envs, {self.state_words}]")
         L.check(self.lib.fpv_set_state(self._h, _ptr(state), _stream(self.device)), "fpv_set_state")
         torch.cuda.current_stream(self.device).synchronize()  # `state` may be a temporary
 

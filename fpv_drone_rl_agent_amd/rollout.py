@@ -47,10 +47,15 @@ class RolloutCollector:
         dev = self.device = engine.device
         T, N = self.T, self.N
         f32, u8 = torch.float32, torch.uint8
-        self.obs_norm = ops.RunningNorm(20, dev, clip=clip_obs)
+        O, A = engine.obs_words, engine.act_words       # 20 / 4 hover (hover.py:59-70), 12 / 1 yaw (yaw.py:37-45)
+        self.O, self.A = O, A
+        if (policy.obs_dim, policy.act_dim) != (O, A):
+            raise ValueError(f"policy is {policy.obs_dim}->{policy.act_dim} but the task needs {O}->{A}")
+        fused = bool(fused) and engine.task == "hover"   # the fused kernels are built for the hover shapes
+        self.obs_norm = ops.RunningNorm(O, dev, clip=clip_obs)
         self.rew_norm = ops.RewardNorm(N, dev, gamma=gamma, clip=clip_reward)
-        self.buf_obs = torch.zeros((T, N, 20), dtype=f32, device=dev)
-        self.buf_act = torch.zeros((T, N, 4), dtype=f32, device=dev)
+        self.buf_obs = torch.zeros((T, N, O), dtype=f32, device=dev)
+        self.buf_act = torch.zeros((T, N, A), dtype=f32, device=dev)
         self.buf_rew = torch.zeros((T, N), dtype=f32, device=dev)
         self._starts = torch.zeros((T + 1, N), dtype=u8, device=dev)   # row t: episode_start before step t
         self._starts[T].fill_(1)
@@ -59,12 +64,12 @@ class RolloutCollector:
         self.buf_logp = torch.zeros((T, N), dtype=f32, device=dev)
         self.adv = torch.zeros((T, N), dtype=f32, device=dev)
         self.ret = torch.zeros((T, N), dtype=f32, device=dev)
-        self.cur_obs = torch.zeros((N, 20), dtype=f32, device=dev)       # normalised s_t
+        self.cur_obs = torch.zeros((N, O), dtype=f32, device=dev)        # normalised s_t
         self.episode_start = self._starts[T]                                # carried into the next rollout
         self.done = torch.zeros((N,), dtype=u8, device=dev)
-        self.clipped = torch.zeros((N, 4), dtype=f32, device=dev)
+        self.clipped = torch.zeros((N, A), dtype=f32, device=dev)
         self.last_val = torch.zeros((N,), dtype=f32, device=dev)
-        self.snap = torch.zeros((T, 44), dtype=torch.float64, device=dev)   # {obs_rms[41], ret_rms[3]} after step t
+        self.snap = torch.zeros((T, max(44, 2 * O + 4)), dtype=torch.float64, device=dev)  # {obs_rms, ret_rms} after step t
         self.fused = bool(fused)
         if self.fused:
             self.fp = FusedPolicy(policy, seed=policy_seed, id_offset=engine.id_offset)
@@ -103,7 +108,7 @@ class RolloutCollector:
     def _step_torch(self, t: int) -> None:
         eng, pol = self.engine, self.policy
         self.buf_obs[t].copy_(self.cur_obs)
-        eps = torch.randn((self.N, 4), dtype=torch.float32, device=self.device)
+        eps = torch.randn((self.N, self.A), dtype=torch.float32, device=self.device)
         action, value, logp = pol.act(self.cur_obs, eps)
         self.buf_act[t].copy_(action)
         self.buf_val[t].copy_(value)
@@ -112,7 +117,7 @@ class RolloutCollector:
         eng.step(self.clipped)
         torch.bitwise_or(eng.terminated, eng.truncated, out=self.done)
         self._normalise_obs(eng.obs, self.cur_obs)
-        self.snap[t, :41].copy_(self.obs_norm.rms)
+        self.snap[t, :2 * self.O + 1].copy_(self.obs_norm.rms)
         if self.norm_reward:
             self.rew_norm(eng.reward, self.done, out=self.buf_rew[t])
         else:
@@ -205,7 +210,7 @@ class RolloutCollector:
         tobs = eng.led_obs[rows]
         if self.norm_obs:
             rms = self.snap[t_idx]                          # statistics as they were at that step
-            mean, var = rms[:, :20], rms[:, 20:40]
+            mean, var = rms[:, :self.O], rms[:, self.O:2 * self.O]
             tobs = torch.clamp((tobs.double() - mean) / torch.sqrt(var + self.obs_norm.eps), -self.obs_norm.clip,
                                self.obs_norm.clip).float()
         if self.fused:

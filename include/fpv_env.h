@@ -39,6 +39,13 @@ typedef enum {
 
 typedef enum { FPV_F32 = 0, FPV_F64 = 1 } fpv_precision;
 
+/* FPV_TASK_HOVER: simulation/hover.py (state 36, obs 20, action 4).  FPV_TASK_YAW: the yaw-setpoint task of
+ * simulation/yaw.py as completed by docs/SPEC.md §10 (state 44, obs 12, action 1, optional domain randomisation). */
+typedef enum { FPV_TASK_HOVER = 0, FPV_TASK_YAW = 1 } fpv_task;
+#define FPV_YAW_STATE_WORDS 44
+#define FPV_YAW_OBS_WORDS 12   /* simulation/yaw.py:39-45 */
+#define FPV_YAW_ACT_WORDS 1    /* simulation/yaw.py:37 */
+
 /* info bits of a done-ledger entry; ep_len is stored in bits 8..31 */
 #define FPV_INFO_TERMINATED 1u    /* hover.py:281,290 */
 #define FPV_INFO_TRUNCATED 2u     /* hover.py:275-276 */
@@ -55,11 +62,13 @@ typedef struct {
     int32_t device;          /* HIP device ordinal */
     int32_t precision;       /* fpv_precision: arithmetic + I/O type of this handle */
     int32_t floor_check;     /* 1 = render=False (hover.py:283); 0 disables the floor rule */
-    int32_t reserved0;
+    int32_t task;            /* fpv_task */
     double noise_ratio;      /* cf2x.yaml:5 motor noise (0.02); 0 = noise-free */
     uint64_t seed;           /* Philox key (docs/SPEC.md §9) */
     uint64_t id_offset;      /* global id of drone 0: rank * num_envs */
     int64_t ledger_capacity; /* done-ledger rows (rounded up to a multiple of the tile count); 0 = 2 * num_envs */
+    int32_t domain_rand;     /* FPV_TASK_YAW: per-drone mass / drag resampled at every reset (BASELINE cfg 5) */
+    int32_t reserved1;
 } fpv_config;
 
 /* Device-side view of the done ledger (SB3 VecEnv `infos[i]["terminal_observation"]`,
@@ -91,7 +100,8 @@ int fpv_reset(fpv_env* env, const uint8_t* mask, void* obs, void* stream);
 
 /* QuadXHoverEnv.step() — hover.py:334-358 for every drone, with VecEnv auto-reset.
  * actions [num_envs][4] raw (unscaled, unclipped); obs [num_envs][20]; reward [num_envs];
- * terminated / truncated uint8 [num_envs].  Float handles only. */
+ * terminated / truncated uint8 [num_envs] (FPV_TASK_YAW: actions [num_envs][1], obs [num_envs][12] —
+ * simulation/yaw.py:102-149).  Float handles only. */
 int fpv_step(fpv_env* env, const float* actions, float* obs, float* reward, uint8_t* terminated,
              uint8_t* truncated, void* stream);
 /* Same for an FPV_F64 handle (trajectory-level parity runs). */
@@ -125,6 +135,9 @@ int fpv_moments_merge(int64_t tiles, const double* partials, double batch_count,
  * var_t = snapshots[t][42], the return variance as it stood after step t.  raw/out are [T][n]; out may alias raw. */
 int fpv_reward_finalize(int64_t T, int64_t n, const float* raw, const double* snapshots, float clip, float eps,
                         float* out, void* stream);
+
+/* Word counts of this handle's task: state blob row, observation row, action row. */
+int fpv_dims(fpv_env* env, int32_t* state_words, int32_t* obs_words, int32_t* act_words);
 
 /* Device address of the handle's agent-tick counter (uint64; keys in-kernel RNG streams, e.g. fpv_policy_io.tick). */
 int fpv_tick_ptr(fpv_env* env, const uint64_t** out);

@@ -214,8 +214,16 @@ double fpv_oracle_reward(const double pos[3], const double euler[3], double omeg
 }
 
 /* ------------------------------------------------------------------ sub-step (SPEC §4) */
+static void substep_p(const fpv_oracle_cfg* cfg, fpv_oracle_state* s, const double sp[4], double pwm[4], int k,
+                      uint64_t drone_id, uint64_t tick, double mass, double k_lin, double k_pqr);
+
 void fpv_oracle_substep(const fpv_oracle_cfg* cfg, fpv_oracle_state* s, const double sp[4],
                         double pwm[4], int k, uint64_t drone_id, uint64_t tick) {
+    substep_p(cfg, s, sp, pwm, k, drone_id, tick, MASS, K_LIN, K_PQR);
+}
+
+static void substep_p(const fpv_oracle_cfg* cfg, fpv_oracle_state* s, const double sp[4], double pwm[4], int k,
+                      uint64_t drone_id, uint64_t tick, double mass, double k_lin, double k_pqr) {
     /* 1. control */
     if ((k & 1) == 0) {
         double u[3];
@@ -253,17 +261,17 @@ void fpv_oracle_substep(const fpv_oracle_cfg* cfg, fpv_oracle_state* s, const do
     double vb[3];
     for (int i = 0; i < 3; ++i) vb[i] = R[0][i] * s->vel[0] + R[1][i] * s->vel[1] + R[2][i] * s->vel[2];
     double Fb[3], tb[3] = {0, 0, 0};
-    for (int i = 0; i < 3; ++i) Fb[i] = -K_LIN * fabs(vb[i]) * vb[i];
+    for (int i = 0; i < 3; ++i) Fb[i] = -k_lin * fabs(vb[i]) * vb[i];
     for (int i = 0; i < 4; ++i) {
         Fb[2] += f[i];
         tb[0] += PROP_Y[i] * f[i];
         tb[1] -= PROP_X[i] * f[i];
         tb[2] += KQ_OVER_KF * SPIN[i] * f[i];
     }
-    for (int i = 0; i < 3; ++i) tb[i] -= K_PQR * fabs(s->omega[i]) * s->omega[i];
+    for (int i = 0; i < 3; ++i) tb[i] -= k_pqr * fabs(s->omega[i]) * s->omega[i];
     /* 4. accelerations */
     double acc[3];
-    for (int i = 0; i < 3; ++i) acc[i] = (R[i][0] * Fb[0] + R[i][1] * Fb[1] + R[i][2] * Fb[2]) / MASS;
+    for (int i = 0; i < 3; ++i) acc[i] = (R[i][0] * Fb[0] + R[i][1] * Fb[1] + R[i][2] * Fb[2]) / mass;
     acc[2] -= GRAV;
     const double* w = s->omega;
     double Iw[3] = {INERTIA[0] * w[0], INERTIA[1] * w[1], INERTIA[2] * w[2]};
@@ -422,4 +430,102 @@ void fpv_oracle_gae(int64_t T, int64_t n, const double* rewards, const double* v
     }
 }
 
-int fpv_oracle_version(void) { return 1; }
+/* ------------------------------------------------------------------ yaw task (SPEC §10, yaw.py) */
+static void yaw_uniforms(uint64_t seed, uint64_t drone_id, uint64_t tick, double u[4]) {
+    uint32_t ctr[4] = {(uint32_t)drone_id, (uint32_t)tick, (uint32_t)(tick >> 32), 0x59415731u};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t x[4];
+    fpv_oracle_philox4x32_10(ctr, key, x);
+    for (int j = 0; j < 4; ++j) u[j] = ((double)(x[j] >> 8) + 0.5) * (1.0 / 16777216.0);
+}
+
+static int yaw_observe(const double* y, const double euler[3], const double angvel[3], double obs[FPV_ORACLE_YAW_OBS]) {
+    const fpv_oracle_state* s = (const fpv_oracle_state*)y;
+    double c[2], area, ratio;
+    int vis = fpv_oracle_camera(s->pos, s->quat, c, &area, &ratio);
+    for (int i = 0; i < 3; ++i) obs[i] = euler[i] / M_PI;             /* yaw.py:59 */
+    obs[3] = c[0]; obs[4] = c[1];                                     /* yaw.py:62-63 ([BUILD] panel centre) */
+    for (int i = 0; i < 3; ++i) obs[5 + i] = angvel[i];               /* yaw.py:66 */
+    for (int i = 0; i < 4; ++i) obs[8 + i] = y[36 + i];               /* yaw.py:69 */
+    return vis;
+}
+
+void fpv_oracle_yaw_reset_state(const fpv_oracle_cfg* cfg, double* y, uint64_t drone_id, uint64_t tick,
+                                double obs[FPV_ORACLE_YAW_OBS]) {
+    fpv_oracle_state* s = (fpv_oracle_state*)y;
+    double u[4];
+    yaw_uniforms(cfg->seed, drone_id, tick, u);
+    memset(y, 0, FPV_ORACLE_YAW_STATE * sizeof(double));
+    double psi = M_PI * (2.0 * u[0] - 1.0);                            /* yaw.py:79 */
+    s->pos[2] = Z_REST;
+    s->quat[2] = sin(0.5 * psi); s->quat[3] = cos(0.5 * psi);
+    double thr = 0.0;
+    for (int i = 0; i < 20; ++i) thr += (DT / TAU) * (PWM_IDLE - thr);
+    for (int i = 0; i < 4; ++i) s->thr[i] = thr;
+    s->prev_euler[2] = psi;
+    y[40] = cfg->domain_rand ? 0.08 + 0.04 * u[1] : MASS;
+    y[41] = cfg->domain_rand ? 1.0 + u[2] : 1.5;
+    y[42] = cfg->domain_rand ? (0.5 + 1.5 * u[3]) * 1.0e-4 : K_PQR;
+    double euler[3] = {0.0, 0.0, psi}, zero[3] = {0, 0, 0}, tmp[FPV_ORACLE_YAW_OBS];
+    yaw_observe(y, euler, zero, obs ? obs : tmp);
+}
+
+uint32_t fpv_oracle_yaw_step_one(const fpv_oracle_cfg* cfg, double* y, double action, uint64_t drone_id,
+                                 uint64_t agent_tick, double obs[FPV_ORACLE_YAW_OBS], double* reward) {
+    fpv_oracle_state* s = (fpv_oracle_state*)y;
+    double prev_a = y[39];
+    y[36] = y[37]; y[37] = y[38]; y[38] = y[39]; y[39] = action;      /* yaw.py:107 */
+    double full[4] = {0.0, 0.0, action, -1.0}, sp[4], pwm[4] = {0, 0, 0, 0};  /* yaw.py:110-115 */
+    fpv_oracle_scale_action(full, sp);                                /* yaw.py:118-121 */
+    double k_lin = 0.5 * 1.225 * y[41] * 3.0e-4;
+    for (int k = 0; k < 2; ++k)                                       /* yaw.py:126-127: one aviary step */
+        substep_p(cfg, s, sp, pwm, k, drone_id, agent_tick * 2u + (uint64_t)k, y[40], k_lin, y[42]);
+    double euler[3], angvel[3];
+    fpv_oracle_euler_from_quat(s->quat, euler);
+    uint32_t bits = 0;
+    if (s->step_count >= MAX_STEPS) bits |= FPV_ORACLE_TRUNC;         /* yaw.py:138 */
+    if (sqrt(s->pos[0] * s->pos[0] + s->pos[1] * s->pos[1] + s->pos[2] * s->pos[2]) > DOME)
+        bits |= FPV_ORACLE_TERM | FPV_ORACLE_OOB;                     /* yaw.py:141-143 */
+    s->step_count += 1.0;                                             /* yaw.py:145 */
+    for (int i = 0; i < 3; ++i) angvel[i] = clampd(fpv_oracle_wrap(euler[i] - s->prev_euler[i]) * 120.0 / 30.0, -1.0, 1.0);
+    int vis = yaw_observe(y, euler, angvel, obs);
+    double target = vis ? -sqrt(obs[3] * obs[3] + obs[4] * obs[4]) : -2.0;
+    *reward = 1.0 + target - 0.01 * s->omega[2] * s->omega[2] - 0.2 * fabs(action - prev_a);
+    memcpy(s->prev_euler, euler, sizeof euler);
+    s->ep_return += *reward;
+    return bits;
+}
+
+void fpv_oracle_yaw_reset_batch(const fpv_oracle_cfg* cfg, int64_t n, double* state, double* obs,
+                                const uint8_t* mask, uint64_t tick) {
+    for (int64_t i = 0; i < n; ++i) {
+        if (mask && !mask[i]) continue;
+        fpv_oracle_yaw_reset_state(cfg, state + i * FPV_ORACLE_YAW_STATE, cfg->id_offset + (uint64_t)i, tick,
+                                   obs ? obs + i * FPV_ORACLE_YAW_OBS : NULL);
+    }
+}
+
+void fpv_oracle_yaw_step_batch(const fpv_oracle_cfg* cfg, int64_t n, double* state, const double* actions,
+                               uint64_t agent_tick, double* obs, double* reward, uint8_t* terminated,
+                               uint8_t* truncated, int64_t* led_count, int32_t* led_idx, uint32_t* led_info,
+                               double* led_ret, double* led_obs) {
+    for (int64_t i = 0; i < n; ++i) {
+        double* y = state + i * FPV_ORACLE_YAW_STATE;
+        double* o = obs + i * FPV_ORACLE_YAW_OBS;
+        uint32_t b = fpv_oracle_yaw_step_one(cfg, y, actions[i], cfg->id_offset + (uint64_t)i, agent_tick, o, &reward[i]);
+        terminated[i] = (b & FPV_ORACLE_TERM) ? 1 : 0;
+        truncated[i] = (b & FPV_ORACLE_TRUNC) ? 1 : 0;
+        if (b & (FPV_ORACLE_TERM | FPV_ORACLE_TRUNC)) {
+            if (led_count) {
+                int64_t c = (*led_count)++;
+                led_idx[c] = (int32_t)i;
+                led_info[c] = b | (((uint32_t)((fpv_oracle_state*)y)->step_count) << 8);
+                led_ret[c] = ((fpv_oracle_state*)y)->ep_return;
+                memcpy(led_obs + c * FPV_ORACLE_YAW_OBS, o, FPV_ORACLE_YAW_OBS * sizeof(double));
+            }
+            fpv_oracle_yaw_reset_state(cfg, y, cfg->id_offset + (uint64_t)i, agent_tick, o);
+        }
+    }
+}
+
+int fpv_oracle_version(void) { return 2; }

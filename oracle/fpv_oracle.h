@@ -27,6 +27,8 @@ extern "C" {
 
 #define FPV_ORACLE_STATE_WORDS 36
 #define FPV_ORACLE_OBS_WORDS 20
+#define FPV_ORACLE_YAW_STATE 44 /* SPEC §10: 36 hover words + act_hist[4] + mass, Cd, k_pqr, spare */
+#define FPV_ORACLE_YAW_OBS 12   /* yaw.py:39-45 */
 
 /* canonical word order of docs/SPEC.md §2 */
 typedef struct {
@@ -48,7 +50,7 @@ typedef struct {
 
 typedef struct {
     int32_t floor_check;   /* hover.py:283 — 0 when render=True */
-    int32_t reserved;
+    int32_t domain_rand;   /* SPEC §10: resample mass / Cd / k_pqr at every yaw-task reset */
     double noise_ratio;    /* cf2x.yaml:5 (0.02) or 0 for noise-free KATs */
     uint64_t seed;         /* Philox key */
     uint64_t id_offset;    /* global id of drone 0 (rank offset) */
@@ -103,6 +105,18 @@ void fpv_oracle_gae(int64_t T, int64_t n, const double* rewards, const double* v
                     const uint8_t* episode_starts, const double* last_values,
                     const uint8_t* last_dones, double gamma, double lam, double* adv,
                     double* returns);
+
+/* ---- yaw task (simulation/yaw.py skeleton + docs/SPEC.md §10); state [n][44], obs [n][12], actions [n] ---- */
+void fpv_oracle_yaw_reset_state(const fpv_oracle_cfg* cfg, double* y, uint64_t drone_id, uint64_t tick,
+                                double obs[FPV_ORACLE_YAW_OBS]);
+uint32_t fpv_oracle_yaw_step_one(const fpv_oracle_cfg* cfg, double* y, double action, uint64_t drone_id,
+                                 uint64_t agent_tick, double obs[FPV_ORACLE_YAW_OBS], double* reward);
+void fpv_oracle_yaw_reset_batch(const fpv_oracle_cfg* cfg, int64_t n, double* state, double* obs,
+                                const uint8_t* mask_or_null, uint64_t tick);
+void fpv_oracle_yaw_step_batch(const fpv_oracle_cfg* cfg, int64_t n, double* state, const double* actions,
+                               uint64_t agent_tick, double* obs, double* reward, uint8_t* terminated,
+                               uint8_t* truncated, int64_t* led_count, int32_t* led_idx, uint32_t* led_info,
+                               double* led_ret, double* led_obs);
 
 int fpv_oracle_version(void);
 

@@ -21,6 +21,8 @@ _LIB = os.path.join(_HERE, "libfpv_oracle.so")
 
 STATE_WORDS = 36
 OBS_WORDS = 20
+YAW_STATE_WORDS = 44
+YAW_OBS_WORDS = 12
 TERM, TRUNC, OOB, FLOOR = 1, 2, 4, 8
 
 
@@ -34,7 +36,7 @@ def build(force: bool = False) -> str:
 
 
 class _Cfg(C.Structure):
-    _fields_ = [("floor_check", C.c_int32), ("reserved", C.c_int32), ("noise_ratio", C.c_double),
+    _fields_ = [("floor_check", C.c_int32), ("domain_rand", C.c_int32), ("noise_ratio", C.c_double),
                 ("seed", C.c_uint64), ("id_offset", C.c_uint64)]
 
 
@@ -67,8 +69,8 @@ def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
-def make_cfg(floor_check=True, noise_ratio=0.02, seed=0, id_offset=0):
-    return _Cfg(int(bool(floor_check)), 0, float(noise_ratio), int(seed), int(id_offset))
+def make_cfg(floor_check=True, noise_ratio=0.02, seed=0, id_offset=0, domain_rand=False):
+    return _Cfg(int(bool(floor_check)), int(bool(domain_rand)), float(noise_ratio), int(seed), int(id_offset))
 
 
 # ---------------------------------------------------------------- small pieces
@@ -156,12 +158,12 @@ def step_one(cfg, state_row, action, drone_id, agent_tick):
 
 
 class Ledger:
-    def __init__(self, cap):
+    def __init__(self, cap, obs_words=OBS_WORDS):
         self.count = C.c_int64(0)
         self.idx = np.zeros(cap, np.int32)
         self.info = np.zeros(cap, np.uint32)
         self.ret = np.zeros(cap)
-        self.obs = np.zeros((cap, OBS_WORDS))
+        self.obs = np.zeros((cap, obs_words))
 
     def rows(self):
         c = self.count.value
@@ -190,6 +192,33 @@ def step_batch(cfg, state, actions, agent_tick, ledger=None, nthreads=1):
         ledger.info.ctypes.data_as(C.POINTER(C.c_uint32)), _dp(ledger.ret), _dp(ledger.obs),
         C.c_int(nthreads))
     return obs, rew, term, trunc, (ledger if not ledger_tmp else ledger)
+
+
+# ---------------------------------------------------------------- yaw task (SPEC §10)
+def yaw_reset_states(cfg, n, tick=0):
+    st = np.zeros((n, YAW_STATE_WORDS))
+    obs = np.zeros((n, YAW_OBS_WORDS))
+    lib().fpv_oracle_yaw_reset_batch(C.byref(cfg), C.c_int64(n), _dp(st), _dp(obs), None, C.c_uint64(tick))
+    return st, obs
+
+
+def yaw_step_batch(cfg, state, actions, agent_tick, ledger=None):
+    n = state.shape[0]
+    assert state.dtype == np.float64 and state.flags.c_contiguous and state.shape[1] == YAW_STATE_WORDS
+    a = _f64(actions).reshape(n)
+    obs = np.zeros((n, YAW_OBS_WORDS))
+    rew = np.zeros(n)
+    term = np.zeros(n, np.uint8)
+    trunc = np.zeros(n, np.uint8)
+    if ledger is None:
+        ledger = Ledger(n, obs_words=YAW_OBS_WORDS)
+    u8 = C.POINTER(C.c_uint8)
+    lib().fpv_oracle_yaw_step_batch(
+        C.byref(cfg), C.c_int64(n), _dp(state), _dp(a), C.c_uint64(agent_tick), _dp(obs), _dp(rew),
+        term.ctypes.data_as(u8), trunc.ctypes.data_as(u8), C.byref(ledger.count),
+        ledger.idx.ctypes.data_as(C.POINTER(C.c_int32)), ledger.info.ctypes.data_as(C.POINTER(C.c_uint32)),
+        _dp(ledger.ret), _dp(ledger.obs))
+    return obs, rew, term, trunc, ledger
 
 
 def gae(rewards, values, episode_starts, last_values, last_dones, gamma=0.99, lam=0.95):

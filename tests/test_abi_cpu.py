@@ -28,7 +28,7 @@ def test_header_symbols_all_exported_and_bound():
 
 def test_config_struct_layout_matches_header():
     from fpv_drone_rl_agent_amd import _lib
-    assert ctypes.sizeof(_lib.FpvConfig) == 56  # i64, 4 x i32, f64, 2 x u64, i64
+    assert ctypes.sizeof(_lib.FpvConfig) == 64  # i64, 4 x i32, f64, 2 x u64, i64, 2 x i32
     assert _lib.FpvConfig.noise_ratio.offset == 24 and _lib.FpvConfig.ledger_capacity.offset == 48
     assert ctypes.sizeof(_lib.FpvLedger) == 64
 
