@@ -101,7 +101,8 @@ def main() -> None:
     torch.manual_seed(0)
     yaw = args.task == "yaw"
     policy = (ActorCritic(obs_dim=12, act_dim=1) if yaw else ActorCritic()).to(dev)
-    eng = FpvEngine(n, dev, noise_ratio=0.02, seed=0, id_offset=rank * n, task=args.task, domain_rand=yaw)
+    eng = FpvEngine(n, dev, noise_ratio=0.02, seed=0, id_offset=rank * n, task=args.task, domain_rand=yaw,
+                    ledger_capacity=n * max(2, T // 8))
     col = RolloutCollector(eng, policy, n_steps=T, use_graph=not args.no_graph)
     col.start()
     if not yaw:

@@ -36,7 +36,8 @@ def main():
     dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.manual_seed(args.seed)                       # same initial policy on every rank
     policy = ActorCritic(log_std_init=args.log_std_init).to(dev)
-    eng = FpvEngine(args.drones, dev, seed=args.seed, id_offset=rank * args.drones)
+    eng = FpvEngine(args.drones, dev, seed=args.seed, id_offset=rank * args.drones,
+                    ledger_capacity=args.drones * max(2, args.n_steps // 8))
     col = RolloutCollector(eng, policy, n_steps=args.n_steps, policy_seed=args.seed, gamma=args.gamma)
     model = PPO(col, learning_rate=args.lr, n_epochs=args.epochs, n_minibatches=args.minibatches, ent_coef=args.ent_coef,
                 target_kl=args.target_kl)

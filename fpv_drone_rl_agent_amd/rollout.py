@@ -195,6 +195,10 @@ class RolloutCollector:
         the Monitor-style episode statistics from the done ledger.  One synchronising compaction per rollout."""
         eng = self.engine
         total, all_rows = eng.ledger_rows()
+        if int(total.item()) != all_rows.numel():
+            raise RuntimeError(f"done ledger overflow: {int(total.item())} episode ends but {all_rows.numel()} rows fit "
+                               f"({eng.ledger_rows_per_tile} per 64-drone tile); create the engine with a larger "
+                               "ledger_capacity or collect shorter rollouts")
         self.episodes = {"count": int(total.item()), "ep_return": eng.led_ret[all_rows],
                          "ep_len": eng.led_info[all_rows] >> 8}
         if all_rows.numel() == 0:
