@@ -72,6 +72,7 @@ def main() -> None:
     ap.add_argument("--task", choices=["hover", "yaw"], default="hover",
                     help="yaw = BASELINE configs[4] (yaw-setpoint task with domain randomisation); not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-split-extra", action="store_true", help="skip the extra bf16x6-policy measurement")
     ap.add_argument("--kernel-launches", type=int, default=200)
     args = ap.parse_args()
 
@@ -127,6 +128,25 @@ def main() -> None:
         elapsed = float(tmax.item())
     episodes = int(col.episodes["count"])
 
+    # ---- extra (not the headline): the same K steps with the policy GEMMs on the 6-term bf16 split ----
+    split_value = None
+    if not yaw and not args.no_split_extra:
+        col.set_policy_gemm("bf16x6")
+        for _ in range(2):
+            col.collect()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(K // T):
+            col.collect()
+        barrier()
+        el2 = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([el2], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            td.all_reduce(tmax, op=td.ReduceOp.MAX)
+            el2 = float(tmax.item())
+        split_value = n * world * K / el2
+        col.set_policy_gemm("f32")
+
     # ---- roofline of the dominant kernel: kernel-only pass, HIP events on the launch stream ----
     roofline = None
     if rank == 0:
@@ -170,10 +190,14 @@ def main() -> None:
                                     "(fused fp32-MFMA policy forward + sample, fused HIP env-step + VecNormalize "
                                     "bookkeeping, buffer) + GAE + advantage-stat all-gather every n_steps"),
                        "drones_per_gpu": n, "total_drones": n * world, "n_steps": T,
-                       "hip_graph": not args.no_graph, "policy": "MlpPolicy pi/vf [128,128] tanh" + ("" if yaw else " (39 049 params)"),
+                       "hip_graph": not args.no_graph, "policy": "MlpPolicy pi/vf [128,128] tanh" + ("" if yaw else " (39 049 params), exact-fp32 MFMA"),
                        "episodes_in_last_rollout": episodes},
             "roofline": roofline,
         }
+        if split_value is not None:
+            out["extra"] = {"value_with_policy_gemm_bf16x6": split_value,
+                            "note": "same workload with the policy's hidden GEMMs on a 6-term bf16 split (fp32-level error, "
+                                    "tests/test_policy_gpu.py); the headline value uses exact-fp32 MFMA"}
         if world == 1 and not args.no_cpu_baseline and not yaw:
             out["cpu_baseline"] = cpu_baseline(n, seed=0)
         print(json.dumps(out), flush=True)

@@ -12,7 +12,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libfpv_env.so")
-SOURCES = ["fpv_step.hip", "fpv_yaw.hip", "fpv_rollout.hip", "fpv_policy.hip", "fpv_capi.hip"]
+SOURCES = ["fpv_step.hip", "fpv_yaw.hip", "fpv_rollout.hip", "fpv_policy.hip", "fpv_policy_split.hip", "fpv_capi.hip"]
 HEADERS = ["fpv_dynamics.h", "fpv_internal.h", os.path.join("..", "..", "include", "fpv_env.h")]
 
 
@@ -36,7 +36,8 @@ def build_extension(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB_PATH
     srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + srcs
+    extra = os.environ.get("FPV_EXTRA_HIPCC_FLAGS", "").split()
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + extra + ["-o", LIB_PATH] + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

@@ -52,7 +52,9 @@ struct fpv_env {
 struct fpv_policy {
     int device;
     int cus;
+    int gemm;               // 0: exact fp32 MFMA, 1: 6-term bf16 split MFMA
     float* image;
+    unsigned char* split_image;
 };
 
 // per-device reduction scratch for the handle-less rollout primitives
@@ -372,7 +374,10 @@ int fpv_policy_create(int32_t device, fpv_policy** out) {
     hipDeviceProp_t prop;
     FPV_HIP(hipGetDeviceProperties(&prop, device));
     p->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    p->gemm = 0;
+    p->split_image = nullptr;
     hipError_t e = hipMalloc((void**)&p->image, sizeof(float) * (size_t)policy_image_floats());
+    if (e == hipSuccess) e = hipMalloc((void**)&p->split_image, (size_t)policy_split_image_bytes());
     if (e != hipSuccess) {
         delete p;
         return fail(FPV_ERR_HIP, "fpv_policy_create: %s", hipGetErrorString(e));
@@ -384,6 +389,7 @@ int fpv_policy_create(int32_t device, fpv_policy** out) {
 int fpv_policy_destroy(fpv_policy* p) {
     if (!p) return FPV_OK;
     if (p->image) (void)hipFree(p->image);
+    if (p->split_image) (void)hipFree(p->split_image);
     delete p;
     return FPV_OK;
 }
@@ -393,6 +399,14 @@ int fpv_policy_load(fpv_policy* p, const float* const* weights, void* stream) {
     for (int i = 0; i < 13; ++i)
         if (!weights[i]) return fail(FPV_ERR_ARG, "fpv_policy_load: weight pointer %d is null", i);
     FPV_HIP(launch_policy_pack(weights, p->image, (hipStream_t)stream));
+    FPV_HIP(launch_policy_split_pack(weights, p->split_image, (hipStream_t)stream));
+    return FPV_OK;
+}
+
+int fpv_policy_set_gemm(fpv_policy* p, int32_t mode) {
+    if (!p) return fail(FPV_ERR_ARG, "fpv_policy_set_gemm: null handle");
+    if (mode != 0 && mode != 1) return fail(FPV_ERR_ARG, "fpv_policy_set_gemm: mode must be 0 (fp32 MFMA) or 1 (bf16 6-term split)");
+    p->gemm = mode;
     return FPV_OK;
 }
 
@@ -402,6 +416,12 @@ int fpv_policy_forward(fpv_policy* p, const fpv_policy_io* io, void* stream) {
     if (((uintptr_t)io->obs | (uintptr_t)io->obs_n | (uintptr_t)io->action | (uintptr_t)io->clipped |
          (uintptr_t)io->eps_in | (uintptr_t)io->eps_out) & 15)
         return fail(FPV_ERR_ARG, "fpv_policy_forward: row buffers must be 16-byte aligned");
+    if (p->gemm == 1) {
+        FPV_HIP(launch_policy_split_forward(p->split_image, io->obs, io->rms, io->eps_in, io->tick, io->obs_n, io->action,
+                                            io->clipped, io->value, io->logp, io->eps_out, io->n, io->seed, io->id_offset,
+                                            io->clip_obs, io->eps_norm, io->deterministic, p->cus, (hipStream_t)stream));
+        return FPV_OK;
+    }
     FPV_HIP(launch_policy_forward(p->image, io->obs, io->rms, io->eps_in, io->tick, io->obs_n, io->action, io->clipped,
                                   io->value, io->logp, io->eps_out, io->n, io->seed, io->id_offset, io->clip_obs,
                                   io->eps_norm, io->deterministic, p->cus, (hipStream_t)stream));

@@ -19,7 +19,7 @@ def _ptr(t):
 
 
 class FusedPolicy:
-    def __init__(self, module: ActorCritic, device=None, seed: int = 0, id_offset: int = 0):
+    def __init__(self, module: ActorCritic, device=None, seed: int = 0, id_offset: int = 0, gemm: str = "f32"):
         if (module.obs_dim, module.act_dim, module.hidden) != (20, 4, 128):
             raise ValueError("the fused kernel is built for obs 20, act 4, hidden 128 (train_hover.py:57)")
         self.module = module
@@ -32,7 +32,16 @@ class FusedPolicy:
         h = C.c_void_p()
         L.check(self.lib.fpv_policy_create(self.device.index or 0, C.byref(h)), "fpv_policy_create")
         self._h = h
+        self.set_gemm(gemm)
         self.load()
+
+    def set_gemm(self, gemm: str) -> None:
+        """'f32': exact fp32 MFMA (default).  'bf16x6': 6-term bf16 split on bf16 MFMA, fp32-level error."""
+        modes = {"f32": 0, "bf16x6": 1}
+        if gemm not in modes:
+            raise ValueError("gemm must be 'f32' or 'bf16x6'")
+        L.check(self.lib.fpv_policy_set_gemm(self._h, modes[gemm]), "fpv_policy_set_gemm")
+        self.gemm = gemm
 
     def _params(self):
         m = self.module

@@ -36,7 +36,8 @@ from .policy import ActorCritic
 class RolloutCollector:
     def __init__(self, engine: FpvEngine, policy: ActorCritic, n_steps: int = 32, gamma: float = 0.99,
                  lam: float = 0.95, norm_obs: bool = True, norm_reward: bool = True, use_graph: bool = True,
-                 clip_obs: float = 10.0, clip_reward: float = 10.0, fused: bool = True, policy_seed: int = 0):
+                 clip_obs: float = 10.0, clip_reward: float = 10.0, fused: bool = True, policy_seed: int = 0,
+                 policy_gemm: str = "f32"):
         if engine.dtype != torch.float32:
             raise ValueError("the rollout collector runs on an fp32 engine")
         self.engine, self.policy = engine, policy
@@ -72,7 +73,7 @@ class RolloutCollector:
         self.snap = torch.zeros((T, max(44, 2 * O + 4)), dtype=torch.float64, device=dev)  # {obs_rms, ret_rms} after step t
         self.fused = bool(fused)
         if self.fused:
-            self.fp = FusedPolicy(policy, seed=policy_seed, id_offset=engine.id_offset)
+            self.fp = FusedPolicy(policy, seed=policy_seed, id_offset=engine.id_offset, gemm=policy_gemm)
             self.partials = torch.zeros((engine.tiles, 44), dtype=torch.float64, device=dev)
             self.raw_rew = torch.zeros((T, N), dtype=f32, device=dev)
         self.stats = torch.zeros((3,), dtype=torch.float64, device=dev)
@@ -151,6 +152,13 @@ class RolloutCollector:
         with torch.cuda.graph(g):
             self._all_steps()
         self._graph = g
+
+    def set_policy_gemm(self, gemm: str) -> None:
+        """'f32' (exact fp32 MFMA) or 'bf16x6' (fp32-faithful 6-term bf16 split); drops the captured graph."""
+        if not self.fused:
+            raise ValueError("policy_gemm applies to the fused path")
+        self.fp.set_gemm(gemm)
+        self._graph = None
 
     def sync_policy(self) -> None:
         """Repack the torch parameters into the fused kernel's weight image (after every optimiser step)."""

@@ -219,6 +219,10 @@ typedef struct {
 } fpv_policy_io;
 
 int fpv_policy_forward(fpv_policy* pol, const fpv_policy_io* io, void* stream);
+/* Hidden-layer GEMM arithmetic: 0 (default) = v_mfma_f32_32x32x2_f32, bit-exact fp32 fma chains; 1 = each fp32
+ * operand cut into three bf16 pieces and the six piece products of order <= 4 summed on v_mfma_f32_32x32x16_bf16
+ * in fp32 accumulators (error at the level of one fp32 rounding, 2.7x fewer matrix-pipe cycles). */
+int fpv_policy_set_gemm(fpv_policy* pol, int32_t mode);
 
 const char* fpv_last_error(void);
 int fpv_version(void);

@@ -9,7 +9,7 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 
-def _setup(seed=0):
+def _setup(seed=0, gemm="f32"):
     from fpv_drone_rl_agent_amd.ops_policy import FusedPolicy
     from fpv_drone_rl_agent_amd.policy import ActorCritic
     torch.manual_seed(seed)
@@ -19,12 +19,13 @@ def _setup(seed=0):
             if p.dim() == 1:
                 p.add_(torch.randn_like(p) * 0.3)
         m.action_net.weight.mul_(30.0)
-    return m, FusedPolicy(m, seed=11)
+    return m, FusedPolicy(m, seed=11, gemm=gemm)
 
 
+@pytest.mark.parametrize("gemm", ["f32", "bf16x6"])
 @pytest.mark.parametrize("n", [1, 31, 256, 5000, 65536])
-def test_fused_forward_matches_torch(n):
-    m, fp = _setup()
+def test_fused_forward_matches_torch(n, gemm):
+    m, fp = _setup(gemm=gemm)
     g = torch.Generator(device="cuda").manual_seed(n)
     obs = torch.randn(n, 20, device="cuda", generator=g) * 3 + 1
     eps = torch.randn(n, 4, device="cuda", generator=g)
@@ -88,3 +89,47 @@ def test_in_kernel_sampling_is_standard_normal_and_keyed():
     tick += 1
     fp.forward(obs, eps_out=eps2, tick=tick)
     assert not torch.equal(eps, eps2)
+
+
+def test_split_gemm_keeps_fp32_accuracy():
+    """Both GEMM modes against an fp64 evaluation of the same network: the 6-term bf16 split must sit at the
+    same error level as the exact-fp32 MFMA path (and as torch's own fp32 forward)."""
+    import copy
+    n = 20000
+    m, fp32k = _setup(5, "f32")
+    _, splitk = _setup(5, "bf16x6")
+    obs = torch.randn(n, 20, device="cuda") * 2
+    m64 = copy.deepcopy(m).double()
+    with torch.no_grad():
+        mu64, v64 = m64.mean_value(obs.double())
+        mu_t, v_t = m.mean_value(obs)
+    errs = {}
+    for name, k in (("f32", fp32k), ("bf16x6", splitk)):
+        a = torch.zeros(n, 4, device="cuda")
+        r = k.forward(obs, action=a, deterministic=True)
+        errs[name] = (float((a.double() - mu64).abs().max()), float((r["value"].double() - v64).abs().max()))
+    errs["torch"] = (float((mu_t.double() - mu64).abs().max()), float((v_t.double() - v64).abs().max()))
+    scale_mu, scale_v = float(mu64.abs().max()), float(v64.abs().max())
+    print(errs, scale_mu, scale_v)
+    for name in ("f32", "bf16x6"):
+        assert errs[name][0] <= 4e-6 * max(1.0, scale_mu) and errs[name][1] <= 4e-6 * max(1.0, scale_v), errs
+    assert errs["bf16x6"][0] <= 3 * errs["f32"][0] + 1e-6 and errs["bf16x6"][1] <= 3 * errs["f32"][1] + 1e-6, errs
+
+
+@pytest.mark.parametrize("gemm", ["f32", "bf16x6"])
+def test_policy_kernel_repeated_launches_every_row(gemm):
+    """Many launches at the bench size with every row checked (a timing-dependent fault would show up here)."""
+    import copy
+    m, k = _setup(7, gemm)
+    m64 = copy.deepcopy(m).double()
+    n = 65536
+    for trial in range(25):
+        torch.manual_seed(trial)
+        obs = torch.randn(n, 20, device="cuda") * 2
+        with torch.no_grad():
+            mu64, v64 = m64.mean_value(obs.double())
+        a = torch.zeros(n, 4, device="cuda")
+        r = k.forward(obs, action=a, deterministic=True)
+        scale = float(mu64.abs().max())
+        assert float((a.double() - mu64).abs().max()) <= 4e-6 * max(1.0, scale), trial
+        assert float((r["value"].double() - v64).abs().max()) <= 1e-5, trial
