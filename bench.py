@@ -29,6 +29,8 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_STEP = 382  # 35 words r+w, 16 B action, 80 B obs, 4 B reward, 2 B flags
 HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA (= vector fp32) peak
+POLICY_FLOP_PER_ROW = 2 * (2 * (20 * 128 + 128 * 128) + 128 * 4 + 128)  # 77 056: both MLPs + heads
 
 
 def synthetic_states(n: int, seed: int):
@@ -79,6 +81,7 @@ def main() -> None:
     import torch
     import torch.distributed as td
     from fpv_drone_rl_agent_amd import dist as D
+    from fpv_drone_rl_agent_amd import ops
     from fpv_drone_rl_agent_amd.engine import FpvEngine
     from fpv_drone_rl_agent_amd.policy import ActorCritic
     from fpv_drone_rl_agent_amd.rollout import RolloutCollector
@@ -147,36 +150,100 @@ def main() -> None:
         split_value = n * world * K / el2
         col.set_policy_gemm("f32")
 
-    # ---- roofline of the dominant kernel: kernel-only pass, HIP events on the launch stream ----
-    roofline = None
+    # ---- rooflines: kernel-only passes in this process, HIP events on the launch stream (events cannot bracket a
+    # node inside the replayed graph).  `roofline` is the kernel that dominates the timed region by time (the fused
+    # actor-critic forward, MFMA-bound); `roofline_env_step` is the HBM-bound dynamics kernel BASELINE's "% HBM
+    # roofline" refers to, as it runs in the rollout (with the VecNormalize bookkeeping fused in) and stand-alone.
+    roofline = roofline_env = roofline_env_plain = None
     if rank == 0:
         L = args.kernel_launches
         act = torch.rand((n, eng.act_words), device=dev) * 2 - 1
-        for _ in range(20):
-            eng.step(act)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize(dev)
-        e0.record()
-        for _ in range(L):
-            eng.step(act)
-        e1.record()
-        torch.cuda.synchronize(dev)
-        us = e0.elapsed_time(e1) * 1e3 / L
-        alg_bytes = 458 if yaw else ALG_BYTES_PER_STEP   # yaw: 44 words r+w, 4 B action, 48 B obs, 4 B reward, 2 B flags
-        achieved = alg_bytes * n / us / 1e3  # GB/s
-        # HBM bytes per launch from the PMC passes recorded under profiles/ (cannot be collected from inside
-        # the process); only reported when it was measured for this drone count
-        traffic = None
-        try:
-            rec = json.load(open(os.path.join(ROOT, "profiles", "step_kernel_traffic.json")))
-            if int(rec["drones"]) == n and not yaw:
-                traffic = int(rec["hbm_bytes_per_launch"])
-        except (OSError, ValueError, KeyError):
-            pass
-        roofline = {"bound": "hbm", "kernel": "fpv::yaw_step_kernel<float,true>" if yaw else "fpv::step_kernel<float,true>", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                    "traffic": traffic, "us_per_launch": round(us, 2), "launches": L,
-                    "algorithmic_bytes_per_launch": alg_bytes * n}
+
+        def timed(fn):
+            for _ in range(20):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize(dev)
+            e0.record()
+            for _ in range(L):
+                fn()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            return e0.elapsed_time(e1) * 1e3 / L
+
+        def traffic_of(kernel):
+            # HBM bytes per launch from the PMC passes recorded under profiles/ (not collectable in-process)
+            try:
+                rec = json.load(open(os.path.join(ROOT, "profiles", "kernel_traffic.json")))
+                if int(rec["drones"]) == n and kernel in rec["kernels"]:
+                    return int(rec["kernels"][kernel]["hbm_bytes_per_launch"])
+            except (OSError, ValueError, KeyError):
+                pass
+            return None
+
+        def hbm(kernel, us, alg_bytes):
+            achieved = alg_bytes * n / us / 1e3
+            return {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic_of(kernel), "us_per_launch": round(us, 2),
+                    "launches": L, "algorithmic_bytes_per_launch": alg_bytes * n}
+
+        def graph_kernel_times(rollouts=4):
+            """Average device-side duration of every kernel inside the replayed rollout graph — the timed region's own
+            launches — from the HIP activity tracer (torch.profiler / roctracer timestamps).  HIP events cannot bracket a
+            node inside a replayed graph; {} if the tracer is unavailable (e.g. another profiler owns it)."""
+            under_profiler = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or \
+                "rocprof" in os.environ.get("LD_PRELOAD", "")
+            if under_profiler:       # rocprofv3 owns the activity tracer: its own trace is the measurement then
+                return {}
+            try:
+                from torch.profiler import ProfilerActivity, profile
+                with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                    for _ in range(rollouts):
+                        col.collect()
+                    torch.cuda.synchronize(dev)
+                acc = {}
+                for e in prof.events():
+                    if e.device_type == torch.autograd.DeviceType.CUDA:
+                        acc.setdefault(e.name, []).append(getattr(e, "device_time", None) or e.cuda_time)
+                return {k: sum(v) / len(v) for k, v in acc.items()}
+            except Exception:
+                return {}
+
+        def pick(times, needle):
+            for k, v in times.items():
+                if needle in k.replace(", ", ","):
+                    return float(v)
+            return None
+
+        if yaw:
+            us = timed(lambda: eng.step(act))
+            roofline = hbm("fpv::yaw_step_kernel<float,true>", us, 458)   # 44 words r+w, 4 B action, 48 B obs, 4 B reward, 2 B flags
+        else:
+            us_plain = timed(lambda: eng.step(act))
+            roofline_env_plain = hbm("fpv::step_kernel<float,true,false>", us_plain, ALG_BYTES_PER_STEP)
+            if col.fused:
+                io = dict(rms=col.obs_norm.rms, tick=eng.tick_ptr, obs_n=col.buf_obs[0], action=col.buf_act[0],
+                          clipped=col.clipped, value=col.buf_val[0], logp=col.buf_logp[0])
+                ev_pol = timed(lambda: col.fp.forward(eng.obs, **io))
+                ev_fused = timed(lambda: eng.step_fused(col.clipped, done=col._starts[1], ret=col.rew_norm.ret,
+                                                        partials=col.partials, gamma=col.gamma, reward=col.raw_rew[0]))
+                in_graph = graph_kernel_times()
+                us_pol = pick(in_graph, "policy_forward_kernel") or ev_pol
+                us_fused = pick(in_graph, "step_kernel<float,true,true>") or ev_fused
+                if not (0.6 * ev_pol < us_pol < 1.6 * ev_pol and 0.6 * ev_fused < us_fused < 1.6 * ev_fused):
+                    in_graph, us_pol, us_fused = {}, ev_pol, ev_fused     # tracer output implausible: trust the events
+                how = "device timestamps of the launches inside the replayed rollout graph" if in_graph else \
+                      "HIP events around back-to-back launches"
+                roofline_env = hbm("fpv::step_kernel<float,true,true>", us_fused, ALG_BYTES_PER_STEP)
+                roofline_env.update(measured=how, us_per_launch_hip_events_back_to_back=round(ev_fused, 2))
+                tf = POLICY_FLOP_PER_ROW * n / us_pol / 1e6
+                roofline = {"bound": "mfma", "kernel": "fpv::policy_forward_kernel", "achieved": round(tf, 1),
+                            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                            "traffic": traffic_of("fpv::policy_forward_kernel"), "us_per_launch": round(us_pol, 2),
+                            "launches": L, "algorithmic_flop_per_launch": POLICY_FLOP_PER_ROW * n, "dtype": "f32",
+                            "measured": how, "us_per_launch_hip_events_back_to_back": round(ev_pol, 2)}
+            else:
+                roofline = roofline_env_plain
 
     if rank == 0:
         out = {
@@ -194,6 +261,9 @@ def main() -> None:
                        "episodes_in_last_rollout": episodes},
             "roofline": roofline,
         }
+        if roofline_env is not None:
+            out["roofline_env_step"] = roofline_env
+            out["roofline_env_step_unfused"] = roofline_env_plain
         if split_value is not None:
             out["extra"] = {"value_with_policy_gemm_bf16x6": split_value,
                             "note": "same workload with the policy's hidden GEMMs on a 6-term bf16 split (fp32-level error, "

@@ -102,7 +102,15 @@ static int step_impl(fpv_env* e, const T* actions, T* obs, T* reward, uint8_t* t
     return FPV_OK;
 }
 
+__global__ void fpv_noop_kernel() {}
+
 extern "C" {
+
+int fpv_noop(void* stream) {
+    hipLaunchKernelGGL(fpv_noop_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream);
+    FPV_HIP(hipGetLastError());
+    return FPV_OK;
+}
 
 const char* fpv_last_error(void) { return g_err; }
 int fpv_version(void) { return 1; }

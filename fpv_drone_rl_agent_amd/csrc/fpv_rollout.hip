@@ -247,16 +247,19 @@ __global__ __launch_bounds__(1024) void tile_partials_merge_kernel(const double*
     __shared__ double l[kTileMergeWays][64];
     const int j = threadIdx.x / kPartialWords, c = threadIdx.x % kPartialWords;
     if (j < kTileMergeWays) {
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        int b = j;
-        for (; b + 3 * kTileMergeWays < nrows; b += 4 * kTileMergeWays) {
-            a0 += rows[(int64_t)b * kPartialWords + c];
-            a1 += rows[(int64_t)(b + kTileMergeWays) * kPartialWords + c];
-            a2 += rows[(int64_t)(b + 2 * kTileMergeWays) * kPartialWords + c];
-            a3 += rows[(int64_t)(b + 3 * kTileMergeWays) * kPartialWords + c];
+        // nrows <= 1024 (more tiles go through stage 1): every load of this thread is requested before the first
+        // add, so the whole table costs one memory round trip; the adds then run in row order
+        constexpr int kIter = (1024 + kTileMergeWays - 1) / kTileMergeWays;   // 45
+        double v[kIter];
+#pragma unroll
+        for (int q = 0; q < kIter; ++q) {
+            const int b = j + q * kTileMergeWays;
+            v[q] = b < nrows ? rows[(int64_t)b * kPartialWords + c] : 0.0;
         }
-        for (; b < nrows; b += kTileMergeWays) a0 += rows[(int64_t)b * kPartialWords + c];
-        l[j][c] = (a0 + a1) + (a2 + a3);
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < kIter; ++q) acc += v[q];
+        l[j][c] = acc;
     }
     const double obs_count = obs_rms ? obs_rms[40] : 0.0, ret_count = ret_rms ? ret_rms[2] : 0.0;
     __syncthreads();

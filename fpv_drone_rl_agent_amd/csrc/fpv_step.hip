@@ -61,7 +61,8 @@ __device__ __forceinline__ void drone_from_template(Drone<T>& d, T tv) {
 // ---------------------------------------------------------------- K1
 template <typename T, bool NOISE, bool FUSED>
 __global__ __launch_bounds__(kTile) void step_kernel(StepArgs<T> p) {
-    __shared__ Vec4<T> lds[kTile * kObsWords / 4 + (FUSED ? kTile / 4 : 0)];
+    // observation tile; fused variant: + 64 returns + a 64 x 2 fp64 exchange area (fp32 handles only)
+    __shared__ Vec4<T> lds[kTile * kObsWords / 4 + (FUSED ? kTile / 4 + kTile : 0)];
     const int lane = threadIdx.x;
     const int64_t tile = blockIdx.x;
     const int64_t i = tile * kTile + lane;
@@ -75,6 +76,10 @@ __global__ __launch_bounds__(kTile) void step_kernel(StepArgs<T> p) {
     const uint64_t agent_tick = p.tick[tile];
     const uint32_t led_fill = p.led_count[tile];
     const T tmpl_lane = p.tmpl[lane < kStateWords + kObsWords ? lane : 0];
+    T ret_in = T(0);   // VecNormalize's discounted return: requested with the state so its latency hides under the physics
+    if constexpr (FUSED) {
+        if (p.ret && live) ret_in = p.ret[i];
+    }
     const uint32_t gid = (uint32_t)(p.id_offset + (uint64_t)i);
 
     // hover.py:337-341 action scaling; the mode-0 thrust setpoint is clipped to [0,1] (SPEC §4.1)
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(kTile) void step_kernel(StepArgs<T> p) {
         if (live && p.done) p.done[i] = done ? 1 : 0;
         T ret = T(0);
         if (p.ret) {
-            ret = live ? p.ret[i] * (T)p.gamma + reward : T(0);
+            ret = live ? ret_in * (T)p.gamma + reward : T(0);
             if (live) p.ret[i] = done ? T(0) : ret;
         }
         lds_w[kTile * kObsWords + lane] = ret;
@@ -180,18 +185,19 @@ __global__ __launch_bounds__(kTile) void step_kernel(StepArgs<T> p) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q) { const double d = (double)v[q]; s1 += d; s2 += d * d; }
             }
-            // fold the row groups in a fixed order: lanes c, c+20, c+40 -> lane c ; lanes 60..63 -> lane 60
-            const double a1 = __shfl(s1, lane + kObsWords), a2 = __shfl(s1, lane + 2 * kObsWords);
-            const double b1 = __shfl(s2, lane + kObsWords), b2 = __shfl(s2, lane + 2 * kObsWords);
-            const double r1 = __shfl(s1, 61), r2 = __shfl(s1, 62), r3 = __shfl(s1, 63);
-            const double q1 = __shfl(s2, 61), q2 = __shfl(s2, 62), q3 = __shfl(s2, 63);
+            // fold the row groups in a fixed order through a small LDS exchange (cheaper than twelve 64-bit
+            // cross-lane shuffles): lanes c, c+20, c+40 -> lane c ; lanes 60..63 -> lane 60
+            double* xch = reinterpret_cast<double*>(lds_w + kTile * kObsWords + kTile);
+            xch[2 * lane] = s1;
+            xch[2 * lane + 1] = s2;
+            __syncthreads();
             double* row = p.partials + tile * kPartialWords;
             if (lane < kObsWords) {
-                row[lane] = (s1 + a1) + a2;
-                row[kObsWords + lane] = (s2 + b1) + b2;
+                row[lane] = (xch[2 * lane] + xch[2 * (lane + kObsWords)]) + xch[2 * (lane + 2 * kObsWords)];
+                row[kObsWords + lane] = (xch[2 * lane + 1] + xch[2 * (lane + kObsWords) + 1]) + xch[2 * (lane + 2 * kObsWords) + 1];
             } else if (lane == 60) {
-                row[2 * kObsWords] = (s1 + r1) + (r2 + r3);
-                row[2 * kObsWords + 1] = (s2 + q1) + (q2 + q3);
+                row[2 * kObsWords] = (xch[120] + xch[122]) + (xch[124] + xch[126]);
+                row[2 * kObsWords + 1] = (xch[121] + xch[123]) + (xch[125] + xch[127]);
                 row[2 * kObsWords + 2] = 0.0;
                 row[2 * kObsWords + 3] = 0.0;
             }

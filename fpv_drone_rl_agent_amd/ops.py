@@ -125,3 +125,8 @@ def reward_finalize(raw, snapshots, clip=10.0, eps=1e-8, out=None):
     L.check(L.load().fpv_reward_finalize(T, n, _ptr(raw), _ptr(snapshots), float(clip), float(eps), _ptr(out),
                                          _stream(raw.device)), "fpv_reward_finalize")
     return out
+
+
+def noop(device) -> None:
+    """Empty kernel through the library's launch path (timing calibration)."""
+    L.check(L.load().fpv_noop(_stream(torch.device(device))), "fpv_noop")

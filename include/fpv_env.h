@@ -224,6 +224,9 @@ int fpv_policy_forward(fpv_policy* pol, const fpv_policy_io* io, void* stream);
  * in fp32 accumulators (error at the level of one fp32 rounding, 2.7x fewer matrix-pipe cycles). */
 int fpv_policy_set_gemm(fpv_policy* pol, int32_t mode);
 
+/* Launches an empty kernel on `stream`: the floor of this library's launch path, for calibrating event timings. */
+int fpv_noop(void* stream);
+
 const char* fpv_last_error(void);
 int fpv_version(void);
 
