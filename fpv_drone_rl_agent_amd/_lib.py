@@ -45,7 +45,8 @@ class FpvPolicyIo(C.Structure):
         ("n", C.c_int64), ("obs", C.c_void_p), ("rms", C.c_void_p), ("eps_in", C.c_void_p), ("tick", C.c_void_p),
         ("obs_n", C.c_void_p), ("action", C.c_void_p), ("clipped", C.c_void_p), ("value", C.c_void_p),
         ("logp", C.c_void_p), ("eps_out", C.c_void_p), ("seed", C.c_uint64), ("id_offset", C.c_uint64),
-        ("clip_obs", C.c_float), ("eps_norm", C.c_float), ("deterministic", C.c_int32), ("reserved", C.c_int32),
+        ("clip_obs", C.c_float), ("eps_norm", C.c_float), ("deterministic", C.c_int32), ("nets", C.c_int32),
+        ("narrow", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

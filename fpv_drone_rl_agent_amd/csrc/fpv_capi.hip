@@ -420,11 +420,15 @@ int fpv_policy_set_gemm(fpv_policy* p, int32_t mode) {
 
 int fpv_policy_forward(fpv_policy* p, const fpv_policy_io* io, void* stream) {
     if (!p || !io) return fail(FPV_ERR_ARG, "fpv_policy_forward: null argument");
-    if (io->n <= 0 || !io->obs || !io->value) return fail(FPV_ERR_ARG, "fpv_policy_forward: n, obs and value are required");
+    const int nets = io->nets == 0 ? 3 : io->nets;
+    if (nets < 1 || nets > 3) return fail(FPV_ERR_ARG, "fpv_policy_forward: nets must be 0..3");
+    if (io->n <= 0 || !io->obs || ((nets & 2) && !io->value))
+        return fail(FPV_ERR_ARG, "fpv_policy_forward: n, obs and (when V is evaluated) value are required");
     if (((uintptr_t)io->obs | (uintptr_t)io->obs_n | (uintptr_t)io->action | (uintptr_t)io->clipped |
          (uintptr_t)io->eps_in | (uintptr_t)io->eps_out) & 15)
         return fail(FPV_ERR_ARG, "fpv_policy_forward: row buffers must be 16-byte aligned");
     if (p->gemm == 1) {
+        if (nets != 3 || io->narrow) return fail(FPV_ERR_UNSUPPORTED, "fpv_policy_forward: the bf16-split kernel evaluates both nets in 512-thread workgroups");
         FPV_HIP(launch_policy_split_forward(p->split_image, io->obs, io->rms, io->eps_in, io->tick, io->obs_n, io->action,
                                             io->clipped, io->value, io->logp, io->eps_out, io->n, io->seed, io->id_offset,
                                             io->clip_obs, io->eps_norm, io->deterministic, p->cus, (hipStream_t)stream));
@@ -432,7 +436,7 @@ int fpv_policy_forward(fpv_policy* p, const fpv_policy_io* io, void* stream) {
     }
     FPV_HIP(launch_policy_forward(p->image, io->obs, io->rms, io->eps_in, io->tick, io->obs_n, io->action, io->clipped,
                                   io->value, io->logp, io->eps_out, io->n, io->seed, io->id_offset, io->clip_obs,
-                                  io->eps_norm, io->deterministic, p->cus, (hipStream_t)stream));
+                                  io->eps_norm, io->deterministic, p->cus, nets, io->narrow ? 1 : 0, (hipStream_t)stream));
     return FPV_OK;
 }
 

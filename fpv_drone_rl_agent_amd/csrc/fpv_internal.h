@@ -81,7 +81,8 @@ hipError_t launch_policy_pack(const float* const* w, float* image, hipStream_t s
 hipError_t launch_policy_forward(const float* image, const float* obs, const double* rms, const float* eps_in,
                                  const uint64_t* tick, float* obs_n, float* action, float* clipped, float* value,
                                  float* logp, float* eps_out, int64_t n, uint64_t seed, uint64_t id_offset,
-                                 float clip_obs, float eps_norm, int deterministic, int max_blocks, hipStream_t s);
+                                 float clip_obs, float eps_norm, int deterministic, int max_blocks, int nets, int narrow,
+                                 hipStream_t s);
 int policy_image_floats();
 // fpv_policy_split.hip
 hipError_t launch_policy_split_pack(const float* const* w, unsigned char* image, hipStream_t s);

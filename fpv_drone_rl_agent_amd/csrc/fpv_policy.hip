@@ -25,9 +25,7 @@ constexpr int kHeadBase = 2 * kNetFloats;                                   // 3
 constexpr int kOffWa = kHeadBase, kOffWv = kHeadBase + 512, kOffBa = kHeadBase + 640, kOffBv = kHeadBase + 644,
               kOffLogStd = kHeadBase + 648, kOffStd = kHeadBase + 652, kOffLogpConst = kHeadBase + 656;
 constexpr int kImageFloats = kHeadBase + 660;                               // packed image
-constexpr int kOffMean = kImageFloats, kOffInv = kImageFloats + 20;
-constexpr int kLdsFloats = kImageFloats + 40;                               // 40124 floats = 160 496 B
-constexpr int kPolicyThreads = 512;
+// LDS: the staged nets, then the 660 head floats, then the normaliser mean[20] / inv_std[20] (160 496 B for both nets)
 
 __host__ __device__ constexpr int tile_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -141,31 +139,37 @@ __device__ __forceinline__ void tanh_all(Hidden& a) {
         for (int r = 0; r < 16; ++r) a.t[m][r] = fast_tanh(a.t[m][r]);
 }
 
-__global__ __launch_bounds__(kPolicyThreads) void policy_forward_kernel(PolicyArgs p) {
+// THREADS = 512: two waves per SIMD (the stand-alone shape).  THREADS = 256: one wave per SIMD and <= 256 VGPRs of
+// the 512-entry file, which leaves room for the VALU-bound env-step waves to co-reside: the critic pass is run that
+// way on a second stream beside fpv_step (matrix pipe and vector pipe are separate on CDNA4).
+// Nets [net_first, net_first + net_count) of {0: pi, 1: V} are evaluated; only their images are staged into LDS.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void policy_forward_kernel(PolicyArgs p, int net_first, int net_count) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // ---- stage the weight image (L2-resident after the first workgroups) and the normaliser
+    float* hb = lds + net_count * kNetFloats;        // heads [660], then normaliser mean[20], inv[20]
+    // ---- stage the weight image (L2-resident after the first workgroups) and the normaliser: every granule of a
+    // thread is requested before the first one is written to LDS, so the block pays one L2 round trip
     {
-        // all of a thread's 20 image granules are requested before the first one is written to LDS, so the
-        // block pays one L2 round trip for the 160 KB image, not twenty
-        const f32x4* src = reinterpret_cast<const f32x4*>(p.image);
+        const f32x4* src = reinterpret_cast<const f32x4*>(p.image + (size_t)net_first * kNetFloats);
         f32x4* dst = reinterpret_cast<f32x4*>(lds);
-        constexpr int kGranules = kImageFloats / 4, kPer = (kGranules + kPolicyThreads - 1) / kPolicyThreads;
-        f32x4 stage[kPer];
+        constexpr int kNetGran = kNetFloats / 4, kPer = (kNetGran + THREADS - 1) / THREADS;
+        for (int sl = 0; sl < net_count; ++sl) {
+            f32x4 stage[kPer];
 #pragma unroll
-        for (int q = 0; q < kPer; ++q) {
-            const int g = q * kPolicyThreads + threadIdx.x;
-            stage[q] = src[g < kGranules ? g : 0];
-        }
+            for (int q = 0; q < kPer; ++q) {
+                const int g = q * THREADS + threadIdx.x;
+                stage[q] = src[sl * kNetGran + (g < kNetGran ? g : 0)];
+            }
 #pragma unroll
-        for (int q = 0; q < kPer; ++q) {
-            const int g = q * kPolicyThreads + threadIdx.x;
-            if (g < kGranules) dst[g] = stage[q];
+            for (int q = 0; q < kPer; ++q) {
+                const int g = q * THREADS + threadIdx.x;
+                if (g < kNetGran) dst[sl * kNetGran + g] = stage[q];
+            }
         }
+        for (int q = threadIdx.x; q < kImageFloats - kHeadBase; q += THREADS) hb[q] = p.image[kHeadBase + q];
         if (threadIdx.x < kIn) {
-            const float mu = p.rms ? (float)p.rms[threadIdx.x] : 0.0f;
-            const float iv = p.rms ? (float)(1.0 / sqrt(p.rms[kIn + threadIdx.x] + (double)p.eps_norm)) : 1.0f;
-            lds[kOffMean + threadIdx.x] = mu;
-            lds[kOffInv + threadIdx.x] = iv;
+            hb[660 + threadIdx.x] = p.rms ? (float)p.rms[threadIdx.x] : 0.0f;
+            hb[680 + threadIdx.x] = p.rms ? (float)(1.0 / sqrt(p.rms[kIn + threadIdx.x] + (double)p.eps_norm)) : 1.0f;
         }
     }
     __syncthreads();
@@ -173,8 +177,10 @@ __global__ __launch_bounds__(kPolicyThreads) void policy_forward_kernel(PolicyAr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 31, h = lane >> 5;
     const float clip = p.rms ? p.clip_obs : 3.0e38f;
+    const bool do_pi = net_first == 0, do_v = net_first + net_count == 2;
+    constexpr int kChunk = THREADS / 2;              // 32 drones per wave
 
-    for (int64_t base = (int64_t)blockIdx.x * 256; base < p.n; base += (int64_t)gridDim.x * 256) {
+    for (int64_t base = (int64_t)blockIdx.x * kChunk; base < p.n; base += (int64_t)gridDim.x * kChunk) {
         const int64_t d = base + wave * 32 + col;   // this lane's drone (both halves of the wave share it)
         const bool live = d < p.n;
         // ---- observation: half 0 holds k = 0..11, half 1 holds k = 12..23 (20..23 are zero padding)
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(kPolicyThreads) void policy_forward_kernel(PolicyAr
 #pragma unroll
             for (int j = 0; j < 12; ++j) {
                 const int k = 12 * h + j;
-                if (k < kIn) x[j] = fminf(fmaxf((x[j] - lds[kOffMean + k]) * lds[kOffInv + k], -clip), clip);
+                if (k < kIn) x[j] = fminf(fmaxf((x[j] - hb[660 + k]) * hb[680 + k], -clip), clip);
             }
             if (p.obs_n && live) {
                 f32x4* out = reinterpret_cast<f32x4*>(p.obs_n + d * kIn);
@@ -202,8 +208,9 @@ __global__ __launch_bounds__(kPolicyThreads) void policy_forward_kernel(PolicyAr
 
         float head[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // 4 action means + value (partial sums of this lane half)
 #pragma unroll 1
-        for (int net = 0; net < 2; ++net) {
-            const float* nb = lds + net * kNetFloats;
+        for (int sl = 0; sl < net_count; ++sl) {
+            const int net = net_first + sl;
+            const float* nb = lds + sl * kNetFloats;
             // ---- layer 1: 20 (padded 24) -> 128
             Hidden a;
             bias_init(a, nb + kOffB1, h);
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(kPolicyThreads) void policy_forward_kernel(PolicyAr
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const f32x4 w = *reinterpret_cast<const f32x4*>(lds + kOffWa + (((h * 4 + kt) * 16 + r) * 4));
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(hb + (((h * 4 + kt) * 16 + r) * 4));
                         const float v = c.t[kt][r];
                         head[0] += w.x * v; head[1] += w.y * v; head[2] += w.z * v; head[3] += w.w * v;
                     }
@@ -245,15 +252,15 @@ __global__ __launch_bounds__(kPolicyThreads) void policy_forward_kernel(PolicyAr
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) head[4] += lds[kOffWv + (h * 4 + kt) * 16 + r] * c.t[kt][r];
+                    for (int r = 0; r < 16; ++r) head[4] += hb[512 + (h * 4 + kt) * 16 + r] * c.t[kt][r];
             }
         }
         // ---- combine the two lane halves, add biases
 #pragma unroll
         for (int j = 0; j < 5; ++j) head[j] += __shfl_xor(head[j], 32);
-        const float mu[4] = {head[0] + lds[kOffBa], head[1] + lds[kOffBa + 1], head[2] + lds[kOffBa + 2],
-                             head[3] + lds[kOffBa + 3]};
-        const float value = head[4] + lds[kOffBv];
+        if (do_v && live && h == 1) p.value[d] = head[4] + hb[644];
+        if (!do_pi) continue;
+        const float mu[4] = {head[0] + hb[640], head[1] + hb[641], head[2] + hb[642], head[3] + hb[643]};
 
         // ---- sample: eps from memory, or Philox4x32-10 keyed like the env noise (stream tag 'POL1')
         float eps[4] = {0.f, 0.f, 0.f, 0.f};
@@ -274,10 +281,10 @@ __global__ __launch_bounds__(kPolicyThreads) void policy_forward_kernel(PolicyAr
                 eps[2] = rb * __builtin_amdgcn_cosf(u3); eps[3] = rb * __builtin_amdgcn_sinf(u3);
             }
         }
-        float act[4], lp = lds[kOffLogpConst];
+        float act[4], lp = hb[656];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            act[j] = mu[j] + lds[kOffStd + j] * eps[j];
+            act[j] = mu[j] + hb[652 + j] * eps[j];
             lp -= 0.5f * eps[j] * eps[j];
         }
         if (live) {
@@ -288,7 +295,6 @@ __global__ __launch_bounds__(kPolicyThreads) void policy_forward_kernel(PolicyAr
                         f32x4{fminf(fmaxf(act[0], -1.f), 1.f), fminf(fmaxf(act[1], -1.f), 1.f),
                               fminf(fmaxf(act[2], -1.f), 1.f), fminf(fmaxf(act[3], -1.f), 1.f)};
             } else {
-                p.value[d] = value;
                 if (p.logp) p.logp[d] = lp;
                 if (p.eps_out) reinterpret_cast<f32x4*>(p.eps_out)[d] = f32x4{eps[0], eps[1], eps[2], eps[3]};
             }
@@ -307,20 +313,30 @@ hipError_t launch_policy_pack(const float* const* w /* 13 device pointers in Pol
 hipError_t launch_policy_forward(const float* image, const float* obs, const double* rms, const float* eps_in,
                                  const uint64_t* tick, float* obs_n, float* action, float* clipped, float* value,
                                  float* logp, float* eps_out, int64_t n, uint64_t seed, uint64_t id_offset,
-                                 float clip_obs, float eps_norm, int deterministic, int max_blocks, hipStream_t s) {
+                                 float clip_obs, float eps_norm, int deterministic, int max_blocks, int nets, int narrow,
+                                 hipStream_t s) {
+    // nets: 3 = pi + V (one launch), 1 = pi only (with the sampling epilogue), 2 = V only.
+    // narrow: 256-thread workgroups (one wave per SIMD) so that other kernels can co-reside.
     static bool attr_set = false;
-    const size_t lds_bytes = (size_t)kLdsFloats * sizeof(float);
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)policy_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds_bytes);
+        const int full = (int)((2 * kNetFloats + (kImageFloats - kHeadBase) + 40) * sizeof(float));
+        hipError_t e = hipFuncSetAttribute((const void*)policy_forward_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, full);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)policy_forward_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, full);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    const int net_first = nets == 2 ? 1 : 0, net_count = nets == 3 ? 2 : 1;
+    const size_t lds_bytes = (size_t)(net_count * kNetFloats + (kImageFloats - kHeadBase) + 40) * sizeof(float);
     PolicyArgs p{image, obs, rms, eps_in, tick, obs_n, action, clipped, value, logp, eps_out,
                  n, seed, id_offset, clip_obs, eps_norm, deterministic};
-    int64_t blocks = (n + 255) / 256;
+    const int threads = narrow ? 256 : 512, chunk = threads / 2;
+    int64_t blocks = (n + chunk - 1) / chunk;
     if (blocks > max_blocks) blocks = max_blocks;
-    hipLaunchKernelGGL(policy_forward_kernel, dim3((unsigned)blocks), dim3(kPolicyThreads), lds_bytes, s, p);
+    if (narrow)
+        hipLaunchKernelGGL(policy_forward_kernel<256>, dim3((unsigned)blocks), dim3(256), lds_bytes, s, p, net_first, net_count);
+    else
+        hipLaunchKernelGGL(policy_forward_kernel<512>, dim3((unsigned)blocks), dim3(512), lds_bytes, s, p, net_first, net_count);
     return hipGetLastError();
 }
 

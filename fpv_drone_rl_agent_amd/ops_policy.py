@@ -61,17 +61,19 @@ class FusedPolicy:
                 "fpv_policy_load")
 
     def forward(self, obs, *, rms=None, eps_in=None, tick=None, obs_n=None, action=None, clipped=None, value=None,
-                logp=None, eps_out=None, clip_obs: float = 10.0, eps_norm: float = 1e-8, deterministic: bool = False):
+                logp=None, eps_out=None, clip_obs: float = 10.0, eps_norm: float = 1e-8, deterministic: bool = False,
+                nets: str = "both", narrow: bool = False):
         """obs [n,20] fp32 raw observations; rms = fp64[41] VecNormalize statistics or None.  Output tensors
         are written in place when given; value is always produced.  Returns dict of the outputs."""
         n = obs.shape[0]
         if obs.dtype != torch.float32 or not obs.is_contiguous() or obs.shape[1] != 20:
             raise ValueError("obs must be a contiguous [n,20] fp32 device tensor")
-        if value is None:
+        mask = {"both": 3, "pi": 1, "v": 2}[nets]
+        if value is None and mask & 2:
             value = torch.empty((n,), dtype=torch.float32, device=obs.device)
         io = L.FpvPolicyIo(n, _ptr(obs), _ptr(rms), _ptr(eps_in), _ptr(tick), _ptr(obs_n), _ptr(action), _ptr(clipped),
                            _ptr(value), _ptr(logp), _ptr(eps_out), self.seed, self.id_offset, float(clip_obs),
-                           float(eps_norm), 1 if deterministic else 0, 0)
+                           float(eps_norm), 1 if deterministic else 0, mask, 1 if narrow else 0, 0)
         L.check(self.lib.fpv_policy_forward(self._h, C.byref(io),
                                             C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)),
                 "fpv_policy_forward")

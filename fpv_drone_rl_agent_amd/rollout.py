@@ -37,7 +37,7 @@ class RolloutCollector:
     def __init__(self, engine: FpvEngine, policy: ActorCritic, n_steps: int = 32, gamma: float = 0.99,
                  lam: float = 0.95, norm_obs: bool = True, norm_reward: bool = True, use_graph: bool = True,
                  clip_obs: float = 10.0, clip_reward: float = 10.0, fused: bool = True, policy_seed: int = 0,
-                 policy_gemm: str = "f32"):
+                 policy_gemm: str = "f32", overlap_critic: bool = False):
         if engine.dtype != torch.float32:
             raise ValueError("the rollout collector runs on an fp32 engine")
         self.engine, self.policy = engine, policy
@@ -76,6 +76,12 @@ class RolloutCollector:
             self.fp = FusedPolicy(policy, seed=policy_seed, id_offset=engine.id_offset, gemm=policy_gemm)
             self.partials = torch.zeros((engine.tiles, 44), dtype=torch.float64, device=dev)
             self.raw_rew = torch.zeros((T, N), dtype=f32, device=dev)
+            # overlap_critic: the env step needs pi only, so the critic pass (MFMA-bound) can run on a second stream
+            # beside the env-step kernel (VALU-bound).  Measured on MI355X (profiles/r01_overlap_experiment.txt): alone
+            # V takes 32 us and the env step 17 us, co-resident 59 us and 41-52 us — the two kernels fight over VALU
+            # issue slots and the instruction cache — so the serial schedule is faster and this stays off by default.
+            self.overlap_critic = bool(overlap_critic) and policy_gemm == "f32"
+            self._vstream = torch.cuda.Stream(dev) if self.overlap_critic else None
         self.stats = torch.zeros((3,), dtype=torch.float64, device=dev)
         self._graph = None
         self._tick0 = 0
@@ -98,9 +104,19 @@ class RolloutCollector:
 
     def _step_fused(self, t: int) -> None:
         eng = self.engine
-        self.fp.forward(eng.obs, rms=self.obs_norm.rms if self.norm_obs else None, tick=eng.tick_ptr,
-                        obs_n=self.buf_obs[t], action=self.buf_act[t], clipped=self.clipped, value=self.buf_val[t],
-                        logp=self.buf_logp[t], clip_obs=self.obs_norm.clip, eps_norm=self.obs_norm.eps)
+        rms = self.obs_norm.rms if self.norm_obs else None
+        if self.overlap_critic:
+            self.fp.forward(eng.obs, rms=rms, tick=eng.tick_ptr, obs_n=self.buf_obs[t], action=self.buf_act[t],
+                            clipped=self.clipped, logp=self.buf_logp[t], clip_obs=self.obs_norm.clip,
+                            eps_norm=self.obs_norm.eps, nets="pi")
+            main = torch.cuda.current_stream(self.device)
+            self._vstream.wait_stream(main)
+            with torch.cuda.stream(self._vstream):     # V(s_t) from the normalised row the pi pass just wrote
+                self.fp.forward(self.buf_obs[t], value=self.buf_val[t], nets="v", narrow=True, deterministic=True)
+        else:
+            self.fp.forward(eng.obs, rms=rms, tick=eng.tick_ptr, obs_n=self.buf_obs[t], action=self.buf_act[t],
+                            clipped=self.clipped, value=self.buf_val[t], logp=self.buf_logp[t],
+                            clip_obs=self.obs_norm.clip, eps_norm=self.obs_norm.eps)
         eng.step_fused(self.clipped, done=self._starts[t + 1], ret=self.rew_norm.ret, partials=self.partials,
                        gamma=self.gamma, reward=self.raw_rew[t])
         ops.moments_merge(self.partials, self.N, obs_rms=self.obs_norm.rms if self.norm_obs else None,
@@ -129,6 +145,8 @@ class RolloutCollector:
         self._starts[0].copy_(self._starts[self.T])
         for t in range(self.T):
             self._step(t)
+        if self.fused and self.overlap_critic:
+            torch.cuda.current_stream(self.device).wait_stream(self._vstream)   # join the critic passes
 
     # ------------------------------------------------------------------ public API
     def start(self) -> None:
@@ -158,6 +176,7 @@ class RolloutCollector:
         if not self.fused:
             raise ValueError("policy_gemm applies to the fused path")
         self.fp.set_gemm(gemm)
+        self.overlap_critic = self._vstream is not None and gemm == "f32"
         self._graph = None
 
     def sync_policy(self) -> None:

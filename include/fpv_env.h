@@ -215,6 +215,9 @@ typedef struct {
     uint64_t seed, id_offset;
     float clip_obs, eps_norm;
     int32_t deterministic;   /* 1: a = mu */
+    int32_t nets;            /* 0 or 3: pi and V; 1: pi only (action / log-prob / clip outputs); 2: V only (value) */
+    int32_t narrow;          /* 1: 256-thread workgroups (one wave per SIMD) so that a VALU-bound kernel such as
+                                fpv_step can co-execute on another stream; 0: 512-thread workgroups */
     int32_t reserved;
 } fpv_policy_io;
 

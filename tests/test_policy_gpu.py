@@ -133,3 +133,22 @@ def test_policy_kernel_repeated_launches_every_row(gemm):
         scale = float(mu64.abs().max())
         assert float((a.double() - mu64).abs().max()) <= 4e-6 * max(1.0, scale), trial
         assert float((r["value"].double() - v64).abs().max()) <= 1e-5, trial
+
+
+@pytest.mark.parametrize("narrow", [False, True])
+def test_single_net_launches_match_the_joint_launch(narrow):
+    m, fp = _setup(9)
+    n = 7777
+    g = torch.Generator(device="cuda").manual_seed(1)
+    obs = torch.randn(n, 20, device="cuda", generator=g)
+    eps = torch.randn(n, 4, device="cuda", generator=g)
+    ref = {k: torch.zeros(n, d, device="cuda") for k, d in (("obs_n", 20), ("action", 4), ("clipped", 4))}
+    v_ref, lp_ref = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    fp.forward(obs, eps_in=eps, value=v_ref, logp=lp_ref, **ref)
+    out = {k: torch.zeros_like(t) for k, t in ref.items()}
+    lp = torch.zeros(n, device="cuda")
+    fp.forward(obs, eps_in=eps, logp=lp, nets="pi", narrow=narrow, **out)
+    v = fp.forward(out["obs_n"], nets="v", narrow=narrow, deterministic=True)["value"]
+    for k in ref:
+        assert torch.equal(out[k], ref[k]), k
+    assert torch.equal(lp, lp_ref) and torch.equal(v, v_ref)
