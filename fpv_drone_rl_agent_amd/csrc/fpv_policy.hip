@@ -153,6 +153,8 @@ __global__ __launch_bounds__(THREADS) void policy_forward_kernel(PolicyArgs p, i
         const f32x4* src = reinterpret_cast<const f32x4*>(p.image + (size_t)net_first * kNetFloats);
         f32x4* dst = reinterpret_cast<f32x4*>(lds);
         constexpr int kNetGran = kNetFloats / 4, kPer = (kNetGran + THREADS - 1) / THREADS;
+        constexpr int kHeadGran = (kImageFloats - kHeadBase) / 4;   // 165 granules, requested together with the first net
+        const f32x4 hv = reinterpret_cast<const f32x4*>(p.image + kHeadBase)[threadIdx.x < kHeadGran ? threadIdx.x : 0];
         for (int sl = 0; sl < net_count; ++sl) {
             f32x4 stage[kPer];
 #pragma unroll
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(THREADS) void policy_forward_kernel(PolicyArgs p, i
                 if (g < kNetGran) dst[sl * kNetGran + g] = stage[q];
             }
         }
-        for (int q = threadIdx.x; q < kImageFloats - kHeadBase; q += THREADS) hb[q] = p.image[kHeadBase + q];
+        if (threadIdx.x < kHeadGran) reinterpret_cast<f32x4*>(hb)[threadIdx.x] = hv;
         if (threadIdx.x < kIn) {
             hb[660 + threadIdx.x] = p.rms ? (float)p.rms[threadIdx.x] : 0.0f;
             hb[680 + threadIdx.x] = p.rms ? (float)(1.0 / sqrt(p.rms[kIn + threadIdx.x] + (double)p.eps_norm)) : 1.0f;
