@@ -201,9 +201,11 @@ class VecNormalize:
         if self.venv.device_mode:
             return obs_n, rew_n, dones, infos
         if self.norm_obs and dones.any():
-            for i in np.nonzero(dones)[0]:
-                if "terminal_observation" in infos[i]:
-                    infos[i]["terminal_observation"] = self.normalize_obs(infos[i]["terminal_observation"][None])[0]
+            idx = [i for i in np.nonzero(dones)[0] if "terminal_observation" in infos[i]]
+            if idx:                                   # one normalisation launch for all terminal observations
+                tn = self.normalize_obs(np.stack([infos[i]["terminal_observation"] for i in idx]))
+                for k, i in enumerate(idx):
+                    infos[i]["terminal_observation"] = tn[k]
         return obs_n.cpu().numpy(), rew_n.cpu().numpy(), dones, infos
 
     def step(self, actions):
