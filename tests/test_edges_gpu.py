@@ -1,0 +1,92 @@
+"""Edge cases of the C ABI on the device: ragged sizes around the 64-drone tile, argument errors, handle churn."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 129, 1000])
+def test_ragged_sizes_step_fused_and_ledger(oracle, n):
+    """Sizes that do not fill the last tile: plain and fused step agree with the oracle, nothing is written past n."""
+    from fpv_drone_rl_agent_amd import ops
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    st0 = oracle.synthetic_states(n, seed=n)
+    st0[::3, 34] = 401                                   # a third of the drones truncate
+    st0 = st0.astype(np.float32)
+    act = np.random.default_rng(n).uniform(-1, 1, (n, 4)).astype(np.float32)
+    ref = st0.astype(np.float64)
+    cfg = oracle.make_cfg(noise_ratio=0.02, seed=n)
+    o_r, r_r, te_r, tr_r, led = oracle.step_batch(cfg, ref, act.astype(np.float64), 3)
+    for fused in (False, True):
+        eng = FpvEngine(n, 0, seed=n)
+        eng.set_state(torch.from_numpy(st0))
+        eng.set_tick(3)
+        guard = torch.full((n + 64, 20), -9.0, device="cuda")          # canary rows behind the real ones
+        rew = torch.full((n + 64,), -9.0, device="cuda")
+        a = torch.from_numpy(act).cuda()
+        if fused:
+            done = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+            ret = torch.zeros(n + 64, device="cuda")
+            part = torch.zeros((eng.tiles, 44), dtype=torch.float64, device="cuda")
+            eng.step_fused(a, done=done[:n], ret=ret[:n], partials=part, gamma=0.99, obs=guard[:n], reward=rew[:n])
+            assert (done[:n].cpu().numpy() == ((te_r | tr_r) > 0)).all() and (done[n:] == 0).all() and (ret[n:] == 0).all()
+            o = guard[:n].double()
+            tot = part.sum(0).cpu().numpy()
+            assert np.allclose(tot[:20], o.sum(0).cpu().numpy(), rtol=1e-9, atol=1e-9)
+            assert np.allclose(tot[20:40], (o * o).sum(0).cpu().numpy(), rtol=1e-9, atol=1e-9)
+            rms = torch.zeros(41, dtype=torch.float64, device="cuda"); rms[20:40] = 1; rms[40] = 1e-4
+            ops.moments_merge(part, n, obs_rms=rms)
+            assert np.isclose(float(rms[40]), n + 1e-4)
+        else:
+            eng.step(a, obs=guard[:n], reward=rew[:n])
+        assert (guard[n:] == -9.0).all() and (rew[n:] == -9.0).all()    # no write past the last drone
+        assert (eng.terminated.cpu().numpy() == te_r).all() and (eng.truncated.cpu().numpy() == tr_r).all()
+        st = eng.get_state().cpu().numpy()
+        assert (np.abs(st - ref) <= 1e-5 * np.maximum(1, np.abs(ref))).all()
+        got = eng.ledger_read()
+        assert (got["idx"] == led.rows()[0]).all() and got["count"] == len(led.rows()[0])
+        eng.close()
+
+
+def test_abi_argument_errors_on_device():
+    from fpv_drone_rl_agent_amd import _lib as L
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    lib = L.load()
+    eng = FpvEngine(128, 0)
+    a = torch.zeros(128, 4, device="cuda")
+    bad = torch.zeros(128 * 4 + 1, device="cuda")[1:].view(128, 4)        # 4-byte aligned only
+    assert lib.fpv_step(eng._h, C.c_void_p(bad.data_ptr()), C.c_void_p(eng.obs.data_ptr()), C.c_void_p(eng.reward.data_ptr()),
+                        C.c_void_p(eng.terminated.data_ptr()), C.c_void_p(eng.truncated.data_ptr()), None) == -1
+    assert b"aligned" in lib.fpv_last_error()
+    # fp32 handle through the fp64 entry point
+    assert lib.fpv_step_f64(eng._h, C.c_void_p(a.data_ptr()), C.c_void_p(eng.obs.data_ptr()), C.c_void_p(eng.reward.data_ptr()),
+                            C.c_void_p(eng.terminated.data_ptr()), C.c_void_p(eng.truncated.data_ptr()), None) == -1
+    assert b"precision" in lib.fpv_last_error()
+    cfg = L.FpvConfig(64, 99, 0, 1, 0, 0.02, 0, 0, 0, 0, 0)               # device that does not exist
+    h = C.c_void_p()
+    assert lib.fpv_create(C.byref(cfg), C.byref(h)) == -1 and b"not present" in lib.fpv_last_error()
+    cfg = L.FpvConfig(64, 0, 0, 1, 7, 0.02, 0, 0, 0, 0, 0)                # unknown task
+    assert lib.fpv_create(C.byref(cfg), C.byref(h)) == -1 and b"task" in lib.fpv_last_error()
+    with pytest.raises(ValueError):
+        FpvEngine(64, 0, task="yaw").step_fused(torch.zeros(64, 1, device="cuda"))
+    with pytest.raises(ValueError):
+        FpvEngine(64, 0, precision="f64").step_fused(torch.zeros(64, 4, device="cuda", dtype=torch.float64))
+    eng.step(a)                                                           # the handle is still usable after errors
+    eng.close()
+
+
+def test_handle_churn_does_not_leak():
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    torch.cuda.synchronize()
+    a = torch.zeros(4096, 4, device="cuda")
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(40):
+        eng = FpvEngine(4096, 0, task="yaw" if _ % 2 else "hover")
+        eng.reset()
+        eng.close()
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] < 64 * 2 ** 20           # nothing accumulates across create/destroy
