@@ -20,10 +20,15 @@ from .rollout import RolloutCollector
 class PPO:
     def __init__(self, collector: RolloutCollector, learning_rate: float = 3e-4, n_epochs: int = 4,
                  n_minibatches: int = 8, clip_range: float = 0.2, ent_coef: float = 0.0, vf_coef: float = 0.5,
-                 max_grad_norm: float = 0.5, normalize_advantage: bool = True, target_kl: float | None = None):
+                 max_grad_norm: float = 0.5, normalize_advantage: bool = True, target_kl: float | None = None,
+                 use_graph: bool = True):
         self.col = collector
         self.policy = collector.policy
-        self.opt = torch.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5)
+        # capturable Adam: its step counter lives on the device, so one minibatch update (forward, loss, backward,
+        # gradient all-reduce, clip, Adam) can be captured once into a HIP graph and replayed
+        self.use_graph = bool(use_graph) and next(self.policy.parameters()).is_cuda
+        self.opt = torch.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5, capturable=self.use_graph)
+        self._mb_graph = None
         self.n_epochs, self.n_minibatches = n_epochs, n_minibatches
         self.clip_range, self.ent_coef, self.vf_coef = clip_range, ent_coef, vf_coef
         self.max_grad_norm, self.normalize_advantage, self.target_kl = max_grad_norm, normalize_advantage, target_kl
@@ -50,11 +55,57 @@ class PPO:
             g.copy_(flat[o:o + g.numel()].view_as(g))
             o += g.numel()
 
+    def _minibatch_update(self, obs, act, old_lp, ret, adv):
+        """One clipped-surrogate + value-loss step; returns the detached statistics vector."""
+        v, lp, ent = self.policy.evaluate(obs, act)
+        ratio = torch.exp(lp - old_lp)
+        pg = -torch.min(adv * ratio, adv * torch.clamp(ratio, 1 - self.clip_range, 1 + self.clip_range)).mean()
+        vl = torch.nn.functional.mse_loss(v, ret)
+        loss = pg + self.vf_coef * vl - self.ent_coef * ent.mean()
+        self.opt.zero_grad(set_to_none=False)
+        loss.backward()
+        self._allreduce_grads()
+        torch.nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
+        self.opt.step()
+        with torch.no_grad():
+            log_ratio = lp - old_lp
+            kl = ((torch.exp(log_ratio) - 1) - log_ratio).mean()
+            return torch.stack([pg.detach(), vl.detach(), kl, ((ratio - 1).abs() > self.clip_range).float().mean()])
+
+    def _build_graph(self, mb: int, obs_dim: int, act_dim: int, dev) -> None:
+        f32 = torch.float32
+        self._g_in = [torch.zeros((mb, obs_dim), dtype=f32, device=dev), torch.zeros((mb, act_dim), dtype=f32, device=dev),
+                      torch.zeros((mb,), dtype=f32, device=dev), torch.zeros((mb,), dtype=f32, device=dev),
+                      torch.zeros((mb,), dtype=f32, device=dev)]
+        # warm-up on a side stream with the optimiser state saved and restored, then capture
+        saved = ({k: v.clone() for k, v in self.policy.state_dict().items()},
+                 {"state": {k: {n: (t.clone() if torch.is_tensor(t) else t) for n, t in st.items()}
+                            for k, st in self.opt.state_dict()["state"].items()},
+                  "param_groups": self.opt.state_dict()["param_groups"]})
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self._minibatch_update(*self._g_in)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._g_out = self._minibatch_update(*self._g_in)
+        self.policy.load_state_dict(saved[0])
+        if saved[1]["state"]:
+            self.opt.load_state_dict(saved[1])
+        else:                                   # first update ever: reset the freshly created Adam moments
+            for st in self.opt.state.values():
+                for t in st.values():
+                    if torch.is_tensor(t):
+                        t.zero_()
+        self._mb_graph, self._mb_size = g, mb
+
     def train_on(self, batch: dict) -> None:
         T, N = self.col.T, self.col.N
         obs = batch["obs"].reshape(T * N, -1)
         act = batch["actions"].reshape(T * N, -1)
-        old_v = batch["values"].reshape(-1)
         old_lp = batch["log_probs"].reshape(-1)
         ret = batch["returns"].reshape(-1)
         adv = batch["advantages"].reshape(-1)
@@ -63,30 +114,22 @@ class PPO:
             adv = (adv - batch["adv_mean"].float()) / (batch["adv_std"].float() + 1e-8)
         total = T * N
         mb = total // self.n_minibatches
+        graph = self.use_graph and not (D.world_size() > 1 and td.get_backend() == "gloo")
+        if graph and (self._mb_graph is None or self._mb_size != mb):
+            self._build_graph(mb, obs.shape[1], act.shape[1], obs.device)
         stats = []
-        stop = False
         for epoch in range(self.n_epochs):
             perm = torch.randperm(total, device=obs.device, generator=self._gen)
             for k in range(self.n_minibatches):
                 idx = perm[k * mb:(k + 1) * mb]
-                v, lp, ent = self.policy.evaluate(obs[idx], act[idx])
-                ratio = torch.exp(lp - old_lp[idx])
-                a = adv[idx]
-                pg = -torch.min(a * ratio, a * torch.clamp(ratio, 1 - self.clip_range, 1 + self.clip_range)).mean()
-                vl = torch.nn.functional.mse_loss(v, ret[idx])
-                loss = pg + self.vf_coef * vl - self.ent_coef * ent.mean()
-                self.opt.zero_grad(set_to_none=True)
-                loss.backward()
-                self._allreduce_grads()
-                torch.nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
-                self.opt.step()
-                with torch.no_grad():
-                    log_ratio = lp - old_lp[idx]
-                    kl = ((torch.exp(log_ratio) - 1) - log_ratio).mean()
-                    stats.append(torch.stack([pg.detach(), vl.detach(), kl, ((ratio - 1).abs() > self.clip_range).float().mean()]))
-            if self.target_kl is not None and float(stats[-1][2]) > 1.5 * self.target_kl:
-                stop = True
-            if stop:
+                if graph:
+                    for dst, src in zip(self._g_in, (obs, act, old_lp, ret, adv)):
+                        torch.index_select(src, 0, idx, out=dst)
+                    self._mb_graph.replay()
+                    stats.append(self._g_out.clone())
+                else:
+                    stats.append(self._minibatch_update(obs[idx], act[idx], old_lp[idx], ret[idx], adv[idx]))
+            if self.target_kl is not None and float(torch.stack(stats[-self.n_minibatches:]).mean(0)[2]) > 1.5 * self.target_kl:
                 break
         s = torch.stack(stats).mean(0).tolist()
         self.logger.update({"train/policy_gradient_loss": s[0], "train/value_loss": s[1], "train/approx_kl": s[2],
