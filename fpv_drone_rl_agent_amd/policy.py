@@ -16,6 +16,41 @@ from torch import nn
 LOG_2PI = math.log(2.0 * math.pi)
 
 
+class _SplitKLinear(torch.autograd.Function):
+    """y = x W^T + b whose weight gradient is a split-K product.  PPO minibatches here are tens of thousands of
+    rows against 128 x 128 (or 128 x 20) weights: dW = dY^T X has a tiny output and K = rows, which rocBLAS runs on a
+    handful of workgroups (210 us at 65 536 rows, profiles/r01_train_profile.txt).  Cutting the rows into chunks,
+    multiplying the chunks as one batched GEMM and summing fills the chip."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.addmm(b, x, w.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gx = g @ w if ctx.needs_input_grad[0] else None
+        n = x.shape[0]
+        s = 1
+        while s < 128 and n % (2 * s) == 0 and n // (2 * s) >= 256:
+            s *= 2
+        if s > 1:
+            gw = torch.bmm(g.view(s, n // s, -1).transpose(1, 2), x.view(s, n // s, -1)).sum(0)
+        else:
+            gw = g.t() @ x
+        return gx, gw, g.sum(0)
+
+
+def _trunk(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
+    """seq(x) with split-K weight gradients for the Linear layers when a large batch is being differentiated."""
+    if not (torch.is_grad_enabled() and x.shape[0] >= 4096 and x.is_cuda):
+        return seq(x)
+    for m in seq:
+        x = _SplitKLinear.apply(x.contiguous(), m.weight, m.bias) if isinstance(m, nn.Linear) else m(x)
+    return x
+
+
 class ActorCritic(nn.Module):
     def __init__(self, obs_dim: int = 20, act_dim: int = 4, hidden: int = 128, log_std_init: float = 0.0):
         super().__init__()
@@ -36,7 +71,7 @@ class ActorCritic(nn.Module):
         nn.init.zeros_(self.value_net.bias)
 
     def mean_value(self, obs: torch.Tensor):
-        return self.action_net(self.pi(obs)), self.value_net(self.vf(obs)).squeeze(-1)
+        return self.action_net(_trunk(self.pi, obs)), self.value_net(_trunk(self.vf, obs)).squeeze(-1)
 
     def value(self, obs: torch.Tensor):
         return self.value_net(self.vf(obs)).squeeze(-1)

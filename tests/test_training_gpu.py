@@ -66,3 +66,19 @@ def test_checkpoint_cadence_roundtrip_and_playback(tmp_path):
         obs, reward, done, info = vn.step(action.cpu().numpy())
     assert obs.shape == (4, 20) and reward.shape == (4,)
     env.close(); eng.close()
+
+
+def test_splitk_linear_gradients_match_autograd():
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    torch.manual_seed(0)
+    a, b = ActorCritic().cuda(), ActorCritic().cuda()
+    b.load_state_dict(a.state_dict())
+    obs = torch.randn(16384, 20, device="cuda")
+    act = torch.randn(16384, 4, device="cuda")
+    va, lpa, _ = a.evaluate(obs, act)                   # large batch -> split-K path
+    (va.square().mean() + lpa.mean()).backward()
+    for i in range(0, 16384, 2048):                     # reference: small chunks -> stock autograd path
+        vb, lpb, _ = b.evaluate(obs[i:i + 2048], act[i:i + 2048])
+        ((vb.square().sum() + lpb.sum()) / 16384).backward()
+    for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.allclose(pa.grad, pb.grad, rtol=2e-3, atol=2e-5), n
