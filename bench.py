@@ -155,7 +155,7 @@ def main() -> None:
     # actor-critic forward, MFMA-bound); `roofline_env_step` is the HBM-bound dynamics kernel BASELINE's "% HBM
     # roofline" refers to, as it runs in the rollout (with the VecNormalize bookkeeping fused in) and stand-alone.
     roofline = roofline_env = roofline_env_plain = None
-    if rank == 0:
+    if True:   # every rank runs the same passes (collect() contains the collective); only rank 0 reports them
         L = args.kernel_launches
         act = torch.rand((n, eng.act_words), device=dev) * 2 - 1
 
