@@ -76,6 +76,7 @@ SIGNATURES = {
     "fpv_policy_create": (C.c_int, [_i32, C.POINTER(_vp)]),
     "fpv_policy_destroy": (C.c_int, [_vp]),
     "fpv_policy_load": (C.c_int, [_vp, C.POINTER(_vp), _vp]),
+    "fpv_policy_set_dims": (C.c_int, [_vp, _i32, _i32]),
     "fpv_policy_set_gemm": (C.c_int, [_vp, _i32]),
     "fpv_policy_forward": (C.c_int, [_vp, C.POINTER(FpvPolicyIo), _vp]),
     "fpv_noop": (C.c_int, [_vp]),

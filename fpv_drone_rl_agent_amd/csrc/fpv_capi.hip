@@ -53,6 +53,7 @@ struct fpv_policy {
     int device;
     int cus;
     int gemm;               // 0: exact fp32 MFMA, 1: 6-term bf16 split MFMA
+    int in_dim, act_dim;    // 20 / 4 (hover) unless fpv_policy_set_dims says otherwise
     float* image;
     unsigned char* split_image;
 };
@@ -383,6 +384,8 @@ int fpv_policy_create(int32_t device, fpv_policy** out) {
     FPV_HIP(hipGetDeviceProperties(&prop, device));
     p->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     p->gemm = 0;
+    p->in_dim = 20;
+    p->act_dim = 4;
     p->split_image = nullptr;
     hipError_t e = hipMalloc((void**)&p->image, sizeof(float) * (size_t)policy_image_floats());
     if (e == hipSuccess) e = hipMalloc((void**)&p->split_image, (size_t)policy_split_image_bytes());
@@ -406,8 +409,17 @@ int fpv_policy_load(fpv_policy* p, const float* const* weights, void* stream) {
     if (!p || !weights) return fail(FPV_ERR_ARG, "fpv_policy_load: null argument");
     for (int i = 0; i < 13; ++i)
         if (!weights[i]) return fail(FPV_ERR_ARG, "fpv_policy_load: weight pointer %d is null", i);
-    FPV_HIP(launch_policy_pack(weights, p->image, (hipStream_t)stream));
-    FPV_HIP(launch_policy_split_pack(weights, p->split_image, (hipStream_t)stream));
+    FPV_HIP(launch_policy_pack(weights, p->image, p->in_dim, p->act_dim, (hipStream_t)stream));
+    if (p->in_dim == 20 && p->act_dim == 4) FPV_HIP(launch_policy_split_pack(weights, p->split_image, (hipStream_t)stream));
+    return FPV_OK;
+}
+
+int fpv_policy_set_dims(fpv_policy* p, int32_t in_dim, int32_t act_dim) {
+    if (!p) return fail(FPV_ERR_ARG, "fpv_policy_set_dims: null handle");
+    if (in_dim < 4 || in_dim > 24 || (in_dim % 4) || act_dim < 1 || act_dim > 4)
+        return fail(FPV_ERR_ARG, "fpv_policy_set_dims: need in_dim in {4,8,...,24} and act_dim in 1..4");
+    p->in_dim = in_dim;
+    p->act_dim = act_dim;
     return FPV_OK;
 }
 
@@ -424,10 +436,12 @@ int fpv_policy_forward(fpv_policy* p, const fpv_policy_io* io, void* stream) {
     if (nets < 1 || nets > 3) return fail(FPV_ERR_ARG, "fpv_policy_forward: nets must be 0..3");
     if (io->n <= 0 || !io->obs || ((nets & 2) && !io->value))
         return fail(FPV_ERR_ARG, "fpv_policy_forward: n, obs and (when V is evaluated) value are required");
-    if (((uintptr_t)io->obs | (uintptr_t)io->obs_n | (uintptr_t)io->action | (uintptr_t)io->clipped |
-         (uintptr_t)io->eps_in | (uintptr_t)io->eps_out) & 15)
+    const uintptr_t act_rows = p->act_dim == 4 ? ((uintptr_t)io->action | (uintptr_t)io->clipped | (uintptr_t)io->eps_in |
+                                                   (uintptr_t)io->eps_out) : 0;
+    if (((uintptr_t)io->obs | (uintptr_t)io->obs_n | act_rows) & 15)
         return fail(FPV_ERR_ARG, "fpv_policy_forward: row buffers must be 16-byte aligned");
     if (p->gemm == 1) {
+        if (p->in_dim != 20 || p->act_dim != 4) return fail(FPV_ERR_UNSUPPORTED, "fpv_policy_forward: the bf16-split kernel is built for 20 -> 4");
         if (nets != 3 || io->narrow) return fail(FPV_ERR_UNSUPPORTED, "fpv_policy_forward: the bf16-split kernel evaluates both nets in 512-thread workgroups");
         FPV_HIP(launch_policy_split_forward(p->split_image, io->obs, io->rms, io->eps_in, io->tick, io->obs_n, io->action,
                                             io->clipped, io->value, io->logp, io->eps_out, io->n, io->seed, io->id_offset,
@@ -436,7 +450,8 @@ int fpv_policy_forward(fpv_policy* p, const fpv_policy_io* io, void* stream) {
     }
     FPV_HIP(launch_policy_forward(p->image, io->obs, io->rms, io->eps_in, io->tick, io->obs_n, io->action, io->clipped,
                                   io->value, io->logp, io->eps_out, io->n, io->seed, io->id_offset, io->clip_obs,
-                                  io->eps_norm, io->deterministic, p->cus, nets, io->narrow ? 1 : 0, (hipStream_t)stream));
+                                  io->eps_norm, io->deterministic, p->cus, nets, io->narrow ? 1 : 0, p->in_dim, p->act_dim,
+                                  (hipStream_t)stream));
     return FPV_OK;
 }
 

@@ -77,12 +77,12 @@ hipError_t launch_normalize_reward(int64_t n, const float* r, const uint8_t* don
                                    double* rms, int32_t update, float gamma, float clip, float eps, double* scratch,
                                    hipStream_t s);
 // fpv_policy.hip
-hipError_t launch_policy_pack(const float* const* w, float* image, hipStream_t s);
+hipError_t launch_policy_pack(const float* const* w, float* image, int in_dim, int act_dim, hipStream_t s);
 hipError_t launch_policy_forward(const float* image, const float* obs, const double* rms, const float* eps_in,
                                  const uint64_t* tick, float* obs_n, float* action, float* clipped, float* value,
                                  float* logp, float* eps_out, int64_t n, uint64_t seed, uint64_t id_offset,
                                  float clip_obs, float eps_norm, int deterministic, int max_blocks, int nets, int narrow,
-                                 hipStream_t s);
+                                 int in_dim, int act_dim, hipStream_t s);
 int policy_image_floats();
 // fpv_policy_split.hip
 hipError_t launch_policy_split_pack(const float* const* w, unsigned char* image, hipStream_t s);

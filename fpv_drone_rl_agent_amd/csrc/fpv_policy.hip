@@ -34,6 +34,7 @@ __host__ __device__ constexpr int tile_row(int r, int h) { return (r & 3) + 8 * 
 struct PolicyParams {
     const float *pi_w1, *pi_b1, *pi_w2, *pi_b2, *wa, *ba, *log_std;
     const float *vf_w1, *vf_b1, *vf_w2, *vf_b2, *wv, *bv;
+    int in_dim, act_dim;   // 20 / 4 hover (hover.py:59-70), 12 / 1 yaw (yaw.py:37-45); in_dim % 4 == 0, <= 24; act_dim <= 4
 };
 
 __global__ void policy_pack_kernel(PolicyParams p, float* __restrict__ img) {
@@ -49,7 +50,7 @@ __global__ void policy_pack_kernel(PolicyParams p, float* __restrict__ img) {
         if (o < kOffB1) {                       // W1p[m][s][lane] = W1[m*32 + i][s + 12 h]
             const int lane = o % 64, s = (o / 64) % 12, m = o / (64 * 12);
             const int k = s + 12 * (lane >> 5);
-            v = k < kIn ? w1[(m * 32 + (lane & 31)) * kIn + k] : 0.0f;
+            v = k < p.in_dim ? w1[(m * 32 + (lane & 31)) * p.in_dim + k] : 0.0f;
         } else if (o < kOffW2) {                // b1p[m][h][r]
             const int q = o - kOffB1, r = q % 16, h = (q / 16) % 2, m = q / 32;
             v = b1[m * 32 + tile_row(r, h)];
@@ -64,16 +65,17 @@ __global__ void policy_pack_kernel(PolicyParams p, float* __restrict__ img) {
         const int q = e - kHeadBase;
         if (q < 512) {                          // Wa[h][kt][r][o]
             const int o = q % 4, r = (q / 4) % 16, kt = (q / 64) % 4, h = q / 256;
-            v = p.wa[o * kHid + kt * 32 + tile_row(r, h)];
+            v = o < p.act_dim ? p.wa[o * kHid + kt * 32 + tile_row(r, h)] : 0.0f;
         } else if (q < 640) {                   // Wv[h][kt][r]
             const int z = q - 512, r = z % 16, kt = (z / 16) % 4, h = z / 64;
             v = p.wv[kt * 32 + tile_row(r, h)];
-        } else if (q < 644) v = p.ba[q - 640];
+        } else if (q < 644) v = q - 640 < p.act_dim ? p.ba[q - 640] : 0.0f;
         else if (q == 644) v = p.bv[0];
-        else if (q >= 648 && q < 652) v = p.log_std[q - 648];
-        else if (q >= 652 && q < 656) v = expf(p.log_std[q - 652]);
-        else if (q == 656)
-            v = -(p.log_std[0] + p.log_std[1] + p.log_std[2] + p.log_std[3]) - 2.0f * 1.8378770664093453f;  // 4 * 0.5 ln 2 pi
+        else if (q >= 648 && q < 652) v = q - 648 < p.act_dim ? p.log_std[q - 648] : 0.0f;
+        else if (q >= 652 && q < 656) v = q - 652 < p.act_dim ? expf(p.log_std[q - 652]) : 0.0f;
+        else if (q == 656) {                    // -sum log_std - act_dim * 0.5 ln 2 pi
+            for (int j = 0; j < p.act_dim; ++j) v -= p.log_std[j] + 0.5f * 1.8378770664093453f;
+        }
     }
     img[e] = v;
 }
@@ -113,6 +115,7 @@ struct PolicyArgs {
     uint64_t seed, id_offset;
     float clip_obs, eps_norm;
     int32_t deterministic;   // 1: action = mean (SB3 predict(deterministic=True), test_hover.py:17)
+    int32_t in_dim, act_dim;
 };
 
 // one hidden layer's 64 values per lane: 4 accumulator tiles
@@ -169,9 +172,9 @@ __global__ __launch_bounds__(THREADS) void policy_forward_kernel(PolicyArgs p, i
             }
         }
         if (threadIdx.x < kHeadGran) reinterpret_cast<f32x4*>(hb)[threadIdx.x] = hv;
-        if (threadIdx.x < kIn) {
+        if ((int)threadIdx.x < p.in_dim) {
             hb[660 + threadIdx.x] = p.rms ? (float)p.rms[threadIdx.x] : 0.0f;
-            hb[680 + threadIdx.x] = p.rms ? (float)(1.0 / sqrt(p.rms[kIn + threadIdx.x] + (double)p.eps_norm)) : 1.0f;
+            hb[680 + threadIdx.x] = p.rms ? (float)(1.0 / sqrt(p.rms[p.in_dim + threadIdx.x] + (double)p.eps_norm)) : 1.0f;
         }
     }
     __syncthreads();
@@ -188,23 +191,23 @@ __global__ __launch_bounds__(THREADS) void policy_forward_kernel(PolicyArgs p, i
         // ---- observation: half 0 holds k = 0..11, half 1 holds k = 12..23 (20..23 are zero padding)
         float x[12];
         {
-            const f32x4* row = reinterpret_cast<const f32x4*>(p.obs + (live ? d : 0) * kIn);
+            const f32x4* row = reinterpret_cast<const f32x4*>(p.obs + (live ? d : 0) * p.in_dim);
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                const bool have = live && (h == 0 || q < 2);
+                const bool have = live && 4 * (3 * h + q) < p.in_dim;
                 const f32x4 v = have ? row[3 * h + q] : f32x4{0.f, 0.f, 0.f, 0.f};
                 x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
             }
 #pragma unroll
             for (int j = 0; j < 12; ++j) {
                 const int k = 12 * h + j;
-                if (k < kIn) x[j] = fminf(fmaxf((x[j] - hb[660 + k]) * hb[680 + k], -clip), clip);
+                if (k < p.in_dim) x[j] = fminf(fmaxf((x[j] - hb[660 + k]) * hb[680 + k], -clip), clip);
             }
             if (p.obs_n && live) {
-                f32x4* out = reinterpret_cast<f32x4*>(p.obs_n + d * kIn);
+                f32x4* out = reinterpret_cast<f32x4*>(p.obs_n + d * p.in_dim);
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
-                    if (h == 0 || q < 2) out[3 * h + q] = f32x4{x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+                    if (4 * (3 * h + q) < p.in_dim) out[3 * h + q] = f32x4{x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
             }
         }
 
@@ -268,8 +271,12 @@ __global__ __launch_bounds__(THREADS) void policy_forward_kernel(PolicyArgs p, i
         float eps[4] = {0.f, 0.f, 0.f, 0.f};
         if (!p.deterministic) {
             if (p.eps_in) {
-                const f32x4 e = live ? reinterpret_cast<const f32x4*>(p.eps_in)[d] : f32x4{0.f, 0.f, 0.f, 0.f};
-                eps[0] = e.x; eps[1] = e.y; eps[2] = e.z; eps[3] = e.w;
+                if (p.act_dim == 4) {
+                    const f32x4 e = live ? reinterpret_cast<const f32x4*>(p.eps_in)[d] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    eps[0] = e.x; eps[1] = e.y; eps[2] = e.z; eps[3] = e.w;
+                } else {
+                    for (int j = 0; j < p.act_dim; ++j) eps[j] = live ? p.eps_in[d * p.act_dim + j] : 0.f;
+                }
             } else {
                 const uint64_t t = p.tick ? p.tick[0] : 0ull;
                 uint32_t xr[4];
@@ -287,18 +294,28 @@ __global__ __launch_bounds__(THREADS) void policy_forward_kernel(PolicyArgs p, i
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             act[j] = mu[j] + hb[652 + j] * eps[j];
-            lp -= 0.5f * eps[j] * eps[j];
+            if (j < p.act_dim) lp -= 0.5f * eps[j] * eps[j];
         }
         if (live) {
             if (h == 0) {
-                if (p.action) reinterpret_cast<f32x4*>(p.action)[d] = f32x4{act[0], act[1], act[2], act[3]};
-                if (p.clipped)
-                    reinterpret_cast<f32x4*>(p.clipped)[d] =
-                        f32x4{fminf(fmaxf(act[0], -1.f), 1.f), fminf(fmaxf(act[1], -1.f), 1.f),
-                              fminf(fmaxf(act[2], -1.f), 1.f), fminf(fmaxf(act[3], -1.f), 1.f)};
+                if (p.act_dim == 4) {
+                    if (p.action) reinterpret_cast<f32x4*>(p.action)[d] = f32x4{act[0], act[1], act[2], act[3]};
+                    if (p.clipped)
+                        reinterpret_cast<f32x4*>(p.clipped)[d] =
+                            f32x4{fminf(fmaxf(act[0], -1.f), 1.f), fminf(fmaxf(act[1], -1.f), 1.f),
+                                  fminf(fmaxf(act[2], -1.f), 1.f), fminf(fmaxf(act[3], -1.f), 1.f)};
+                } else {
+                    for (int j = 0; j < p.act_dim; ++j) {
+                        if (p.action) p.action[d * p.act_dim + j] = act[j];
+                        if (p.clipped) p.clipped[d * p.act_dim + j] = fminf(fmaxf(act[j], -1.f), 1.f);
+                    }
+                }
             } else {
                 if (p.logp) p.logp[d] = lp;
-                if (p.eps_out) reinterpret_cast<f32x4*>(p.eps_out)[d] = f32x4{eps[0], eps[1], eps[2], eps[3]};
+                if (p.eps_out) {
+                    if (p.act_dim == 4) reinterpret_cast<f32x4*>(p.eps_out)[d] = f32x4{eps[0], eps[1], eps[2], eps[3]};
+                    else for (int j = 0; j < p.act_dim; ++j) p.eps_out[d * p.act_dim + j] = eps[j];
+                }
             }
         }
     }
@@ -306,8 +323,8 @@ __global__ __launch_bounds__(THREADS) void policy_forward_kernel(PolicyArgs p, i
 
 // ---------------------------------------------------------------- launchers
 hipError_t launch_policy_pack(const float* const* w /* 13 device pointers in PolicyParams order */, float* image,
-                              hipStream_t s) {
-    PolicyParams p{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12]};
+                              int in_dim, int act_dim, hipStream_t s) {
+    PolicyParams p{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], in_dim, act_dim};
     hipLaunchKernelGGL(policy_pack_kernel, dim3((kImageFloats + 255) / 256), dim3(256), 0, s, p, image);
     return hipGetLastError();
 }
@@ -316,7 +333,7 @@ hipError_t launch_policy_forward(const float* image, const float* obs, const dou
                                  const uint64_t* tick, float* obs_n, float* action, float* clipped, float* value,
                                  float* logp, float* eps_out, int64_t n, uint64_t seed, uint64_t id_offset,
                                  float clip_obs, float eps_norm, int deterministic, int max_blocks, int nets, int narrow,
-                                 hipStream_t s) {
+                                 int in_dim, int act_dim, hipStream_t s) {
     // nets: 3 = pi + V (one launch), 1 = pi only (with the sampling epilogue), 2 = V only.
     // narrow: 256-thread workgroups (one wave per SIMD) so that other kernels can co-reside.
     static bool attr_set = false;
@@ -331,7 +348,7 @@ hipError_t launch_policy_forward(const float* image, const float* obs, const dou
     const int net_first = nets == 2 ? 1 : 0, net_count = nets == 3 ? 2 : 1;
     const size_t lds_bytes = (size_t)(net_count * kNetFloats + (kImageFloats - kHeadBase) + 40) * sizeof(float);
     PolicyArgs p{image, obs, rms, eps_in, tick, obs_n, action, clipped, value, logp, eps_out,
-                 n, seed, id_offset, clip_obs, eps_norm, deterministic};
+                 n, seed, id_offset, clip_obs, eps_norm, deterministic, in_dim, act_dim};
     const int threads = narrow ? 256 : 512, chunk = threads / 2;
     int64_t blocks = (n + chunk - 1) / chunk;
     if (blocks > max_blocks) blocks = max_blocks;

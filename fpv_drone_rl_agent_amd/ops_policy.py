@@ -20,8 +20,9 @@ def _ptr(t):
 
 class FusedPolicy:
     def __init__(self, module: ActorCritic, device=None, seed: int = 0, id_offset: int = 0, gemm: str = "f32"):
-        if (module.obs_dim, module.act_dim, module.hidden) != (20, 4, 128):
-            raise ValueError("the fused kernel is built for obs 20, act 4, hidden 128 (train_hover.py:57)")
+        if module.hidden != 128 or module.obs_dim % 4 or not (4 <= module.obs_dim <= 24) or not (1 <= module.act_dim <= 4):
+            raise ValueError("the fused kernel needs hidden 128 (train_hover.py:57), obs_dim in {4..24 step 4}, act_dim 1..4")
+        self.obs_dim, self.act_dim = module.obs_dim, module.act_dim
         self.module = module
         p = next(module.parameters())
         if not p.is_cuda:
@@ -32,6 +33,7 @@ class FusedPolicy:
         h = C.c_void_p()
         L.check(self.lib.fpv_policy_create(self.device.index or 0, C.byref(h)), "fpv_policy_create")
         self._h = h
+        L.check(self.lib.fpv_policy_set_dims(self._h, self.obs_dim, self.act_dim), "fpv_policy_set_dims")
         self.set_gemm(gemm)
         self.load()
 
@@ -66,8 +68,8 @@ class FusedPolicy:
         """obs [n,20] fp32 raw observations; rms = fp64[41] VecNormalize statistics or None.  Output tensors
         are written in place when given; value is always produced.  Returns dict of the outputs."""
         n = obs.shape[0]
-        if obs.dtype != torch.float32 or not obs.is_contiguous() or obs.shape[1] != 20:
-            raise ValueError("obs must be a contiguous [n,20] fp32 device tensor")
+        if obs.dtype != torch.float32 or not obs.is_contiguous() or obs.shape[1] != self.obs_dim:
+            raise ValueError(f"obs must be a contiguous [n,{self.obs_dim}] fp32 device tensor")
         mask = {"both": 3, "pi": 1, "v": 2}[nets]
         if value is None and mask & 2:
             value = torch.empty((n,), dtype=torch.float32, device=obs.device)

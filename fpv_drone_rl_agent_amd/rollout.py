@@ -52,7 +52,8 @@ class RolloutCollector:
         self.O, self.A = O, A
         if (policy.obs_dim, policy.act_dim) != (O, A):
             raise ValueError(f"policy is {policy.obs_dim}->{policy.act_dim} but the task needs {O}->{A}")
-        fused = bool(fused) and engine.task == "hover"   # the fused kernels are built for the hover shapes
+        fused_policy = bool(fused)                       # fpv_policy_forward takes both tasks' widths
+        fused = bool(fused) and engine.task == "hover"   # fpv_step_fused (VecNormalize bookkeeping in-kernel): hover only
         self.obs_norm = ops.RunningNorm(O, dev, clip=clip_obs)
         self.rew_norm = ops.RewardNorm(N, dev, gamma=gamma, clip=clip_reward)
         self.buf_obs = torch.zeros((T, N, O), dtype=f32, device=dev)
@@ -72,8 +73,11 @@ class RolloutCollector:
         self.last_val = torch.zeros((N,), dtype=f32, device=dev)
         self.snap = torch.zeros((T, max(44, 2 * O + 4)), dtype=torch.float64, device=dev)  # {obs_rms, ret_rms} after step t
         self.fused = bool(fused)
+        self.fused_policy = fused_policy
+        if self.fused_policy:
+            self.fp = FusedPolicy(policy, seed=policy_seed, id_offset=engine.id_offset,
+                                  gemm=policy_gemm if self.fused else "f32")
         if self.fused:
-            self.fp = FusedPolicy(policy, seed=policy_seed, id_offset=engine.id_offset, gemm=policy_gemm)
             self.partials = torch.zeros((engine.tiles, 44), dtype=torch.float64, device=dev)
             self.raw_rew = torch.zeros((T, N), dtype=f32, device=dev)
             # overlap_critic: the env step needs pi only, so the critic pass (MFMA-bound) can run on a second stream
@@ -99,8 +103,26 @@ class RolloutCollector:
     def _step(self, t: int) -> None:
         if self.fused:
             self._step_fused(t)
+        elif self.fused_policy:
+            self._step_semifused(t)
         else:
             self._step_torch(t)
+
+    def _step_semifused(self, t: int) -> None:
+        """Fused policy kernel + the stand-alone env-step / normaliser kernels (the yaw task's path)."""
+        eng = self.engine
+        self.fp.forward(eng.obs, rms=self.obs_norm.rms if self.norm_obs else None, tick=eng.tick_ptr,
+                        obs_n=self.buf_obs[t], action=self.buf_act[t], clipped=self.clipped, value=self.buf_val[t],
+                        logp=self.buf_logp[t], clip_obs=self.obs_norm.clip, eps_norm=self.obs_norm.eps)
+        eng.step(self.clipped)
+        torch.bitwise_or(eng.terminated, eng.truncated, out=self._starts[t + 1])
+        if self.norm_obs:
+            self.obs_norm.update_only(eng.obs)
+        self.snap[t, :2 * self.O + 1].copy_(self.obs_norm.rms)
+        if self.norm_reward:
+            self.rew_norm(eng.reward, self._starts[t + 1], out=self.buf_rew[t])
+        else:
+            self.buf_rew[t].copy_(eng.reward)
 
     def _step_fused(self, t: int) -> None:
         eng = self.engine
@@ -181,7 +203,7 @@ class RolloutCollector:
 
     def sync_policy(self) -> None:
         """Repack the torch parameters into the fused kernel's weight image (after every optimiser step)."""
-        if self.fused:
+        if self.fused_policy:
             self.fp.load()
 
     def collect(self) -> dict:
@@ -196,16 +218,17 @@ class RolloutCollector:
             self._graph.replay()
         else:
             self._all_steps()
-        if self.fused:
+        if self.fused_policy:
             self.fp.forward(eng.obs, rms=self.obs_norm.rms if self.norm_obs else None, obs_n=self.cur_obs,
                             value=self.last_val, deterministic=True, clip_obs=self.obs_norm.clip,
                             eps_norm=self.obs_norm.eps)
+        if self.fused:
             if self.norm_reward:
                 ops.reward_finalize(self.raw_rew, self.snap, clip=self.rew_norm.clip, eps=self.rew_norm.eps,
                                     out=self.buf_rew)
             else:
                 self.buf_rew.copy_(self.raw_rew)
-        else:
+        elif not self.fused_policy:
             with torch.no_grad():
                 self.last_val.copy_(self.policy.value(self.cur_obs))
         self._bootstrap_timeouts()
@@ -244,7 +267,7 @@ class RolloutCollector:
             mean, var = rms[:, :self.O], rms[:, self.O:2 * self.O]
             tobs = torch.clamp((tobs.double() - mean) / torch.sqrt(var + self.obs_norm.eps), -self.obs_norm.clip,
                                self.obs_norm.clip).float()
-        if self.fused:
+        if self.fused_policy:
             v = self.fp.forward(tobs.contiguous(), deterministic=True)["value"]
         else:
             with torch.no_grad():

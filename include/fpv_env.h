@@ -199,6 +199,10 @@ int fpv_policy_destroy(fpv_policy* pol);
  * action_net.bias[4], log_std[4], vf.0.weight, vf.0.bias, vf.2.weight, vf.2.bias, value_net.weight[1][128],
  * value_net.bias[1].  Repacks them into the kernel's MFMA-ordered image (call after every update). */
 int fpv_policy_load(fpv_policy* pol, const float* const* weights, void* stream);
+/* Observation / action widths (default 20 / 4, simulation/hover.py:59-70; 12 / 1 for simulation/yaw.py:37-45).  in_dim a
+ * multiple of 4 up to 24, act_dim 1..4; first-layer weights are then [128][in_dim], the action head [act_dim][128], and
+ * the obs / action row buffers of fpv_policy_io have those widths.  Call before fpv_policy_load. */
+int fpv_policy_set_dims(fpv_policy* pol, int32_t in_dim, int32_t act_dim);
 
 typedef struct {
     int64_t n;               /* rows */

@@ -111,3 +111,39 @@ def test_yaw_single_env_surface():
     o, r, term, trunc, info = env.step(np.array([0.5], np.float32))
     assert o.shape == (12,) and isinstance(r, float) and o[11] == 0.5 and not term and not trunc
     env.close()
+
+
+@pytest.mark.gpu
+def test_yaw_fused_policy_matches_torch_and_collects():
+    import torch
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.ops_policy import FusedPolicy
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    from fpv_drone_rl_agent_amd.rollout import RolloutCollector
+    torch.manual_seed(0)
+    m = ActorCritic(obs_dim=12, act_dim=1).cuda()
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.3)
+    fp = FusedPolicy(m)
+    n = 5000
+    obs = torch.randn(n, 12, device="cuda")
+    eps = torch.randn(n, 1, device="cuda")
+    rms = torch.cat([torch.randn(12), torch.rand(12) + 0.5, torch.ones(1)]).double().cuda()
+    out = dict(obs_n=torch.zeros(n, 12, device="cuda"), action=torch.zeros(n, 1, device="cuda"),
+               clipped=torch.zeros(n, 1, device="cuda"), value=torch.zeros(n, device="cuda"), logp=torch.zeros(n, device="cuda"))
+    fp.forward(obs, rms=rms, eps_in=eps, **out)
+    with torch.no_grad():
+        ref_obs = torch.clamp((obs.double() - rms[:12]) / torch.sqrt(rms[12:24] + 1e-8), -10, 10).float()
+        a, v, lp = m.act(ref_obs, eps)
+    assert torch.allclose(out["obs_n"], ref_obs, atol=1e-5) and torch.allclose(out["action"], a, atol=2e-4, rtol=1e-4)
+    assert torch.allclose(out["value"], v, atol=2e-4, rtol=1e-4) and torch.allclose(out["logp"], lp, atol=1e-4)
+    assert torch.equal(out["clipped"], out["action"].clamp(-1, 1))
+    # the collector picks the fused policy for the yaw task (stand-alone env / normaliser kernels) and stays finite
+    eng = FpvEngine(2048, 0, task="yaw", domain_rand=True, ledger_capacity=8192)
+    col = RolloutCollector(eng, m, n_steps=16)
+    assert col.fused_policy and not col.fused
+    b = col.collect()
+    assert torch.isfinite(b["advantages"]).all() and torch.isfinite(b["returns"]).all() and float(b["adv_std"]) > 0
+    eng.close()
