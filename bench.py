@@ -111,6 +111,10 @@ def main() -> None:
     col.start()
     if not yaw:
         eng.set_state(torch.from_numpy(synthetic_states(n, seed=rank)))  # staggered step counts => staggered dones
+    else:
+        st = eng.get_state()                                             # same staggering for the yaw episodes
+        st[:, 34] = torch.randint(0, 401, (n,), device=dev, generator=torch.Generator(device=dev).manual_seed(rank)).float()
+        eng.set_state(st)
 
     def barrier():
         if world > 1:
