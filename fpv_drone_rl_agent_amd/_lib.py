@@ -79,6 +79,7 @@ SIGNATURES = {
     "fpv_policy_set_dims": (C.c_int, [_vp, _i32, _i32]),
     "fpv_policy_set_gemm": (C.c_int, [_vp, _i32]),
     "fpv_policy_forward": (C.c_int, [_vp, C.POINTER(FpvPolicyIo), _vp]),
+    "fpv_set_pair_threshold": (C.c_int, [_i64]),
     "fpv_noop": (C.c_int, [_vp]),
     "fpv_last_error": (C.c_char_p, []),
     "fpv_version": (C.c_int, []),

@@ -107,6 +107,11 @@ __global__ void fpv_noop_kernel() {}
 
 extern "C" {
 
+int fpv_set_pair_threshold(int64_t max_drones) {
+    fpv::g_pair_max_tiles = max_drones <= 0 ? 0 : (max_drones + kTile - 1) / kTile;
+    return FPV_OK;
+}
+
 int fpv_noop(void* stream) {
     hipLaunchKernelGGL(fpv_noop_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream);
     FPV_HIP(hipGetLastError());

@@ -61,6 +61,7 @@ hipError_t launch_yaw_reset(void* state, const uint64_t* tick, const uint8_t* ma
 template <typename T>
 hipError_t launch_yaw_convert(void* state, void* canon, int64_t n, bool to_canon, hipStream_t s);
 
+extern int64_t g_pair_max_tiles;
 hipError_t launch_tick_fill(uint64_t* tick, int64_t tiles, uint64_t v, hipStream_t s);
 
 // fpv_rollout.hip

@@ -207,6 +207,157 @@ __global__ __launch_bounds__(kTile) void step_kernel(StepArgs<T> p) {
     }
 }
 
+// ---------------------------------------------------------------- K1 specialised: physics wave + helper wave
+// For drone counts that leave SIMDs empty (<= 32 768 drones = 512 tiles on 1 024 SIMDs) this variant gives every
+// 64-drone tile a second wave, which then runs on a SIMD of its own (once the two waves have to share a SIMD the
+// instruction mix already saturates its issue rate and nothing is gained — measured, see g_pair_max_tiles):
+//   wave P (lanes 0..63)   : state, control, physics, observation, reward, ledger, reset — everything state-bound;
+//   wave H (lanes 64..127) : the motor-noise draws (Philox + Box-Muller are state-independent: H runs one sub-step
+//                            pair ahead through a double-buffered LDS slot), then the row-major store of the staged
+//                            observation tile and, when FUSED, VecNormalize's tile moment sums.
+// Seven workgroup barriers pair the two waves.  Arithmetic is identical to step_kernel (same device functions, same
+// noise values), so results are bit-identical to it.
+template <bool FUSED>
+__global__ __launch_bounds__(2 * kTile) void step_kernel_pair(StepArgs<float> p) {
+    using T = float;
+    __shared__ T nz[2][8][kTile];
+    __shared__ Vec4<T> lds[kTile * kObsWords / 4 + (FUSED ? kTile / 4 : 0)];
+    const int lane = threadIdx.x & (kTile - 1);
+    const bool helper = threadIdx.x >= kTile;
+    const int64_t tile = blockIdx.x;
+    const int64_t i = tile * kTile + lane;
+    const bool live = i < p.n;
+    const uint64_t agent_tick = p.tick[tile];
+    const uint32_t gid = (uint32_t)(p.id_offset + (uint64_t)i);
+
+    if (helper) {
+        // ---- noise producer: pair k is published before barrier k
+#pragma unroll 1
+        for (int k = 0; k < kSubstepPairs; ++k) {
+            T ga[4], gb[4];
+            normal8(p.seed, gid, agent_tick * (uint64_t)kSubstepPairs + (uint64_t)k, ga, gb);
+            T(*slot)[kTile] = nz[k & 1];
+            slot[0][lane] = ga[0]; slot[1][lane] = ga[1]; slot[2][lane] = ga[2]; slot[3][lane] = ga[3];
+            slot[4][lane] = gb[0]; slot[5][lane] = gb[1]; slot[6][lane] = gb[2]; slot[7][lane] = gb[3];
+            __syncthreads();
+        }
+        __syncthreads();   // barrier 6: wave P has staged the observation tile (and the returns)
+        // ---- row-major store of the tile: five 1-KiB contiguous stores
+        Vec4<T>* out = reinterpret_cast<Vec4<T>*>(p.obs + tile * (kTile * kObsWords));
+        const int64_t rows_left = p.n - tile * kTile;
+#pragma unroll
+        for (int r = 0; r < kObsWords / 4; ++r) {
+            const int f4 = r * kTile + lane;
+            if (f4 / (kObsWords / 4) < rows_left) out[f4] = lds[f4];
+        }
+        if constexpr (FUSED) {
+            if (p.partials) {
+                const T* lds_w = reinterpret_cast<const T*>(lds);
+                const int rows = (int)(rows_left < kTile ? rows_left : kTile);
+                // lanes 0..19: channel sums; lanes 20..39: channel square sums; lanes 40, 41: return sums
+                double acc = 0.0;
+                if (lane < 2 * kObsWords) {
+                    const int c = lane < kObsWords ? lane : lane - kObsWords;
+                    T v[kTile];
+#pragma unroll
+                    for (int r = 0; r < kTile; ++r) v[r] = r < rows ? lds_w[r * kObsWords + c] : T(0);
+#pragma unroll
+                    for (int r = 0; r < kTile; ++r) { const double dd = (double)v[r]; acc += lane < kObsWords ? dd : dd * dd; }
+                } else if (lane < 2 * kObsWords + 2) {
+                    for (int r = 0; r < rows; ++r) {
+                        const double dd = (double)lds_w[kTile * kObsWords + r];
+                        acc += lane == 2 * kObsWords ? dd : dd * dd;
+                    }
+                }
+                if (lane < kPartialWords) p.partials[tile * kPartialWords + lane] = acc;
+            }
+        }
+        return;
+    }
+
+    // ---------------- wave P
+    Drone<T> d;
+    load_drone(d, p.state, tile, lane);
+    const Vec4<T> act = live ? reinterpret_cast<const Vec4<T>*>(p.actions)[i] : Vec4<T>{T(0), T(0), T(0), T(-1)};
+    const uint32_t led_fill = p.led_count[tile];
+    const T tmpl_lane = p.tmpl[lane < kStateWords + kObsWords ? lane : 0];
+    T ret_in = T(0);
+    if constexpr (FUSED) {
+        if (p.ret && live) ret_in = p.ret[i];
+    }
+    const T spx = act.x * T(30), spy = act.y * T(30), spz = act.z * T(-30);
+    const T thrust = clip_((act.w + T(1)) * T(0.5), T(0), T(1));
+    T pwm[4];
+#pragma unroll 1
+    for (int k = 0; k < kSubstepPairs; ++k) {
+        __syncthreads();   // barrier k: pair k's noise is in nz[k & 1]
+        T(*slot)[kTile] = nz[k & 1];
+        const T ga[4] = {slot[0][lane], slot[1][lane], slot[2][lane], slot[3][lane]};
+        const T gb[4] = {slot[4][lane], slot[5][lane], slot[6][lane], slot[7][lane]};
+        control_tick(d, spx, spy, spz, thrust, pwm);
+        physics_substep<T, true>(d, pwm, p.sigma, ga);
+        physics_substep<T, true>(d, pwm, p.sigma, gb);
+    }
+    T roll, pitch, yaw;
+    euler_from_quat(d.qx, d.qy, d.qz, d.qw, roll, pitch, yaw);
+    T o[kObsWords];
+    const bool vis = observe(d, roll, pitch, yaw, act.x, act.y, act.z, act.w, o);
+    uint32_t bits;
+    const T reward = reward_and_flags(d, roll, pitch, vis, o, act.x, act.y, act.z, act.w, p.floor_check != 0, bits);
+    d.er = roll; d.ep = pitch; d.eyaw = yaw;
+    d.steps += T(1);
+    d.a0 = act.x; d.a1 = act.y; d.a2 = act.z; d.a3 = act.w;
+    d.ep_ret += reward;
+
+    const bool done = live && (bits & (kInfoTerm | kInfoTrunc)) != 0;
+    const unsigned long long m = __ballot(done);
+    if (m != 0ull) {
+        Drone<T> r = d;
+        drone_from_template(r, tmpl_lane);
+        T ro[kObsWords];
+#pragma unroll
+        for (int j = 0; j < kObsWords; ++j) ro[j] = __shfl(tmpl_lane, kStateWords + j);
+        if (done) {
+            const int64_t row = (int64_t)led_fill + (int64_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (row < p.led_rows) {
+                const int64_t slot = tile * p.led_rows + row;
+                p.led_idx[slot] = (int32_t)i;
+                p.led_info[slot] = bits | ((uint32_t)d.steps << 8);
+                p.led_tag[slot] = (uint32_t)agent_tick;
+                p.led_ret[slot] = d.ep_ret;
+                Vec4<T>* lo = reinterpret_cast<Vec4<T>*>(p.led_obs + slot * kObsWords);
+#pragma unroll
+                for (int g = 0; g < kObsWords / 4; ++g) lo[g] = Vec4<T>{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+            }
+            d = r;
+#pragma unroll
+            for (int j = 0; j < kObsWords; ++j) o[j] = ro[j];
+        }
+        if (lane == 0) p.led_count[tile] = led_fill + (uint32_t)__popcll(m);
+    }
+    // stage the observation tile (and the discounted returns) for wave H, then finish the state-bound stores
+#pragma unroll
+    for (int g = 0; g < kObsWords / 4; ++g)
+        lds[lane * (kObsWords / 4) + g] = Vec4<T>{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+    if constexpr (FUSED) {
+        T ret = T(0);
+        if (p.ret) {
+            ret = live ? ret_in * (T)p.gamma + reward : T(0);
+            if (live) p.ret[i] = done ? T(0) : ret;
+        }
+        reinterpret_cast<T*>(lds)[kTile * kObsWords + lane] = ret;
+        if (live && p.done) p.done[i] = done ? 1 : 0;
+    }
+    __syncthreads();   // barrier 6
+    store_drone(d, p.state, tile, lane);
+    if (lane == 0) p.tick[tile] = agent_tick + 1ull;
+    if (live) {
+        p.reward[i] = reward;
+        p.terminated[i] = (bits & kInfoTerm) ? 1 : 0;
+        p.truncated[i] = (bits & kInfoTrunc) ? 1 : 0;
+    }
+}
+
 // ---------------------------------------------------------------- K2 masked reset
 template <typename T>
 __global__ __launch_bounds__(kTile) void reset_kernel(Vec4<T>* state, const T* tmpl, const uint8_t* mask, T* obs,
@@ -285,11 +436,20 @@ __global__ void tick_fill_kernel(uint64_t* tick, int64_t tiles, uint64_t v) {
 }
 
 // ---------------------------------------------------------------- launchers
+int64_t g_pair_max_tiles = 512;   // step_kernel_pair up to 32 768 drones: P and H waves then land on different SIMDs
+                                  // (measured: -14 % at 4 096, -5 % at 32 768, tie at 65 536, +30 % at 131 072)
+
 template <typename T>
 hipError_t launch_step(const StepArgs<T>& a, bool noise, hipStream_t s) {
     const int64_t tiles = (a.n + kTile - 1) / kTile;
     const bool fused = a.done || a.ret || a.partials;
     if constexpr (sizeof(T) == 4) {
+        // few enough tiles that the chip would sit at one wave per SIMD: physics wave + helper wave per tile
+        if (noise && g_pair_max_tiles > 0 && tiles <= g_pair_max_tiles) {
+            if (fused) hipLaunchKernelGGL((step_kernel_pair<true>), dim3((unsigned)tiles), dim3(2 * kTile), 0, s, a);
+            else hipLaunchKernelGGL((step_kernel_pair<false>), dim3((unsigned)tiles), dim3(2 * kTile), 0, s, a);
+            return hipGetLastError();
+        }
         if (fused) {
             if (noise) hipLaunchKernelGGL((step_kernel<T, true, true>), dim3((unsigned)tiles), dim3(kTile), 0, s, a);
             else hipLaunchKernelGGL((step_kernel<T, false, true>), dim3((unsigned)tiles), dim3(kTile), 0, s, a);

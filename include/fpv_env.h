@@ -231,6 +231,12 @@ int fpv_policy_forward(fpv_policy* pol, const fpv_policy_io* io, void* stream);
  * in fp32 accumulators (error at the level of one fp32 rounding, 2.7x fewer matrix-pipe cycles). */
 int fpv_policy_set_gemm(fpv_policy* pol, int32_t mode);
 
+/* Process-wide tuning knob: hover handles with at most `max_drones` drones (default 32 768) run the env step as a
+ * physics wave + helper wave pair per 64-drone tile (the helper draws the motor noise one sub-step pair ahead and
+ * stores the observation tile); that pays while the helper wave finds a SIMD of its own.  Larger handles use the
+ * single-wave kernel.  0 disables the pair kernel.  Results are bit-identical either way. */
+int fpv_set_pair_threshold(int64_t max_drones);
+
 /* Launches an empty kernel on `stream`: the floor of this library's launch path, for calibrating event timings. */
 int fpv_noop(void* stream);
 

@@ -90,3 +90,37 @@ def test_handle_churn_does_not_leak():
     torch.cuda.empty_cache()
     torch.cuda.synchronize()
     assert free0 - torch.cuda.mem_get_info()[0] < 64 * 2 ** 20           # nothing accumulates across create/destroy
+
+
+def test_pair_and_single_wave_kernels_are_bit_identical():
+    """fpv_set_pair_threshold only changes the schedule (physics wave + helper wave), never the results."""
+    from fpv_drone_rl_agent_amd import _lib as L
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.synthetic import synthetic_states
+    lib = L.load()
+    n = 3000
+    st0 = synthetic_states(n, seed=4).astype(np.float32)
+    st0[::5, 34] = 401
+    outs = []
+    for thr in (0, 1 << 30):
+        lib.fpv_set_pair_threshold(thr)
+        eng = FpvEngine(n, 0, seed=9)
+        eng.set_state(torch.from_numpy(st0))
+        g = torch.Generator(device="cuda").manual_seed(0)
+        done = torch.zeros(n, dtype=torch.uint8, device="cuda"); ret = torch.zeros(n, device="cuda")
+        part = torch.zeros((eng.tiles, 44), dtype=torch.float64, device="cuda")
+        rews = []
+        for t in range(5):
+            a = torch.rand(n, 4, device="cuda", generator=g) * 2 - 1
+            if t % 2:
+                eng.step_fused(a, done=done, ret=ret, partials=part)
+            else:
+                eng.step(a)
+            rews.append(eng.reward.clone())
+        led = eng.ledger_read()
+        outs.append((eng.get_state().clone(), eng.obs.clone(), torch.stack(rews), ret.clone(), part.clone(), led["idx"], led["obs"]))
+        eng.close()
+    lib.fpv_set_pair_threshold(32768)
+    for a, b in zip(outs[0][:5], outs[1][:5]):
+        assert torch.equal(a, b)
+    assert np.array_equal(outs[0][5], outs[1][5]) and np.array_equal(outs[0][6], outs[1][6])
