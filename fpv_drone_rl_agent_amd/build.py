@@ -37,7 +37,10 @@ def build_extension(force: bool = False, verbose: bool = False) -> str:
         return LIB_PATH
     srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
     extra = os.environ.get("FPV_EXTRA_HIPCC_FLAGS", "").split()
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + extra + ["-o", LIB_PATH] + srcs
+    # -ffp-contract=on: a*b+c fuses only inside one source expression, so the same device function yields the same
+    # bits in every kernel it is inlined into (the default "fast" also fuses across statements, context-dependent)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fPIC", "-shared"] + extra + \
+          ["-o", LIB_PATH] + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
