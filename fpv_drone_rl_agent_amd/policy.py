@@ -42,6 +42,13 @@ class _SplitKLinear(torch.autograd.Function):
         return gx, gw, g.sum(0)
 
 
+def _linear(lin: nn.Linear, x: torch.Tensor) -> torch.Tensor:
+    """lin(x), with the split-K weight gradient when a large batch is being differentiated."""
+    if torch.is_grad_enabled() and x.shape[0] >= 4096 and x.is_cuda:
+        return _SplitKLinear.apply(x.contiguous(), lin.weight, lin.bias)
+    return lin(x)
+
+
 def _trunk(seq: nn.Sequential, x: torch.Tensor) -> torch.Tensor:
     """seq(x) with split-K weight gradients for the Linear layers when a large batch is being differentiated."""
     if not (torch.is_grad_enabled() and x.shape[0] >= 4096 and x.is_cuda):
@@ -71,7 +78,27 @@ class ActorCritic(nn.Module):
         nn.init.zeros_(self.value_net.bias)
 
     def mean_value(self, obs: torch.Tensor):
-        return self.action_net(_trunk(self.pi, obs)), self.value_net(_trunk(self.vf, obs)).squeeze(-1)
+        return _linear(self.action_net, _trunk(self.pi, obs)), _linear(self.value_net, _trunk(self.vf, obs)).squeeze(-1)
+
+    def flatten_parameters(self):
+        """Re-home every parameter (and its gradient) as a view into ONE contiguous buffer, so that the optimiser
+        step, the gradient clip, the zeroing and the cross-rank all-reduce are single-tensor operations instead of
+        thirteen small ones each.  Returns (flat_param, flat_grad); state_dict keys and shapes are unchanged."""
+        params = list(self.parameters())
+        n = sum(p.numel() for p in params)
+        dev, dt = params[0].device, params[0].dtype
+        flat = nn.Parameter(torch.empty(n, device=dev, dtype=dt))
+        flat.grad = torch.zeros(n, device=dev, dtype=dt)
+        o = 0
+        with torch.no_grad():
+            for p in params:
+                k = p.numel()
+                flat.data[o:o + k].copy_(p.data.reshape(-1))
+                p.data = flat.data[o:o + k].view_as(p)
+                p.grad = flat.grad[o:o + k].view_as(p)
+                o += k
+        self._flat = (flat, flat.grad)
+        return self._flat
 
     def value(self, obs: torch.Tensor):
         return self.value_net(self.vf(obs)).squeeze(-1)

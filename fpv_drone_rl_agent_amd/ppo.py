@@ -27,7 +27,9 @@ class PPO:
         # capturable Adam: its step counter lives on the device, so one minibatch update (forward, loss, backward,
         # gradient all-reduce, clip, Adam) can be captured once into a HIP graph and replayed
         self.use_graph = bool(use_graph) and next(self.policy.parameters()).is_cuda
-        self.opt = torch.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5, capturable=self.use_graph)
+        # all parameters / gradients live in one flat buffer: one Adam, one clip, one all-reduce per minibatch
+        self._flat, self._flat_grad = self.policy.flatten_parameters()
+        self.opt = torch.optim.Adam([self._flat], lr=learning_rate, eps=1e-5, capturable=self.use_graph)
         self._mb_graph = None
         self.n_epochs, self.n_minibatches = n_epochs, n_minibatches
         self.clip_range, self.ent_coef, self.vf_coef = clip_range, ent_coef, vf_coef
@@ -41,19 +43,14 @@ class PPO:
         w = D.world_size()
         if w == 1:
             return
-        grads = [p.grad for p in self.policy.parameters() if p.grad is not None]
-        flat = torch.cat([g.reshape(-1) for g in grads])
+        flat = self._flat_grad
         if td.get_backend() == "gloo" and flat.is_cuda:
             host = flat.cpu()
             td.all_reduce(host)
-            flat = host.to(flat.device)
+            flat.copy_(host.to(flat.device))
         else:
             td.all_reduce(flat)
         flat /= w
-        o = 0
-        for g in grads:
-            g.copy_(flat[o:o + g.numel()].view_as(g))
-            o += g.numel()
 
     def _minibatch_update(self, obs, act, old_lp, ret, adv):
         """One clipped-surrogate + value-loss step; returns the detached statistics vector."""
@@ -62,10 +59,10 @@ class PPO:
         pg = -torch.min(adv * ratio, adv * torch.clamp(ratio, 1 - self.clip_range, 1 + self.clip_range)).mean()
         vl = torch.nn.functional.mse_loss(v, ret)
         loss = pg + self.vf_coef * vl - self.ent_coef * ent.mean()
-        self.opt.zero_grad(set_to_none=False)
-        loss.backward()
+        self._flat_grad.zero_()
+        loss.backward()                      # accumulates into the views of the flat gradient buffer
         self._allreduce_grads()
-        torch.nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
+        torch.nn.utils.clip_grad_norm_([self._flat], self.max_grad_norm)
         self.opt.step()
         with torch.no_grad():
             log_ratio = lp - old_lp
