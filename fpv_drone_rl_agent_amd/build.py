@@ -35,12 +35,27 @@ def build_extension(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/*.hip into libfpv_env.so for gfx950.  Returns the library path."""
     if not force and not _stale():
         return LIB_PATH
-    srcs = [os.path.join(CSRC, f) for f in SOURCES if os.path.exists(os.path.join(CSRC, f))]
     extra = os.environ.get("FPV_EXTRA_HIPCC_FLAGS", "").split()
-    # -ffp-contract=on: a*b+c fuses only inside one source expression, so the same device function yields the same
-    # bits in every kernel it is inlined into (the default "fast" also fuses across statements, context-dependent)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=on", "-fPIC", "-shared"] + extra + \
-          ["-o", LIB_PATH] + srcs
+    base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + extra
+    objdir = os.path.join(_HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    objs = []
+    for f in SOURCES:
+        src = os.path.join(CSRC, f)
+        if not os.path.exists(src):
+            continue
+        # Env kernels: -ffp-contract=on — a*b+c fuses only inside one source expression, so the same device function
+        # yields the same bits in every kernel it is inlined into (pair == single-wave step, shard independence); the
+        # default "fast" also fuses across statements, which depends on the surrounding kernel.  The policy kernels
+        # have no such twin and keep "fast" (2 us quicker).
+        contract = "fast" if f.startswith("fpv_policy") else "on"
+        obj = os.path.join(objdir, f.replace(".hip", ".o"))
+        cmd = base + [f"-ffp-contract={contract}", "-c", "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd, cwd=CSRC)
+        objs.append(obj)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
