@@ -50,6 +50,16 @@ class FpvPolicyIo(C.Structure):
     ]
 
 
+class FpvPpoIo(C.Structure):
+    _fields_ = [
+        ("rows", C.c_int64), ("index", C.c_void_p), ("obs", C.c_void_p), ("actions", C.c_void_p),
+        ("old_logp", C.c_void_p), ("advantages", C.c_void_p), ("returns", C.c_void_p),
+        ("clip_range", C.c_float), ("vf_coef", C.c_float), ("ent_coef", C.c_float), ("reserved0", C.c_float),
+        ("weights", C.c_void_p * 13), ("grads", C.c_void_p * 13), ("stats", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+    ]
+
+
 # every symbol of include/fpv_env.h: name -> (restype, argtypes)
 _vp, _i64, _i32, _f32, _u64 = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_uint64
 SIGNATURES = {
@@ -79,6 +89,9 @@ SIGNATURES = {
     "fpv_policy_set_dims": (C.c_int, [_vp, _i32, _i32]),
     "fpv_policy_set_gemm": (C.c_int, [_vp, _i32]),
     "fpv_policy_forward": (C.c_int, [_vp, C.POINTER(FpvPolicyIo), _vp]),
+    "fpv_ppo_workspace_bytes": (C.c_int, [_vp, _i64, C.POINTER(_i64)]),
+    "fpv_ppo_grad": (C.c_int, [_vp, C.POINTER(FpvPpoIo), _vp]),
+    "fpv_adam_clip_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp]),
     "fpv_set_pair_threshold": (C.c_int, [_i64]),
     "fpv_noop": (C.c_int, [_vp]),
     "fpv_last_error": (C.c_char_p, []),

@@ -12,7 +12,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libfpv_env.so")
-SOURCES = ["fpv_step.hip", "fpv_yaw.hip", "fpv_rollout.hip", "fpv_policy.hip", "fpv_policy_split.hip", "fpv_capi.hip"]
+SOURCES = ["fpv_step.hip", "fpv_yaw.hip", "fpv_rollout.hip", "fpv_policy.hip", "fpv_policy_split.hip", "fpv_ppo.hip", "fpv_capi.hip"]
 HEADERS = ["fpv_dynamics.h", "fpv_internal.h", os.path.join("..", "..", "include", "fpv_env.h")]
 
 
@@ -48,7 +48,7 @@ def build_extension(force: bool = False, verbose: bool = False) -> str:
         # yields the same bits in every kernel it is inlined into (pair == single-wave step, shard independence); the
         # default "fast" also fuses across statements, which depends on the surrounding kernel.  The policy kernels
         # have no such twin and keep "fast" (2 us quicker).
-        contract = "fast" if f.startswith("fpv_policy") else "on"
+        contract = "fast" if f.startswith(("fpv_policy", "fpv_ppo")) else "on"
         obj = os.path.join(objdir, f.replace(".hip", ".o"))
         cmd = base + [f"-ffp-contract={contract}", "-c", "-o", obj, src]
         if verbose:

@@ -460,4 +460,44 @@ int fpv_policy_forward(fpv_policy* p, const fpv_policy_io* io, void* stream) {
     return FPV_OK;
 }
 
+int fpv_ppo_workspace_bytes(fpv_policy* p, int64_t rows, int64_t* bytes) {
+    if (!p || !bytes || rows <= 0) return fail(FPV_ERR_ARG, "fpv_ppo_workspace_bytes: null argument or rows <= 0");
+    *bytes = ppo_workspace_floats(rows, p->cus) * (int64_t)sizeof(float);
+    return FPV_OK;
+}
+
+int fpv_ppo_grad(fpv_policy* p, const fpv_ppo_io* io, void* stream) {
+    if (!p || !io) return fail(FPV_ERR_ARG, "fpv_ppo_grad: null argument");
+    if (io->rows <= 0 || !io->obs || !io->actions || !io->old_logp || !io->advantages || !io->returns || !io->stats ||
+        !io->workspace)
+        return fail(FPV_ERR_ARG, "fpv_ppo_grad: rows, obs, actions, old_logp, advantages, returns, stats and workspace are required");
+    for (int i = 0; i < 13; ++i)
+        if (!io->weights[i] || !io->grads[i]) return fail(FPV_ERR_ARG, "fpv_ppo_grad: weight / gradient pointer %d is null", i);
+    const uintptr_t act_rows = p->act_dim == 4 ? (uintptr_t)io->actions : 0;
+    if (((uintptr_t)io->obs | act_rows | (uintptr_t)io->workspace) & 15)
+        return fail(FPV_ERR_ARG, "fpv_ppo_grad: row buffers and workspace must be 16-byte aligned");
+    const int64_t need = ppo_workspace_floats(io->rows, p->cus) * (int64_t)sizeof(float);
+    if (io->workspace_bytes < need)
+        return fail(FPV_ERR_ARG, "fpv_ppo_grad: workspace of %lld bytes, %lld needed (fpv_ppo_workspace_bytes)",
+                    (long long)io->workspace_bytes, (long long)need);
+    FPV_HIP(launch_ppo_grad(io->weights, io->grads, io->index, io->obs, io->actions, io->old_logp, io->advantages, io->returns,
+                            io->rows, io->clip_range, io->vf_coef, io->ent_coef, io->stats, (float*)io->workspace, p->in_dim,
+                            p->act_dim, p->cus, (hipStream_t)stream));
+    return FPV_OK;
+}
+
+int fpv_adam_clip_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t* step,
+                       float* grad_norm, int64_t n, float lr, float beta1, float beta2, float eps, float max_grad_norm,
+                       void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !step || n <= 0)
+        return fail(FPV_ERR_ARG, "fpv_adam_clip_step: null argument or n <= 0");
+    if (n > (1 << 20))
+        return fail(FPV_ERR_UNSUPPORTED, "fpv_adam_clip_step: built for policy-sized tensors (n <= 2^20): every workgroup recomputes the norm");
+    if (!(lr >= 0.f) || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) || !(eps > 0.f))
+        return fail(FPV_ERR_ARG, "fpv_adam_clip_step: need lr >= 0, betas in [0, 1), eps > 0");
+    FPV_HIP(launch_adam_clip(param, grad, exp_avg, exp_avg_sq, step, grad_norm, n, lr, beta1, beta2, eps, max_grad_norm,
+                             (hipStream_t)stream));
+    return FPV_OK;
+}
+
 }  // extern "C"

@@ -1,0 +1,654 @@
+// fpv_ppo.hip — gradient of the PPO minibatch loss (SB3 PPO.train, the learner north_star puts in place of the SAC of
+// simulation/train_hover.py:47-60) for the MlpPolicy of fpv_policy.hip, as hand-written gfx950 kernels:
+//
+//   U0 ppo_pack_kernel     live nn.Linear tensors -> MFMA-ordered training image (forward operands + W2^T, Wa^T)
+//   U1 ppo_fwd_bwd_kernel  per row: pi and V forward, clipped-surrogate / value-loss derivatives, backward through the
+//                          heads and layer 2 — all in registers, transposed like the rollout kernel (drones on the MFMA
+//                          column, an accumulator tile is the next product's B operand as it stands, in both directions).
+//                          Emits H1, H2, D1 = dL/dZ1, D2 = dL/dZ2 per net (row-major [rows][128]) and d mu, d v.
+//   U2 ppo_wgrad_kernel    dW = D^T H as MFMA products whose K index is the row: both operands are read from the
+//                          row-major matrices as they lie (32 consecutive columns per half-wave, no transposes);
+//                          every workgroup reduces a slab of rows, slabs are summed in fixed order by
+//   U3 ppo_reduce_kernel   -> the 13 gradient tensors + {pg loss, value loss, approx KL, clip fraction}.
+// fp32 throughout (v_mfma_f32_32x32x2_f32); no atomics: the result is bitwise reproducible for a given launch shape.
+#include "fpv_internal.h"
+
+namespace fpv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int kHid = 128;
+// per-net training image (floats): W1p | b1 | W2p | b2 | W2Tp
+constexpr int kTOffW1 = 0, kTOffB1 = 3072, kTOffW2 = 3200, kTOffB2 = 19584, kTOffW2T = 19712, kTNet = 36096;
+// head block: Wa[h][kt][r][4] | Wv[h][kt][r] | ba[4] | bv (pad 4) | log_std[4] | inv_std[4] | logp const (pad 4) | WaT[m][s][lane]
+constexpr int kTHead = 2 * kTNet;
+constexpr int kHWa = 0, kHWv = 512, kHBa = 640, kHBv = 644, kHLogStd = 648, kHInvStd = 652, kHLpc = 656, kHWaT = 660;
+constexpr int kHeadFloats = 660 + 512;                  // 1172
+constexpr int kTImage = kTHead + kHeadFloats;
+// U2 partial layout per (net, slab)
+constexpr int kPW1 = 0, kPB1 = 3072, kPW2 = 3200, kPB2 = 19584, kPWh = 19712, kPBh = 20224, kPartStride = 20232;
+constexpr int kWaveStats = 8;                           // pg, vl, kl, clip fraction, d log_std[4]
+
+__host__ __device__ constexpr int tile_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+struct Hidden {
+    f32x16 t[4];
+};
+
+__device__ __forceinline__ float fast_tanh(float x) {
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+__device__ __forceinline__ void bias_init(Hidden& a, const float* __restrict__ lb, int h) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const f32x4* b = reinterpret_cast<const f32x4*>(lb + (m * 2 + h) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = b[q];
+            a.t[m][4 * q] = v.x; a.t[m][4 * q + 1] = v.y; a.t[m][4 * q + 2] = v.z; a.t[m][4 * q + 3] = v.w;
+        }
+    }
+}
+
+__device__ __forceinline__ void tanh_all(Hidden& a) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a.t[m][r] = fast_tanh(a.t[m][r]);
+}
+
+// lane (col, h) holds rows tile_row(r, h) of each 32-row tile: four consecutive rows per register quad -> 16-byte stores
+__device__ __forceinline__ void store_rows(float* __restrict__ mat, int64_t n, const Hidden& t, int h) {
+    f32x4* row = reinterpret_cast<f32x4*>(mat + n * kHid);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            row[m * 8 + 2 * q + h] = f32x4{t.t[m][4 * q], t.t[m][4 * q + 1], t.t[m][4 * q + 2], t.t[m][4 * q + 3]};
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- U0: training image
+struct PpoParams {
+    const float *pi_w1, *pi_b1, *pi_w2, *pi_b2, *wa, *ba, *log_std;
+    const float *vf_w1, *vf_b1, *vf_w2, *vf_b2, *wv, *bv;
+    int in_dim, act_dim;
+};
+
+__global__ void ppo_pack_kernel(PpoParams p, float* __restrict__ img) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= kTImage) return;
+    float v = 0.0f;
+    if (e < kTHead) {
+        const int net = e / kTNet, o = e % kTNet;
+        const float* w1 = net ? p.vf_w1 : p.pi_w1;
+        const float* b1 = net ? p.vf_b1 : p.pi_b1;
+        const float* w2 = net ? p.vf_w2 : p.pi_w2;
+        const float* b2 = net ? p.vf_b2 : p.pi_b2;
+        if (o < kTOffB1) {                      // W1p[m][s][lane] = W1[m*32 + i][s + 12 h]
+            const int lane = o % 64, s = (o / 64) % 12, m = o / (64 * 12);
+            const int k = s + 12 * (lane >> 5);
+            v = k < p.in_dim ? w1[(m * 32 + (lane & 31)) * p.in_dim + k] : 0.0f;
+        } else if (o < kTOffW2) {               // b1p[m][h][r]
+            const int q = o - kTOffB1, r = q % 16, h = (q / 16) % 2, m = q / 32;
+            v = b1[m * 32 + tile_row(r, h)];
+        } else if (o < kTOffB2) {               // W2p[m][kt][r4][lane][rr] = W2[m*32 + i][kt*32 + row(4 r4 + rr, h)]
+            const int q = o - kTOffW2, rr = q % 4, lane = (q / 4) % 64, r4 = (q / 256) % 4, kt = (q / 1024) % 4, m = q / 4096;
+            v = w2[(m * 32 + (lane & 31)) * kHid + kt * 32 + tile_row(4 * r4 + rr, lane >> 5)];
+        } else if (o < kTOffW2T) {
+            const int q = o - kTOffB2, r = q % 16, h = (q / 16) % 2, m = q / 32;
+            v = b2[m * 32 + tile_row(r, h)];
+        } else {                                // W2Tp[m][kt][r4][lane][rr] = W2[kt*32 + row(4 r4 + rr, h)][m*32 + i]
+            const int q = o - kTOffW2T, rr = q % 4, lane = (q / 4) % 64, r4 = (q / 256) % 4, kt = (q / 1024) % 4, m = q / 4096;
+            v = w2[(kt * 32 + tile_row(4 * r4 + rr, lane >> 5)) * kHid + m * 32 + (lane & 31)];
+        }
+    } else {
+        const int q = e - kTHead;
+        if (q < 512) {                          // Wa[h][kt][r][o]
+            const int o = q % 4, r = (q / 4) % 16, kt = (q / 64) % 4, h = q / 256;
+            v = o < p.act_dim ? p.wa[o * kHid + kt * 32 + tile_row(r, h)] : 0.0f;
+        } else if (q < 640) {                   // Wv[h][kt][r]
+            const int z = q - 512, r = z % 16, kt = (z / 16) % 4, h = z / 64;
+            v = p.wv[kt * 32 + tile_row(r, h)];
+        } else if (q < 644) v = q - 640 < p.act_dim ? p.ba[q - 640] : 0.0f;
+        else if (q == 644) v = p.bv[0];
+        else if (q >= 648 && q < 652) v = q - 648 < p.act_dim ? p.log_std[q - 648] : 0.0f;
+        else if (q >= 652 && q < 656) v = q - 652 < p.act_dim ? expf(-p.log_std[q - 652]) : 0.0f;
+        else if (q == 656) {
+            for (int j = 0; j < p.act_dim; ++j) v -= p.log_std[j] + 0.5f * 1.8378770664093453f;
+        } else if (q >= kHWaT) {                // WaT[m][s][lane] = Wa[h + 2 s][m*32 + i]
+            const int z = q - kHWaT, lane = z % 64, s = (z / 64) % 2, m = z / 128;
+            const int j = (lane >> 5) + 2 * s;
+            v = j < p.act_dim ? p.wa[j * kHid + m * 32 + (lane & 31)] : 0.0f;
+        }
+    }
+    img[e] = v;
+}
+
+// ---------------------------------------------------------------- U1: forward + backward through the activations
+struct PpoArgs {
+    const float* image;
+    const int64_t* index;     // [rows] gather indices into the rollout arrays, or null
+    const float* obs;         // [*][in_dim] normalised observations
+    const float* actions;     // [*][act_dim]
+    const float* old_logp;    // [*]
+    const float* adv;         // [*]
+    const float* ret;         // [*]
+    float* mats;              // [2][4][rows][128]: H1, H2, D1, D2 per net
+    float* xg;                // [rows][in_dim] gathered observations (U2's operand for dW1)
+    float* dmu;               // [rows][4]
+    float* dv;                // [rows]
+    float* wave_stats;        // [blocks * waves][8]
+    int64_t rows;
+    float clip_range, vf_coef, inv_rows;
+    int32_t in_dim, act_dim;
+};
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void ppo_fwd_bwd_kernel(PpoArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* hb = lds + kTNet;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    constexpr int kChunk = THREADS / 2;
+    float st[kWaveStats] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int net = 0; net < 2; ++net) {
+        if (net) __syncthreads();               // every wave is done reading the pi image
+        {
+            const f32x4* src = reinterpret_cast<const f32x4*>(p.image + (size_t)net * kTNet);
+            f32x4* dst = reinterpret_cast<f32x4*>(lds);
+            constexpr int kGran = kTNet / 4, kPer = (kGran + THREADS - 1) / THREADS, kBatch = 12;
+            for (int q0 = 0; q0 < kPer; q0 += kBatch) {
+                f32x4 stage[kBatch];
+#pragma unroll
+                for (int q = 0; q < kBatch; ++q) {
+                    const int g = (q0 + q) * THREADS + threadIdx.x;
+                    stage[q] = src[g < kGran ? g : 0];
+                }
+#pragma unroll
+                for (int q = 0; q < kBatch; ++q) {
+                    const int g = (q0 + q) * THREADS + threadIdx.x;
+                    if (g < kGran) dst[g] = stage[q];
+                }
+            }
+            if (net == 0)
+                for (int g = threadIdx.x; g < kHeadFloats / 4; g += THREADS)
+                    reinterpret_cast<f32x4*>(hb)[g] = reinterpret_cast<const f32x4*>(p.image + kTHead)[g];
+        }
+        __syncthreads();
+        float* H1 = p.mats + (size_t)(net * 4 + 0) * p.rows * kHid;
+        float* H2 = p.mats + (size_t)(net * 4 + 1) * p.rows * kHid;
+        float* D1 = p.mats + (size_t)(net * 4 + 2) * p.rows * kHid;
+        float* D2 = p.mats + (size_t)(net * 4 + 3) * p.rows * kHid;
+
+#pragma unroll 1
+        for (int64_t base = (int64_t)blockIdx.x * kChunk; base < p.rows; base += (int64_t)gridDim.x * kChunk) {
+            const int64_t n = base + wave * 32 + col;
+            const bool live = n < p.rows;
+            const int64_t src = live ? (p.index ? p.index[n] : n) : 0;
+            float x[12];
+            {
+                const f32x4* row = reinterpret_cast<const f32x4*>(p.obs + src * p.in_dim);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const bool have = live && 4 * (3 * h + q) < p.in_dim;
+                    const f32x4 v = have ? row[3 * h + q] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+                    if (net == 0 && have) reinterpret_cast<f32x4*>(p.xg + n * p.in_dim)[3 * h + q] = v;
+                }
+            }
+            // ---- forward
+            Hidden a;
+            bias_init(a, lds + kTOffB1, h);
+#pragma unroll
+            for (int s = 0; s < 12; ++s)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    a.t[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[kTOffW1 + (m * 12 + s) * 64 + lane], x[s], a.t[m], 0, 0, 0);
+            tanh_all(a);
+            if (live) store_rows(H1, n, a, h);
+            Hidden c;
+            bias_init(c, lds + kTOffB2, h);
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    f32x4 w[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        w[m] = *reinterpret_cast<const f32x4*>(lds + kTOffW2 + ((((m * 4 + kt) * 4 + r4) * 64 + lane) * 4));
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+                            c.t[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[m][rr], a.t[kt][4 * r4 + rr], c.t[m], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);   // keep the operand loads of later k-steps out of this one
+                }
+            tanh_all(c);
+            if (live) store_rows(H2, n, c, h);
+
+            // ---- heads, loss derivatives, g = dL/dH2
+            Hidden g;
+            if (net == 0) {
+                float mu[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(hb + kHWa + (((h * 4 + kt) * 16 + r) * 4));
+                        const float v = c.t[kt][r];
+                        mu[0] += w.x * v; mu[1] += w.y * v; mu[2] += w.z * v; mu[3] += w.w * v;
+                    }
+                float act[4] = {0.f, 0.f, 0.f, 0.f};
+                if (live) {
+                    if (p.act_dim == 4) {
+                        const f32x4 v = reinterpret_cast<const f32x4*>(p.actions)[src];
+                        act[0] = v.x; act[1] = v.y; act[2] = v.z; act[3] = v.w;
+                    } else {
+                        for (int j = 0; j < p.act_dim; ++j) act[j] = p.actions[src * p.act_dim + j];
+                    }
+                }
+                const float old_lp = live ? p.old_logp[src] : 0.f, adv = live ? p.adv[src] : 0.f;
+                float z[4], lp = hb[kHLpc];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    mu[j] += __shfl_xor(mu[j], 32);
+                    mu[j] += hb[kHBa + j];
+                    z[j] = (act[j] - mu[j]) * hb[kHInvStd + j];      // inv_std is 0 beyond act_dim
+                    lp -= 0.5f * z[j] * z[j];
+                }
+                const float lr = lp - old_lp, ratio = __expf(lr);
+                const float lo = 1.0f - p.clip_range, hi = 1.0f + p.clip_range;
+                const float pg1 = adv * ratio, pg2 = adv * fminf(fmaxf(ratio, lo), hi);
+                const float glp = (live && pg1 <= pg2) ? -adv * ratio * p.inv_rows : 0.f;
+                float dmu[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dmu[j] = glp * z[j] * hb[kHInvStd + j];
+                if (live && h == 0) {
+                    reinterpret_cast<f32x4*>(p.dmu)[n] = f32x4{dmu[0], dmu[1], dmu[2], dmu[3]};
+                    st[0] -= fminf(pg1, pg2);
+                    st[2] += (ratio - 1.0f) - lr;
+                    st[3] += fabsf(ratio - 1.0f) > p.clip_range ? 1.0f : 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) st[4 + j] += j < p.act_dim ? glp * (z[j] * z[j] - 1.0f) : 0.f;
+                }
+                // g^T = Wa^T . dmu^T : K = 4 action components = two k-steps; this half supplies component h + 2 s
+                const float b0 = h ? dmu[1] : dmu[0], b1 = h ? dmu[3] : dmu[2];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    f32x16 acc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hb[kHWaT + (m * 2 + 0) * 64 + lane], b0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hb[kHWaT + (m * 2 + 1) * 64 + lane], b1, acc, 0, 0, 0);
+                    g.t[m] = acc;
+                }
+            } else {
+                float v = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v += hb[kHWv + (h * 4 + kt) * 16 + r] * c.t[kt][r];
+                v += __shfl_xor(v, 32);
+                v += hb[kHBv];
+                const float ret = live ? p.ret[src] : 0.f;
+                const float err = live ? v - ret : 0.f;
+                const float dv = p.vf_coef * 2.0f * err * p.inv_rows;
+                if (live && h == 1) {
+                    p.dv[n] = dv;
+                    st[1] += err * err;
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) g.t[m][r] = hb[kHWv + (h * 4 + m) * 16 + r] * dv;
+            }
+            // ---- D2 = g * (1 - H2^2)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) g.t[m][r] *= 1.0f - c.t[m][r] * c.t[m][r];
+            if (live) store_rows(D2, n, g, h);
+            // ---- dH1^T = W2^T . D2^T : the D2 tiles are the B operands as they stand
+            Hidden e;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) e.t[m][r] = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    f32x4 w[4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        w[m] = *reinterpret_cast<const f32x4*>(lds + kTOffW2T + ((((m * 4 + kt) * 4 + r4) * 64 + lane) * 4));
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+                            e.t[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[m][rr], g.t[kt][4 * r4 + rr], e.t[m], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) e.t[m][r] *= 1.0f - a.t[m][r] * a.t[m][r];
+            if (live) store_rows(D1, n, e, h);
+        }
+    }
+    // ---- per-wave statistics (fixed lane order)
+#pragma unroll
+    for (int k = 0; k < kWaveStats; ++k) {
+        float v = st[k];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) p.wave_stats[((size_t)blockIdx.x * (THREADS / 64) + wave) * kWaveStats + k] = v;
+    }
+}
+
+// ---------------------------------------------------------------- U2: weight gradients, K = rows
+struct WgradArgs {
+    const float* mats;        // [2][4][rows][128]
+    const float* xg;          // [rows][in_dim]
+    const float* dmu;         // [rows][4]
+    const float* dv;          // [rows]
+    float* part;              // [2][slabs][kPartStride]
+    int64_t rows;
+    int32_t rows_per_slab, slabs, in_dim, act_dim;
+};
+
+namespace {
+struct Ops {
+    float a2, a1, ah, x, hh, b[4];
+};
+}  // namespace
+
+// 256 threads: wave w owns output rows 32 w .. 32 w + 31 of dW2 (four 32-column tiles) and dW1, and columns
+// 32 w .. 32 w + 31 of the head gradient.  blockIdx.y = net, blockIdx.x = slab of rows.
+__global__ __launch_bounds__(256) void ppo_wgrad_kernel(WgradArgs p) {
+    const int net = blockIdx.y, slab = blockIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = lane & 31, kk = lane >> 5;
+    const float* H1 = p.mats + (size_t)(net * 4 + 0) * p.rows * kHid;
+    const float* H2 = p.mats + (size_t)(net * 4 + 1) * p.rows * kHid;
+    const float* D1 = p.mats + (size_t)(net * 4 + 2) * p.rows * kHid;
+    const float* D2 = p.mats + (size_t)(net * 4 + 3) * p.rows * kHid;
+    const int nh = net == 0 ? p.act_dim : 1;
+    const int64_t n0 = (int64_t)slab * p.rows_per_slab;
+    const int64_t n1 = n0 + p.rows_per_slab < p.rows ? n0 + p.rows_per_slab : p.rows;
+
+    f32x16 w2[4], w1, hd;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        w2[0][r] = 0.f; w2[1][r] = 0.f; w2[2][r] = 0.f; w2[3][r] = 0.f; w1[r] = 0.f; hd[r] = 0.f;
+    }
+    float sb2 = 0.f, sb1 = 0.f, sbh = 0.f;
+
+    auto load = [&](Ops& o, int64_t n) {
+        const int64_t row = n + kk;
+        const bool ok = row < n1;
+        const int64_t r = ok ? row : n0;
+        const float a2 = D2[r * kHid + 32 * w + i], a1 = D1[r * kHid + 32 * w + i], hh = H2[r * kHid + 32 * w + i];
+        const float ah = i < nh ? (net == 0 ? p.dmu[r * 4 + i] : p.dv[r]) : 0.f;
+        const float x = i < p.in_dim ? p.xg[r * p.in_dim + i] : 0.f;
+        o.a2 = ok ? a2 : 0.f; o.a1 = ok ? a1 : 0.f; o.hh = hh; o.ah = ok ? ah : 0.f; o.x = x;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) o.b[jt] = H1[r * kHid + 32 * jt + i];
+    };
+    auto fma = [&](const Ops& o) {
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) w2[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a2, o.b[jt], w2[jt], 0, 0, 0);
+        w1 = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a1, o.x, w1, 0, 0, 0);
+        hd = __builtin_amdgcn_mfma_f32_32x32x2f32(o.ah, o.hh, hd, 0, 0, 0);
+        sb2 += o.a2; sb1 += o.a1; sbh += o.ah;
+    };
+
+    constexpr int U = 4;                        // k-steps (pairs of rows) per register group
+    Ops A[U], B[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) load(A[u], n0 + 2 * u);
+#pragma unroll 1
+    for (int64_t n = n0; n < n1; n += 4 * U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) load(B[u], n + 2 * U + 2 * u);
+#pragma unroll
+        for (int u = 0; u < U; ++u) fma(A[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) load(A[u], n + 4 * U + 2 * u);
+#pragma unroll
+        for (int u = 0; u < U; ++u) fma(B[u]);
+    }
+
+    float* out = p.part + ((size_t)net * p.slabs + slab) * kPartStride;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int o = 32 * w + tile_row(r, kk);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) out[kPW2 + o * kHid + 32 * jt + i] = w2[jt][r];
+        if (i < p.in_dim) out[kPW1 + o * p.in_dim + i] = w1[r];
+    }
+    if (kk == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < nh) out[kPWh + r * kHid + 32 * w + i] = hd[r];
+    }
+    sb2 += __shfl_xor(sb2, 32); sb1 += __shfl_xor(sb1, 32); sbh += __shfl_xor(sbh, 32);
+    if (kk == 0) {
+        out[kPB2 + 32 * w + i] = sb2;
+        out[kPB1 + 32 * w + i] = sb1;
+        if (w == 0 && i < nh) out[kPBh + i] = sbh;
+    }
+}
+
+// ---------------------------------------------------------------- U3: fixed-order sums -> gradient tensors + statistics
+struct ReduceArgs {
+    const float* part;
+    const float* wave_stats;
+    float* g[13];             // PpoParams order
+    float* stats;             // [4]
+    int32_t slabs, waves, in_dim, act_dim;
+    float inv_rows, ent_coef;
+};
+
+// 256 threads = 8 slab groups x 32 elements: group s sums slabs s, s + 8, ... (independent loads, all in flight), the
+// eight group sums are added in fixed order through LDS.  The last workgroup sums the per-wave statistics instead.
+__global__ __launch_bounds__(256) void ppo_reduce_kernel(ReduceArgs p) {
+    __shared__ float sm[8][32];
+    if (blockIdx.x == gridDim.x - 1) {          // statistics + d log_std: thread = (wave subset j, statistic k)
+        const int k = threadIdx.x & 7, j = threadIdx.x >> 3;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int wv = j;
+        for (; wv + 96 < p.waves; wv += 128) {
+            s0 += p.wave_stats[(size_t)wv * kWaveStats + k]; s1 += p.wave_stats[(size_t)(wv + 32) * kWaveStats + k];
+            s2 += p.wave_stats[(size_t)(wv + 64) * kWaveStats + k]; s3 += p.wave_stats[(size_t)(wv + 96) * kWaveStats + k];
+        }
+        for (; wv < p.waves; wv += 32) s0 += p.wave_stats[(size_t)wv * kWaveStats + k];
+        sm[k][j] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (threadIdx.x < kWaveStats) {
+            float t = 0.f;
+            for (int q = 0; q < 32; ++q) t += sm[threadIdx.x][q];
+            if (threadIdx.x < 4) p.stats[threadIdx.x] = t * p.inv_rows;
+            else if ((int)threadIdx.x - 4 < p.act_dim) p.g[6][threadIdx.x - 4] = t - p.ent_coef;   // -ent_coef * d entropy
+        }
+        return;
+    }
+    const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el;
+    float* dst = nullptr;
+    float sum = 0.f;
+    if (e < 2 * kPartStride) {
+        const int net = e / kPartStride, o = e % kPartStride;
+        const int nh = net == 0 ? p.act_dim : 1;
+        if (o < kPB1) { if (o < kHid * p.in_dim) dst = p.g[net ? 7 : 0] + o; }
+        else if (o < kPW2) dst = p.g[net ? 8 : 1] + (o - kPB1);
+        else if (o < kPB2) dst = p.g[net ? 9 : 2] + (o - kPW2);
+        else if (o < kPWh) dst = p.g[net ? 10 : 3] + (o - kPB2);
+        else if (o < kPBh) { if (o - kPWh < nh * kHid) dst = p.g[net ? 11 : 4] + (o - kPWh); }
+        else if (o - kPBh < nh) dst = p.g[net ? 12 : 5] + (o - kPBh);
+        if (dst) {
+            const float* src = p.part + (size_t)net * p.slabs * kPartStride + o;
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int b = grp + 8 * q;
+                v[q] = b < p.slabs ? src[(size_t)b * kPartStride] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sum += v[q];
+            for (int b = grp + 128; b < p.slabs; b += 8) sum += src[(size_t)b * kPartStride];
+        }
+    }
+    sm[grp][el] = sum;
+    __syncthreads();
+    if (grp == 0 && dst) {
+        float t = sm[0][el];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t += sm[q][el];
+        *dst = t;
+    }
+}
+
+// ---------------------------------------------------------------- U4: gradient clip + Adam on the flat parameter buffer
+// torch.nn.utils.clip_grad_norm_(max_norm) followed by torch.optim.Adam.step() (no weight decay, no amsgrad), for ONE
+// flat tensor of a few 10^4 elements, one launch.
+struct AdamArgs {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t* step;            // device {step count, launch-internal arrival counter}
+    float* grad_norm;         // out (may be null): the norm before clipping
+    int64_t n;
+    float lr, beta1, beta2, eps, max_norm;
+};
+
+// Every 1024-thread workgroup recomputes the norm of the whole gradient (a few 10^4 elements out of L2, the same
+// summation order in every workgroup) and updates its own 1024 elements; the last workgroup to arrive advances the step.
+__global__ __launch_bounds__(1024) void adam_clip_kernel(AdamArgs p) {
+    __shared__ float red[16];
+    __shared__ float bc[3];
+    float ss[4] = {0.f, 0.f, 0.f, 0.f};
+    int64_t i = threadIdx.x;
+    for (; i + 3 * 1024 < p.n; i += 4 * 1024) {
+        const float g0 = p.grad[i], g1 = p.grad[i + 1024], g2 = p.grad[i + 2048], g3 = p.grad[i + 3072];
+        ss[0] += g0 * g0; ss[1] += g1 * g1; ss[2] += g2 * g2; ss[3] += g3 * g3;
+    }
+    for (; i < p.n; i += 1024) {
+        const float g = p.grad[i];
+        ss[0] += g * g;
+    }
+    float s = (ss[0] + ss[1]) + (ss[2] + ss[3]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    const int64_t step = p.step[0] + 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        const float norm = sqrtf(t);
+        if (p.grad_norm && blockIdx.x == 0) *p.grad_norm = norm;
+        bc[0] = p.max_norm > 0.f ? fminf(p.max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
+        bc[1] = p.lr / (1.0f - powf(p.beta1, (float)step));
+        bc[2] = 1.0f / sqrtf(1.0f - powf(p.beta2, (float)step));
+    }
+    __syncthreads();
+    const float coef = bc[0], step_size = bc[1], inv_bc2 = bc[2];
+    const int64_t k = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    if (k < p.n) {
+        const float g = p.grad[k] * coef;
+        const float m = p.beta1 * p.exp_avg[k] + (1.0f - p.beta1) * g;
+        const float v = p.beta2 * p.exp_avg_sq[k] + (1.0f - p.beta2) * g * g;
+        p.exp_avg[k] = m;
+        p.exp_avg_sq[k] = v;
+        p.param[k] -= step_size * m / (sqrtf(v) * inv_bc2 + p.eps);
+    }
+    // every workgroup has read step[0] above; the one that arrives last publishes the new count
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        unsigned long long* arrive = reinterpret_cast<unsigned long long*>(p.step + 1);
+        if (atomicAdd(arrive, 1ull) == (unsigned long long)gridDim.x - 1) {
+            *arrive = 0ull;
+            p.step[0] = step;
+        }
+    }
+}
+
+hipError_t launch_adam_clip(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t* step,
+                            float* grad_norm, int64_t n, float lr, float beta1, float beta2, float eps, float max_norm,
+                            hipStream_t s) {
+    AdamArgs a{param, grad, exp_avg, exp_avg_sq, step, grad_norm, n, lr, beta1, beta2, eps, max_norm};
+    hipLaunchKernelGGL(adam_clip_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, s, a);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- launchers
+static int ppo_slabs(int64_t rows, int* rows_per_slab) {
+    int64_t rps = (rows + 127) / 128;
+    rps = (rps + 15) / 16 * 16;
+    if (rps < 16) rps = 16;
+    *rows_per_slab = (int)rps;
+    return (int)((rows + rps - 1) / rps);
+}
+
+static int ppo_blocks(int64_t rows, int cus) {
+    const int64_t b = (rows + 127) / 128;
+    return (int)(b < cus ? b : cus);
+}
+
+int64_t ppo_workspace_floats(int64_t rows, int cus) {
+    int rps;
+    const int slabs = ppo_slabs(rows, &rps);
+    return (int64_t)kTImage + 8 * rows * kHid + rows * 24 + rows * 4 + rows + (int64_t)ppo_blocks(rows, cus) * 4 * kWaveStats +
+           2 * (int64_t)slabs * kPartStride + 64;
+}
+
+hipError_t launch_ppo_grad(const float* const* w, float* const* grads, const int64_t* index, const float* obs,
+                           const float* actions, const float* old_logp, const float* adv, const float* ret, int64_t rows,
+                           float clip_range, float vf_coef, float ent_coef, float* stats, float* ws, int in_dim, int act_dim,
+                           int cus, hipStream_t s) {
+    static bool attr_set = false;
+    constexpr size_t lds_bytes = (size_t)(kTNet + kHeadFloats) * sizeof(float);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)ppo_fwd_bwd_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    int rps;
+    const int slabs = ppo_slabs(rows, &rps);
+    const int blocks = ppo_blocks(rows, cus);
+    // workspace carve-up (floats; every piece 16-byte aligned)
+    float* image = ws;
+    float* mats = image + kTImage;
+    float* xg = mats + 8 * rows * kHid;
+    float* dmu = xg + rows * 24;
+    float* dv = dmu + rows * 4;
+    float* wave_stats = dv + (rows + 3) / 4 * 4;
+    float* part = wave_stats + (size_t)blocks * 4 * kWaveStats;
+
+    PpoParams pp{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], in_dim, act_dim};
+    hipLaunchKernelGGL(ppo_pack_kernel, dim3((kTImage + 255) / 256), dim3(256), 0, s, pp, image);
+    PpoArgs a{image, index, obs, actions, old_logp, adv, ret, mats, xg, dmu, dv, wave_stats,
+              rows, clip_range, vf_coef, 1.0f / (float)rows, in_dim, act_dim};
+    hipLaunchKernelGGL(ppo_fwd_bwd_kernel<256>, dim3(blocks), dim3(256), lds_bytes, s, a);
+    WgradArgs g{mats, xg, dmu, dv, part, rows, rps, slabs, in_dim, act_dim};
+    hipLaunchKernelGGL(ppo_wgrad_kernel, dim3(slabs, 2), dim3(256), 0, s, g);
+    ReduceArgs r{part, wave_stats, {}, stats, slabs, blocks * 4, in_dim, act_dim, 1.0f / (float)rows, ent_coef};
+    for (int k = 0; k < 13; ++k) r.g[k] = grads[k];
+    hipLaunchKernelGGL(ppo_reduce_kernel, dim3((2 * kPartStride + 31) / 32 + 1), dim3(256), 0, s, r);
+    return hipGetLastError();
+}
+
+}  // namespace fpv

@@ -130,3 +130,51 @@ def reward_finalize(raw, snapshots, clip=10.0, eps=1e-8, out=None):
 def noop(device) -> None:
     """Empty kernel through the library's launch path (timing calibration)."""
     L.check(L.load().fpv_noop(_stream(torch.device(device))), "fpv_noop")
+
+
+class FusedAdam:
+    """clip_grad_norm_ + torch.optim.Adam.step() for ONE flat fp32 parameter tensor as a single launch
+    (fpv_adam_clip_step).  state_dict() has torch.optim.Adam's shape ({"state": {0: {step, exp_avg, exp_avg_sq}},
+    "param_groups": [...]}), so checkpoints written by the torch optimiser and by this one are interchangeable."""
+
+    def __init__(self, param: torch.Tensor, lr: float = 3e-4, betas=(0.9, 0.999), eps: float = 1e-5,
+                 max_grad_norm: float = 0.5):
+        if param.dtype != torch.float32 or not param.is_contiguous() or not param.is_cuda or param.dim() != 1:
+            raise ValueError("FusedAdam needs one flat contiguous fp32 device tensor")
+        self.param, self.lr, self.betas, self.eps, self.max_grad_norm = param, float(lr), tuple(betas), float(eps), float(max_grad_norm)
+        self._step2 = torch.zeros(2, dtype=torch.int64, device=param.device)   # {step, kernel-internal arrival counter}
+        self.state = {0: {"step": self._step2[0],
+                          "exp_avg": torch.zeros_like(param.data), "exp_avg_sq": torch.zeros_like(param.data)}}
+        self.grad_norm = torch.zeros((), dtype=torch.float32, device=param.device)
+        self.lib = L.load()
+
+    def step(self, grad: torch.Tensor | None = None) -> None:
+        g = self.param.grad if grad is None else grad
+        if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.numel() != self.param.numel():
+            raise ValueError("FusedAdam.step: gradient must be a contiguous fp32 tensor of the parameter's size")
+        st = self.state[0]
+        L.check(self.lib.fpv_adam_clip_step(_ptr(self.param.data), _ptr(g), _ptr(st["exp_avg"]), _ptr(st["exp_avg_sq"]),
+                                            _ptr(st["step"]), _ptr(self.grad_norm), self.param.numel(), self.lr,
+                                            self.betas[0], self.betas[1], self.eps, self.max_grad_norm,
+                                            _stream(self.param.device)), "fpv_adam_clip_step")
+
+    def state_dict(self) -> dict:
+        st = self.state[0]
+        return {"state": {0: {"step": st["step"].clone(), "exp_avg": st["exp_avg"].clone(),
+                              "exp_avg_sq": st["exp_avg_sq"].clone()}},
+                "param_groups": [{"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False,
+                                  "params": [0]}]}
+
+    def load_state_dict(self, sd: dict) -> None:
+        src = sd["state"].get(0) if sd.get("state") else None
+        st = self.state[0]
+        if src:
+            st["step"].copy_(torch.as_tensor(src["step"]).to(torch.int64))
+            st["exp_avg"].copy_(src["exp_avg"])
+            st["exp_avg_sq"].copy_(src["exp_avg_sq"])
+        else:
+            for t in st.values():
+                t.zero_()
+        if sd.get("param_groups"):
+            g = sd["param_groups"][0]
+            self.lr, self.betas, self.eps = float(g["lr"]), tuple(g["betas"]), float(g["eps"])

@@ -81,6 +81,56 @@ class FusedPolicy:
                 "fpv_policy_forward")
         return {"obs_n": obs_n, "action": action, "clipped": clipped, "value": value, "logp": logp, "eps": eps_out}
 
+    def _grads(self):
+        gs = []
+        for t in self._params():
+            if t.grad is None:
+                t.grad = torch.zeros_like(t)
+            if not t.grad.is_contiguous() or t.grad.dtype != torch.float32:
+                raise ValueError("parameter gradients must be contiguous fp32 tensors")
+            gs.append(t.grad)
+        return gs
+
+    def ppo_workspace(self, rows: int) -> torch.Tensor:
+        """Scratch tensor for ppo_grad on `rows` transitions (allocate once, outside any graph capture)."""
+        b = C.c_int64()
+        L.check(self.lib.fpv_ppo_workspace_bytes(self._h, int(rows), C.byref(b)), "fpv_ppo_workspace_bytes")
+        return torch.empty((b.value + 3) // 4, dtype=torch.float32, device=self.device)
+
+    def ppo_grad(self, obs, actions, old_logp, advantages, returns, *, index=None, rows=None, clip_range: float = 0.2,
+                 vf_coef: float = 0.5, ent_coef: float = 0.0, stats=None, workspace=None):
+        """Gradient of SB3's PPO minibatch loss w.r.t. every parameter of the module, written into the parameters'
+        .grad tensors by fpv_ppo_grad (forward, loss derivatives and backward as hand-written MFMA kernels; no torch
+        autograd involved).  index: optional int64 row indices into the five arrays.  Returns stats[4] =
+        (policy-gradient loss, value loss, approx KL, clip fraction)."""
+        if index is not None:
+            if index.dtype != torch.int64 or not index.is_contiguous():
+                raise ValueError("index must be a contiguous int64 device tensor")
+            m = index.numel()
+        else:
+            m = obs.shape[0] if rows is None else int(rows)
+        for name, t, w in (("obs", obs, self.obs_dim), ("actions", actions, self.act_dim)):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.dim() != 2 or t.shape[1] != w:
+                raise ValueError(f"{name} must be a contiguous [*,{w}] fp32 device tensor")
+        for name, t in (("old_logp", old_logp), ("advantages", advantages), ("returns", returns)):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != obs.shape[0]:
+                raise ValueError(f"{name} must be a contiguous fp32 vector with one entry per obs row")
+        if stats is None:
+            stats = torch.empty(4, dtype=torch.float32, device=self.device)
+        if workspace is None:
+            workspace = self.ppo_workspace(m)
+        io = L.FpvPpoIo()
+        io.rows, io.index = m, _ptr(index)
+        io.obs, io.actions, io.old_logp = _ptr(obs), _ptr(actions), _ptr(old_logp)
+        io.advantages, io.returns = _ptr(advantages), _ptr(returns)
+        io.clip_range, io.vf_coef, io.ent_coef = float(clip_range), float(vf_coef), float(ent_coef)
+        for k, (w, g) in enumerate(zip(self._params(), self._grads())):
+            io.weights[k], io.grads[k] = w.data_ptr(), g.data_ptr()
+        io.stats, io.workspace, io.workspace_bytes = _ptr(stats), _ptr(workspace), workspace.numel() * 4
+        L.check(self.lib.fpv_ppo_grad(self._h, C.byref(io), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+                "fpv_ppo_grad")
+        return stats
+
     def close(self):
         if getattr(self, "_h", None):
             self.lib.fpv_policy_destroy(self._h)

@@ -4,9 +4,12 @@ north_star replaces the reference's SAC learner (simulation/train_hover.py:47-58
 defaults are kept where they make sense at this batch scale (clip_range 0.2, vf_coef 0.5,
 max_grad_norm 0.5, gamma 0.99, lambda 0.95, Adam); the rollout is n_steps x 65 536 transitions, so
 minibatches are large and few (SB3's 2048 x 64 defaults would be a pointless batch here).
-torch autograd does the backward (the nets are 39 049 parameters: the update is a negligible share
-of a training iteration); gradients are averaged across ranks with ONE all-reduce per minibatch
-(156 KB - latency-bound on xGMI, so no bucketing and no ring of our own).
+The minibatch gradient comes from fpv_ppo_grad (csrc/fpv_ppo.hip: forward, loss derivatives and
+backward as hand-written fp32-MFMA kernels reading the rollout buffers through the minibatch's
+index vector); `fused_update=False` keeps the same loss on torch autograd as the readable
+reference (tests/test_ppo_grad_gpu.py compares the two).  Adam, the gradient clip and the
+cross-rank average are single-tensor torch ops on one flat parameter buffer: ONE all-reduce per
+minibatch (156 KB - latency-bound on xGMI, so no bucketing and no ring of our own).
 """
 from __future__ import annotations
 
@@ -14,6 +17,7 @@ import torch
 import torch.distributed as td
 
 from . import dist as D
+from . import ops as O
 from .rollout import RolloutCollector
 
 
@@ -21,7 +25,7 @@ class PPO:
     def __init__(self, collector: RolloutCollector, learning_rate: float = 3e-4, n_epochs: int = 4,
                  n_minibatches: int = 8, clip_range: float = 0.2, ent_coef: float = 0.0, vf_coef: float = 0.5,
                  max_grad_norm: float = 0.5, normalize_advantage: bool = True, target_kl: float | None = None,
-                 use_graph: bool = True):
+                 use_graph: bool = True, fused_update: bool | None = None):
         self.col = collector
         self.policy = collector.policy
         # capturable Adam: its step counter lives on the device, so one minibatch update (forward, loss, backward,
@@ -29,8 +33,20 @@ class PPO:
         self.use_graph = bool(use_graph) and next(self.policy.parameters()).is_cuda
         # all parameters / gradients live in one flat buffer: one Adam, one clip, one all-reduce per minibatch
         self._flat, self._flat_grad = self.policy.flatten_parameters()
-        self.opt = torch.optim.Adam([self._flat], lr=learning_rate, eps=1e-5, capturable=self.use_graph)
         self._mb_graph = None
+        fp = getattr(collector, "fp", None) if getattr(collector, "fused_policy", False) else None
+        if fused_update is None:
+            fused_update = fp is not None
+        if fused_update and fp is None:
+            raise ValueError("fused_update needs a collector with the fused policy kernel (fused_policy=True)")
+        self.fused_update = bool(fused_update)
+        self._fp = fp
+        self._ws = self._adv_n = None
+        self._stats = torch.zeros(4, dtype=torch.float32, device=collector.device) if self.fused_update else None
+        if self.fused_update:                   # clip + Adam as one launch on the flat buffer
+            self.opt = O.FusedAdam(self._flat, lr=learning_rate, eps=1e-5, max_grad_norm=max_grad_norm or 0.0)
+        else:
+            self.opt = torch.optim.Adam([self._flat], lr=learning_rate, eps=1e-5, capturable=self.use_graph)
         self.n_epochs, self.n_minibatches = n_epochs, n_minibatches
         self.clip_range, self.ent_coef, self.vf_coef = clip_range, ent_coef, vf_coef
         self.max_grad_norm, self.normalize_advantage, self.target_kl = max_grad_norm, normalize_advantage, target_kl
@@ -69,11 +85,17 @@ class PPO:
             kl = ((torch.exp(log_ratio) - 1) - log_ratio).mean()
             return torch.stack([pg.detach(), vl.detach(), kl, ((ratio - 1).abs() > self.clip_range).float().mean()])
 
-    def _build_graph(self, mb: int, obs_dim: int, act_dim: int, dev) -> None:
-        f32 = torch.float32
-        self._g_in = [torch.zeros((mb, obs_dim), dtype=f32, device=dev), torch.zeros((mb, act_dim), dtype=f32, device=dev),
-                      torch.zeros((mb,), dtype=f32, device=dev), torch.zeros((mb,), dtype=f32, device=dev),
-                      torch.zeros((mb,), dtype=f32, device=dev)]
+    def _fused_minibatch(self, idx):
+        """The same step with the gradient from fpv_ppo_grad; the rollout arrays are read through idx in the kernel."""
+        b = self._fused_src
+        self._fp.ppo_grad(b["obs"], b["act"], b["old_lp"], b["adv"], b["ret"], index=idx, clip_range=self.clip_range,
+                          vf_coef=self.vf_coef, ent_coef=self.ent_coef, stats=self._stats, workspace=self._ws)
+        self._allreduce_grads()
+        self.opt.step(self._flat_grad)
+        return self._stats
+
+    def _build_graph(self, step, inputs, dev) -> None:
+        self._g_in = inputs
         # warm-up on a side stream with the optimiser state saved and restored, then capture
         saved = ({k: v.clone() for k, v in self.policy.state_dict().items()},
                  {"state": {k: {n: (t.clone() if torch.is_tensor(t) else t) for n, t in st.items()}
@@ -83,12 +105,12 @@ class PPO:
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(3):
-                self._minibatch_update(*self._g_in)
+                step(*self._g_in)
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self._g_out = self._minibatch_update(*self._g_in)
+            self._g_out = step(*self._g_in)
         self.policy.load_state_dict(saved[0])
         if saved[1]["state"]:
             self.opt.load_state_dict(saved[1])
@@ -97,7 +119,7 @@ class PPO:
                 for t in st.values():
                     if torch.is_tensor(t):
                         t.zero_()
-        self._mb_graph, self._mb_size = g, mb
+        self._mb_graph, self._mb_size = g, inputs[0].shape[0]
 
     def train_on(self, batch: dict) -> None:
         T, N = self.col.T, self.col.N
@@ -111,17 +133,41 @@ class PPO:
             adv = (adv - batch["adv_mean"].float()) / (batch["adv_std"].float() + 1e-8)
         total = T * N
         mb = total // self.n_minibatches
+        dev = obs.device
         graph = self.use_graph and not (D.world_size() > 1 and td.get_backend() == "gloo")
-        if graph and (self._mb_graph is None or self._mb_size != mb):
-            self._build_graph(mb, obs.shape[1], act.shape[1], obs.device)
+        if self.fused_update:
+            if self._adv_n is None or self._adv_n.numel() != total:
+                self._adv_n = torch.empty(total, dtype=torch.float32, device=dev)
+            self._adv_n.copy_(adv)
+            if self._ws is None or self._ws_rows != mb:
+                self._ws, self._ws_rows = self._fp.ppo_workspace(mb), mb
+            src = {"obs": obs, "act": act, "old_lp": old_lp, "adv": self._adv_n, "ret": ret}
+            if graph and self._mb_graph is not None and any(src[k].data_ptr() != self._fused_src[k].data_ptr() for k in src):
+                self._mb_graph = None           # the captured launches hold the rollout buffers' addresses
+            self._fused_src = src
+            if graph and (self._mb_graph is None or self._mb_size != mb):
+                self._build_graph(self._fused_minibatch, [torch.zeros(mb, dtype=torch.int64, device=dev)], dev)
+        elif graph and (self._mb_graph is None or self._mb_size != mb):
+            f32 = torch.float32
+            self._build_graph(self._minibatch_update,
+                              [torch.zeros((mb, obs.shape[1]), dtype=f32, device=dev), torch.zeros((mb, act.shape[1]), dtype=f32, device=dev),
+                               torch.zeros((mb,), dtype=f32, device=dev), torch.zeros((mb,), dtype=f32, device=dev),
+                               torch.zeros((mb,), dtype=f32, device=dev)], dev)
         stats = []
         for epoch in range(self.n_epochs):
-            perm = torch.randperm(total, device=obs.device, generator=self._gen)
+            perm = torch.randperm(total, device=dev, generator=self._gen)
             for k in range(self.n_minibatches):
                 idx = perm[k * mb:(k + 1) * mb]
-                if graph:
-                    for dst, src in zip(self._g_in, (obs, act, old_lp, ret, adv)):
-                        torch.index_select(src, 0, idx, out=dst)
+                if self.fused_update:
+                    if graph:
+                        self._g_in[0].copy_(idx)
+                        self._mb_graph.replay()
+                        stats.append(self._g_out.clone())
+                    else:
+                        stats.append(self._fused_minibatch(idx).clone())
+                elif graph:
+                    for dst, src_t in zip(self._g_in, (obs, act, old_lp, ret, adv)):
+                        torch.index_select(src_t, 0, idx, out=dst)
                     self._mb_graph.replay()
                     stats.append(self._g_out.clone())
                 else:

@@ -231,6 +231,39 @@ int fpv_policy_forward(fpv_policy* pol, const fpv_policy_io* io, void* stream);
  * in fp32 accumulators (error at the level of one fp32 rounding, 2.7x fewer matrix-pipe cycles). */
 int fpv_policy_set_gemm(fpv_policy* pol, int32_t mode);
 
+/* ---- PPO minibatch gradient (SB3 PPO.train: clipped surrogate + vf_coef * MSE value loss - ent_coef * entropy) ----
+ * The learner north_star puts in place of the SAC of simulation/train_hover.py:47-60.  One call = forward of both nets
+ * over `rows` transitions, the loss derivatives, and the backward pass, as hand-written MFMA kernels (fpv_ppo.hip);
+ * the gradient of the MEAN loss over the rows is WRITTEN (not accumulated) to grads[]; optimiser, clipping and the
+ * cross-rank all-reduce stay with the caller.  weights / grads: 13 DEVICE pointers each, in fpv_policy_load's order.
+ * Deterministic (no atomics).  Everything is stream-ordered; nothing is allocated (graph-capturable). */
+typedef struct {
+    int64_t rows;             /* minibatch size M */
+    const int64_t* index;     /* [M] device row indices into the arrays below, or NULL: rows 0..M-1 */
+    const float* obs;         /* [*][in_dim] normalised observations (rollout buffer) */
+    const float* actions;     /* [*][act_dim] unclipped sampled actions */
+    const float* old_logp;    /* [*] */
+    const float* advantages;  /* [*] as the loss should see them (normalise beforehand) */
+    const float* returns;     /* [*] */
+    float clip_range, vf_coef, ent_coef, reserved0;
+    const float* weights[13];
+    float* grads[13];
+    float* stats;             /* [4] out: policy-gradient loss, value loss (MSE), approx KL, clip fraction */
+    void* workspace;          /* device scratch, >= fpv_ppo_workspace_bytes(rows), 16-byte aligned */
+    int64_t workspace_bytes;
+} fpv_ppo_io;
+
+int fpv_ppo_workspace_bytes(fpv_policy* pol, int64_t rows, int64_t* bytes);
+int fpv_ppo_grad(fpv_policy* pol, const fpv_ppo_io* io, void* stream);
+
+/* torch.nn.utils.clip_grad_norm_(max_grad_norm) + torch.optim.Adam.step() (no weight decay, no amsgrad) on ONE flat
+ * fp32 tensor of n elements, as a single launch (SB3 PPO.train's optimiser step, max_grad_norm 0.5, Adam eps 1e-5).
+ * step: device int64[2], zero-initialised by the caller: {step count (incremented), launch-internal counter}; grad_norm: optional device float receiving the norm before clipping;
+ * max_grad_norm <= 0 disables clipping.  grad is not modified. */
+int fpv_adam_clip_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t* step,
+                       float* grad_norm, int64_t n, float lr, float beta1, float beta2, float eps, float max_grad_norm,
+                       void* stream);
+
 /* Process-wide tuning knob: hover handles with at most `max_drones` drones (default 32 768) run the env step as a
  * physics wave + helper wave pair per 64-drone tile (the helper draws the motor noise one sub-step pair ahead and
  * stores the observation tile); that pays while the helper wave finds a SIMD of its own.  Larger handles use the
