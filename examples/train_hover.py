@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--target-kl", type=float, default=0.03)
     ap.add_argument("--ent-coef", type=float, default=0.0)
     ap.add_argument("--gamma", type=float, default=0.99)
+    ap.add_argument("--log-std-min", type=float, default=-3.5, help="floor under the policy log-std (sigma >= 0.03)")
     ap.add_argument("--autograd-update", action="store_true",
                     help="minibatch gradient through torch autograd instead of the fpv_ppo_grad kernels")
     args = ap.parse_args()
@@ -42,7 +43,7 @@ def main():
                     ledger_capacity=args.drones * max(2, args.n_steps // 8))
     col = RolloutCollector(eng, policy, n_steps=args.n_steps, policy_seed=args.seed, gamma=args.gamma)
     model = PPO(col, learning_rate=args.lr, n_epochs=args.epochs, n_minibatches=args.minibatches, ent_coef=args.ent_coef,
-                target_kl=args.target_kl, fused_update=not args.autograd_update)
+                target_kl=args.target_kl, fused_update=not args.autograd_update, log_std_min=args.log_std_min)
     t0 = time.time()
     model.learn(int(args.timesteps), log_every=args.log_every)
     if rank == 0:

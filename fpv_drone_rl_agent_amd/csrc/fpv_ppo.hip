@@ -13,6 +13,10 @@
 // fp32 throughout (v_mfma_f32_32x32x2_f32); no atomics: the result is bitwise reproducible for a given launch shape.
 #include "fpv_internal.h"
 
+#ifndef FPV_PPO_THREADS
+#define FPV_PPO_THREADS 256
+#endif
+
 namespace fpv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -30,6 +34,7 @@ constexpr int kHeadFloats = 660 + 512;                  // 1172
 constexpr int kTImage = kTHead + kHeadFloats;
 // U2 partial layout per (net, slab)
 constexpr int kPW1 = 0, kPB1 = 3072, kPW2 = 3200, kPB2 = 19584, kPWh = 19712, kPBh = 20224, kPartStride = 20232;
+constexpr int kFwdBwdThreads = FPV_PPO_THREADS;          // U1 workgroup: 256 = one wave per SIMD (512 measured slower: 175 vs 133 us)
 constexpr int kWaveStats = 8;                           // pg, vl, kl, clip fraction, d log_std[4]
 
 __host__ __device__ constexpr int tile_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -70,6 +75,32 @@ __device__ __forceinline__ void store_rows(float* __restrict__ mat, int64_t n, c
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             row[m * 8 + 2 * q + h] = f32x4{t.t[m][4 * q], t.t[m][4 * q + 1], t.t[m][4 * q + 2], t.t[m][4 * q + 3]};
+}
+
+__device__ __forceinline__ void store_tile(float* __restrict__ mat, int64_t n, const f32x16& t, int m, int h) {
+    f32x4* row = reinterpret_cast<f32x4*>(mat + n * kHid);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) row[m * 8 + 2 * q + h] = f32x4{t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
+}
+
+__device__ __forceinline__ void load_tile(const float* __restrict__ mat, int64_t n, f32x16& t, int m, int h) {
+    const f32x4* row = reinterpret_cast<const f32x4*>(mat + n * kHid);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = row[m * 8 + 2 * q + h];
+        t[4 * q] = v.x; t[4 * q + 1] = v.y; t[4 * q + 2] = v.z; t[4 * q + 3] = v.w;
+    }
+}
+
+__device__ __forceinline__ void load_rows(const float* __restrict__ mat, int64_t n, Hidden& t, int h) {
+    const f32x4* row = reinterpret_cast<const f32x4*>(mat + n * kHid);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = row[m * 8 + 2 * q + h];
+            t.t[m][4 * q] = v.x; t.t[m][4 * q + 1] = v.y; t.t[m][4 * q + 2] = v.z; t.t[m][4 * q + 3] = v.w;
+        }
 }
 
 }  // namespace
@@ -157,6 +188,7 @@ __global__ __launch_bounds__(THREADS) void ppo_fwd_bwd_kernel(PpoArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 31, h = lane >> 5;
     constexpr int kChunk = THREADS / 2;
+    constexpr bool kReloadH1 = THREADS > 256;
     float st[kWaveStats] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll 1
@@ -213,25 +245,41 @@ __global__ __launch_bounds__(THREADS) void ppo_fwd_bwd_kernel(PpoArgs p) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
                     a.t[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[kTOffW1 + (m * 12 + s) * 64 + lane], x[s], a.t[m], 0, 0, 0);
-            tanh_all(a);
-            if (live) store_rows(H1, n, a, h);
+            // tanh of layer-1 tile kt + 1 and its store ride inside the matrix products that consume tile kt
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a.t[0][r] = fast_tanh(a.t[0][r]);
+            if (live) store_tile(H1, n, a.t[0], 0, h);
             Hidden c;
             bias_init(c, lds + kTOffB2, h);
+            {
+                f32x4 wc[4], wn[4];
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+                for (int m = 0; m < 4; ++m)
+                    wc[m] = *reinterpret_cast<const f32x4*>(lds + kTOffW2 + (((m * 4 * 4) * 64 + lane) * 4));
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    f32x4 w[4];
+                for (int t = 0; t < 16; ++t) {
+                    const int kt = t >> 2, r4 = t & 3;
+                    if (t < 15) {
+                        const int kt1 = (t + 1) >> 2, r41 = (t + 1) & 3;
 #pragma unroll
-                    for (int m = 0; m < 4; ++m)
-                        w[m] = *reinterpret_cast<const f32x4*>(lds + kTOffW2 + ((((m * 4 + kt) * 4 + r4) * 64 + lane) * 4));
+                        for (int m = 0; m < 4; ++m)
+                            wn[m] = *reinterpret_cast<const f32x4*>(lds + kTOffW2 + ((((m * 4 + kt1) * 4 + r41) * 64 + lane) * 4));
+                    }
+                    if (kt < 3) {
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) a.t[kt + 1][4 * r4 + rr] = fast_tanh(a.t[kt + 1][4 * r4 + rr]);
+                        if (r4 == 3 && live) store_tile(H1, n, a.t[kt + 1], kt + 1, h);
+                    }
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
                         for (int m = 0; m < 4; ++m)
-                            c.t[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[m][rr], a.t[kt][4 * r4 + rr], c.t[m], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);   // keep the operand loads of later k-steps out of this one
+                            c.t[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[m][rr], a.t[kt][4 * r4 + rr], c.t[m], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);   // keep later k-steps' operands and VALU work out of this one
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) wc[m] = wn[m];
                 }
+            }
             tanh_all(c);
             if (live) store_rows(H2, n, c, h);
 
@@ -246,6 +294,7 @@ __global__ __launch_bounds__(THREADS) void ppo_fwd_bwd_kernel(PpoArgs p) {
                         const f32x4 w = *reinterpret_cast<const f32x4*>(hb + kHWa + (((h * 4 + kt) * 16 + r) * 4));
                         const float v = c.t[kt][r];
                         mu[0] += w.x * v; mu[1] += w.y * v; mu[2] += w.z * v; mu[3] += w.w * v;
+                        if (r == 15) __builtin_amdgcn_sched_barrier(0);   // bound the look-ahead of the weight reads
                     }
                 float act[4] = {0.f, 0.f, 0.f, 0.f};
                 if (live) {
@@ -296,7 +345,10 @@ __global__ __launch_bounds__(THREADS) void ppo_fwd_bwd_kernel(PpoArgs p) {
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) v += hb[kHWv + (h * 4 + kt) * 16 + r] * c.t[kt][r];
+                    for (int r = 0; r < 16; ++r) {
+                        v += hb[kHWv + (h * 4 + kt) * 16 + r] * c.t[kt][r];
+                        if (r == 15) __builtin_amdgcn_sched_barrier(0);
+                    }
                 v += __shfl_xor(v, 32);
                 v += hb[kHBv];
                 const float ret = live ? p.ret[src] : 0.f;
@@ -307,42 +359,67 @@ __global__ __launch_bounds__(THREADS) void ppo_fwd_bwd_kernel(PpoArgs p) {
                     st[1] += err * err;
                 }
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < 4; ++m) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) g.t[m][r] = hb[kHWv + (h * 4 + m) * 16 + r] * dv;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            // ---- D2 = g * (1 - H2^2)
+            // ---- D2 = g * (1 - H2^2), then dH1^T = W2^T . D2^T : the D2 tiles are the B operands as they stand; tile
+            // kt + 1 is finished (and stored) inside the products that consume tile kt
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) g.t[m][r] *= 1.0f - c.t[m][r] * c.t[m][r];
-            if (live) store_rows(D2, n, g, h);
-            // ---- dH1^T = W2^T . D2^T : the D2 tiles are the B operands as they stand
+            for (int r = 0; r < 16; ++r) g.t[0][r] *= 1.0f - c.t[0][r] * c.t[0][r];
+            if (live) store_tile(D2, n, g.t[0], 0, h);
             Hidden e;
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) e.t[m][r] = 0.f;
+            {
+                f32x4 wc[4], wn[4];
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+                for (int m = 0; m < 4; ++m)
+                    wc[m] = *reinterpret_cast<const f32x4*>(lds + kTOffW2T + (((m * 4 * 4) * 64 + lane) * 4));
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    f32x4 w[4];
+                for (int t = 0; t < 16; ++t) {
+                    const int kt = t >> 2, r4 = t & 3;
+                    if (t < 15) {
+                        const int kt1 = (t + 1) >> 2, r41 = (t + 1) & 3;
 #pragma unroll
-                    for (int m = 0; m < 4; ++m)
-                        w[m] = *reinterpret_cast<const f32x4*>(lds + kTOffW2T + ((((m * 4 + kt) * 4 + r4) * 64 + lane) * 4));
+                        for (int m = 0; m < 4; ++m)
+                            wn[m] = *reinterpret_cast<const f32x4*>(lds + kTOffW2T + ((((m * 4 + kt1) * 4 + r41) * 64 + lane) * 4));
+                    }
+                    if (kt < 3) {
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const float hv = c.t[kt + 1][4 * r4 + rr];
+                            g.t[kt + 1][4 * r4 + rr] *= 1.0f - hv * hv;
+                        }
+                        if (r4 == 3 && live) store_tile(D2, n, g.t[kt + 1], kt + 1, h);
+                    }
 #pragma unroll
                     for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
                         for (int m = 0; m < 4; ++m)
-                            e.t[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[m][rr], g.t[kt][4 * r4 + rr], e.t[m], 0, 0, 0);
+                            e.t[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[m][rr], g.t[kt][4 * r4 + rr], e.t[m], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) wc[m] = wn[m];
                 }
+            }
+            // D1 = dH1 * (1 - H1^2), a tile at a time.  H1 went to memory after layer 1 (U2 needs it there anyway); with
+            // two waves per SIMD there is no room to keep it in registers through the backward products, so it comes
+            // back from L2 here (unconditionally: a predicated load would keep the old tiles alive)
+            if (kReloadH1) asm volatile("" ::: "memory");
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < 4; ++m) {
+                f32x16 hm = a.t[m];
+                if (kReloadH1) load_tile(H1, live ? n : 0, hm, m, h);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) e.t[m][r] *= 1.0f - a.t[m][r] * a.t[m][r];
-            if (live) store_rows(D1, n, e, h);
+                for (int r = 0; r < 16; ++r) e.t[m][r] *= 1.0f - hm[r] * hm[r];
+                if (live) store_tile(D1, n, e.t[m], m, h);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     // ---- per-wave statistics (fixed lane order)
@@ -372,19 +449,30 @@ struct Ops {
 };
 }  // namespace
 
-// 256 threads: wave w owns output rows 32 w .. 32 w + 31 of dW2 (four 32-column tiles) and dW1, and columns
-// 32 w .. 32 w + 31 of the head gradient.  blockIdx.y = net, blockIdx.x = slab of rows.
-__global__ __launch_bounds__(256) void ppo_wgrad_kernel(WgradArgs p) {
+// 512 threads = two sets of four waves.  Wave w of a set owns output rows 32 w .. 32 w + 31 of dW2 (four 32-column
+// tiles) and dW1, and columns 32 w .. 32 w + 31 of the head gradient; the two sets take alternate 8-row groups of the
+// slab (two waves per SIMD hide each other's load latency) and are added through LDS at the end, set 0 + set 1.
+// blockIdx.y = net, blockIdx.x = slab of rows.
+constexpr int kWgradXchFloats = 4 * 99 * 64;
+
+__global__ __launch_bounds__(512) void ppo_wgrad_kernel(WgradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float xch[];     // [4 waves][99][64 lanes]
     const int net = blockIdx.y, slab = blockIdx.x;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = (threadIdx.x >> 6) & 3, set = threadIdx.x >> 8;
     const int i = lane & 31, kk = lane >> 5;
-    const float* H1 = p.mats + (size_t)(net * 4 + 0) * p.rows * kHid;
-    const float* H2 = p.mats + (size_t)(net * 4 + 1) * p.rows * kHid;
-    const float* D1 = p.mats + (size_t)(net * 4 + 2) * p.rows * kHid;
-    const float* D2 = p.mats + (size_t)(net * 4 + 3) * p.rows * kHid;
     const int nh = net == 0 ? p.act_dim : 1;
     const int64_t n0 = (int64_t)slab * p.rows_per_slab;
     const int64_t n1 = n0 + p.rows_per_slab < p.rows ? n0 + p.rows_per_slab : p.rows;
+    const int len = (int)(n1 - n0);
+    // lane-fixed column offsets; rows are 32-bit offsets from the slab's first row
+    const float* H1 = p.mats + ((size_t)(net * 4 + 0) * p.rows + n0) * kHid + i;
+    const float* H2 = p.mats + ((size_t)(net * 4 + 1) * p.rows + n0) * kHid + 32 * w + i;
+    const float* D1 = p.mats + ((size_t)(net * 4 + 2) * p.rows + n0) * kHid + 32 * w + i;
+    const float* D2 = p.mats + ((size_t)(net * 4 + 3) * p.rows + n0) * kHid + 32 * w + i;
+    const float* XG = p.xg + n0 * p.in_dim + (i < p.in_dim ? i : p.in_dim - 1);
+    const float* AH = net == 0 ? p.dmu + n0 * 4 + (i < 4 ? i : 3) : p.dv + n0;
+    const int ah_stride = net == 0 ? 4 : 1;
+    const bool x_on = i < p.in_dim, ah_on = i < nh;
 
     f32x16 w2[4], w1, hd;
 #pragma unroll
@@ -393,40 +481,72 @@ __global__ __launch_bounds__(256) void ppo_wgrad_kernel(WgradArgs p) {
     }
     float sb2 = 0.f, sb1 = 0.f, sbh = 0.f;
 
-    auto load = [&](Ops& o, int64_t n) {
-        const int64_t row = n + kk;
-        const bool ok = row < n1;
-        const int64_t r = ok ? row : n0;
-        const float a2 = D2[r * kHid + 32 * w + i], a1 = D1[r * kHid + 32 * w + i], hh = H2[r * kHid + 32 * w + i];
-        const float ah = i < nh ? (net == 0 ? p.dmu[r * 4 + i] : p.dv[r]) : 0.f;
-        const float x = i < p.in_dim ? p.xg[r * p.in_dim + i] : 0.f;
-        o.a2 = ok ? a2 : 0.f; o.a1 = ok ? a1 : 0.f; o.hh = hh; o.ah = ok ? ah : 0.f; o.x = x;
+    // one k-step = rows row0 + kk (slab-relative).  load() only requests; masking waits until fma(), so that a whole
+    // group of requests is in flight before anything depends on one of them
+    auto load = [&](Ops& o, int row0) {
+        const int row = row0 + kk;
+        const int r = row < len ? row : 0;
+        o.a2 = D2[r * kHid]; o.a1 = D1[r * kHid]; o.ah = AH[r * ah_stride];
+        o.hh = H2[r * kHid];
+        o.x = XG[r * p.in_dim];
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) o.b[jt] = H1[r * kHid + 32 * jt + i];
+        for (int jt = 0; jt < 4; ++jt) o.b[jt] = H1[r * kHid + 32 * jt];
     };
-    auto fma = [&](const Ops& o) {
+    auto fma = [&](const Ops& o, int row0) {
+        const bool ok = row0 + kk < len;
+        const float a2 = ok ? o.a2 : 0.f, a1 = ok ? o.a1 : 0.f, ah = (ok && ah_on) ? o.ah : 0.f, x = x_on ? o.x : 0.f;
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) w2[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a2, o.b[jt], w2[jt], 0, 0, 0);
-        w1 = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a1, o.x, w1, 0, 0, 0);
-        hd = __builtin_amdgcn_mfma_f32_32x32x2f32(o.ah, o.hh, hd, 0, 0, 0);
-        sb2 += o.a2; sb1 += o.a1; sbh += o.ah;
+        for (int jt = 0; jt < 4; ++jt) w2[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, o.b[jt], w2[jt], 0, 0, 0);
+        w1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, x, w1, 0, 0, 0);
+        hd = __builtin_amdgcn_mfma_f32_32x32x2f32(ah, o.hh, hd, 0, 0, 0);
+        sb2 += a2; sb1 += a1; sbh += ah;
     };
 
-    constexpr int U = 4;                        // k-steps (pairs of rows) per register group
+    constexpr int U = 4;                        // k-steps (pairs of rows) per register group = 8 rows
     Ops A[U], B[U];
+    int g0 = 8 * set;                           // this set's groups: rows g0, g0 + 16, ...
 #pragma unroll
-    for (int u = 0; u < U; ++u) load(A[u], n0 + 2 * u);
+    for (int u = 0; u < U; ++u) load(A[u], g0 + 2 * u);
 #pragma unroll 1
-    for (int64_t n = n0; n < n1; n += 4 * U) {
+    for (; g0 < len; g0 += 32) {
+        // the fences pin the order "request the next group, then multiply the current one": left alone, the scheduler
+        // sinks every load next to its use and waits for each (measured 187 us instead of 100)
 #pragma unroll
-        for (int u = 0; u < U; ++u) load(B[u], n + 2 * U + 2 * u);
+        for (int u = 0; u < U; ++u) load(B[u], g0 + 16 + 2 * u);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < U; ++u) fma(A[u]);
+        for (int u = 0; u < U; ++u) fma(A[u], g0 + 2 * u);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < U; ++u) load(A[u], n + 4 * U + 2 * u);
+        for (int u = 0; u < U; ++u) load(A[u], g0 + 32 + 2 * u);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < U; ++u) fma(B[u]);
+        for (int u = 0; u < U; ++u) fma(B[u], g0 + 16 + 2 * u);
+        __builtin_amdgcn_sched_barrier(0);
     }
+
+    // ---- set 1 hands its sums to set 0
+    float* mine = xch + (size_t)w * 99 * 64 + lane;
+    if (set == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) mine[(jt * 16 + r) * 64] = w2[jt][r];
+            mine[(64 + r) * 64] = w1[r];
+            mine[(80 + r) * 64] = hd[r];
+        }
+        mine[96 * 64] = sb2; mine[97 * 64] = sb1; mine[98 * 64] = sbh;
+    }
+    __syncthreads();
+    if (set == 1) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) w2[jt][r] += mine[(jt * 16 + r) * 64];
+        w1[r] += mine[(64 + r) * 64];
+        hd[r] += mine[(80 + r) * 64];
+    }
+    sb2 += mine[96 * 64]; sb1 += mine[97 * 64]; sbh += mine[98 * 64];
 
     float* out = p.part + ((size_t)net * p.slabs + slab) * kPartStride;
 #pragma unroll
@@ -434,7 +554,7 @@ __global__ __launch_bounds__(256) void ppo_wgrad_kernel(WgradArgs p) {
         const int o = 32 * w + tile_row(r, kk);
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) out[kPW2 + o * kHid + 32 * jt + i] = w2[jt][r];
-        if (i < p.in_dim) out[kPW1 + o * p.in_dim + i] = w1[r];
+        if (x_on) out[kPW1 + o * p.in_dim + i] = w1[r];
     }
     if (kk == 0) {
 #pragma unroll
@@ -445,7 +565,7 @@ __global__ __launch_bounds__(256) void ppo_wgrad_kernel(WgradArgs p) {
     if (kk == 0) {
         out[kPB2 + 32 * w + i] = sb2;
         out[kPB1 + 32 * w + i] = sb1;
-        if (w == 0 && i < nh) out[kPBh + i] = sbh;
+        if (w == 0 && ah_on) out[kPBh + i] = sbh;
     }
 }
 
@@ -596,21 +716,22 @@ hipError_t launch_adam_clip(float* param, const float* grad, float* exp_avg, flo
 // ---------------------------------------------------------------- launchers
 static int ppo_slabs(int64_t rows, int* rows_per_slab) {
     int64_t rps = (rows + 127) / 128;
-    rps = (rps + 15) / 16 * 16;
-    if (rps < 16) rps = 16;
+    rps = (rps + 31) / 32 * 32;
+    if (rps < 32) rps = 32;
     *rows_per_slab = (int)rps;
     return (int)((rows + rps - 1) / rps);
 }
 
 static int ppo_blocks(int64_t rows, int cus) {
-    const int64_t b = (rows + 127) / 128;
+    constexpr int chunk = kFwdBwdThreads / 2;
+    const int64_t b = (rows + chunk - 1) / chunk;
     return (int)(b < cus ? b : cus);
 }
 
 int64_t ppo_workspace_floats(int64_t rows, int cus) {
     int rps;
     const int slabs = ppo_slabs(rows, &rps);
-    return (int64_t)kTImage + 8 * rows * kHid + rows * 24 + rows * 4 + rows + (int64_t)ppo_blocks(rows, cus) * 4 * kWaveStats +
+    return (int64_t)kTImage + 8 * rows * kHid + rows * 24 + rows * 4 + rows + (int64_t)ppo_blocks(rows, cus) * (kFwdBwdThreads / 64) * kWaveStats +
            2 * (int64_t)slabs * kPartStride + 64;
 }
 
@@ -621,8 +742,11 @@ hipError_t launch_ppo_grad(const float* const* w, float* const* grads, const int
     static bool attr_set = false;
     constexpr size_t lds_bytes = (size_t)(kTNet + kHeadFloats) * sizeof(float);
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)ppo_fwd_bwd_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute((const void*)ppo_fwd_bwd_kernel<kFwdBwdThreads>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds_bytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)ppo_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(kWgradXchFloats * sizeof(float)));
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -636,16 +760,16 @@ hipError_t launch_ppo_grad(const float* const* w, float* const* grads, const int
     float* dmu = xg + rows * 24;
     float* dv = dmu + rows * 4;
     float* wave_stats = dv + (rows + 3) / 4 * 4;
-    float* part = wave_stats + (size_t)blocks * 4 * kWaveStats;
+    float* part = wave_stats + (size_t)blocks * (kFwdBwdThreads / 64) * kWaveStats;
 
     PpoParams pp{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], in_dim, act_dim};
     hipLaunchKernelGGL(ppo_pack_kernel, dim3((kTImage + 255) / 256), dim3(256), 0, s, pp, image);
     PpoArgs a{image, index, obs, actions, old_logp, adv, ret, mats, xg, dmu, dv, wave_stats,
               rows, clip_range, vf_coef, 1.0f / (float)rows, in_dim, act_dim};
-    hipLaunchKernelGGL(ppo_fwd_bwd_kernel<256>, dim3(blocks), dim3(256), lds_bytes, s, a);
+    hipLaunchKernelGGL(ppo_fwd_bwd_kernel<kFwdBwdThreads>, dim3(blocks), dim3(kFwdBwdThreads), lds_bytes, s, a);
     WgradArgs g{mats, xg, dmu, dv, part, rows, rps, slabs, in_dim, act_dim};
-    hipLaunchKernelGGL(ppo_wgrad_kernel, dim3(slabs, 2), dim3(256), 0, s, g);
-    ReduceArgs r{part, wave_stats, {}, stats, slabs, blocks * 4, in_dim, act_dim, 1.0f / (float)rows, ent_coef};
+    hipLaunchKernelGGL(ppo_wgrad_kernel, dim3(slabs, 2), dim3(512), kWgradXchFloats * sizeof(float), s, g);
+    ReduceArgs r{part, wave_stats, {}, stats, slabs, blocks * (kFwdBwdThreads / 64), in_dim, act_dim, 1.0f / (float)rows, ent_coef};
     for (int k = 0; k < 13; ++k) r.g[k] = grads[k];
     hipLaunchKernelGGL(ppo_reduce_kernel, dim3((2 * kPartStride + 31) / 32 + 1), dim3(256), 0, s, r);
     return hipGetLastError();

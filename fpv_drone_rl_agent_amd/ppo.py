@@ -25,7 +25,7 @@ class PPO:
     def __init__(self, collector: RolloutCollector, learning_rate: float = 3e-4, n_epochs: int = 4,
                  n_minibatches: int = 8, clip_range: float = 0.2, ent_coef: float = 0.0, vf_coef: float = 0.5,
                  max_grad_norm: float = 0.5, normalize_advantage: bool = True, target_kl: float | None = None,
-                 use_graph: bool = True, fused_update: bool | None = None):
+                 use_graph: bool = True, fused_update: bool | None = None, log_std_min: float | None = None):
         self.col = collector
         self.policy = collector.policy
         # capturable Adam: its step counter lives on the device, so one minibatch update (forward, loss, backward,
@@ -50,6 +50,9 @@ class PPO:
         self.n_epochs, self.n_minibatches = n_epochs, n_minibatches
         self.clip_range, self.ent_coef, self.vf_coef = clip_range, ent_coef, vf_coef
         self.max_grad_norm, self.normalize_advantage, self.target_kl = max_grad_norm, normalize_advantage, target_kl
+        # optional floor under the policy's log-std (not in SB3): with 10^4..10^5 drones the Gaussian narrows to
+        # sigma < 0.01 within 10^8 steps, where the importance ratios of a PPO epoch become violently sensitive
+        self.log_std_min = log_std_min
         self.num_timesteps = 0
         self.logger: dict[str, float] = {}
         self._gen = torch.Generator(device=collector.device)
@@ -80,6 +83,8 @@ class PPO:
         self._allreduce_grads()
         torch.nn.utils.clip_grad_norm_([self._flat], self.max_grad_norm)
         self.opt.step()
+        if self.log_std_min is not None:
+            self.policy.log_std.data.clamp_(min=self.log_std_min)
         with torch.no_grad():
             log_ratio = lp - old_lp
             kl = ((torch.exp(log_ratio) - 1) - log_ratio).mean()
@@ -92,6 +97,8 @@ class PPO:
                           vf_coef=self.vf_coef, ent_coef=self.ent_coef, stats=self._stats, workspace=self._ws)
         self._allreduce_grads()
         self.opt.step(self._flat_grad)
+        if self.log_std_min is not None:
+            self.policy.log_std.data.clamp_(min=self.log_std_min)
         return self._stats
 
     def _build_graph(self, step, inputs, dev) -> None:
