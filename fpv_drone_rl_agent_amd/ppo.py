@@ -179,8 +179,12 @@ class PPO:
                     stats.append(self._g_out.clone())
                 else:
                     stats.append(self._minibatch_update(obs[idx], act[idx], old_lp[idx], ret[idx], adv[idx]))
-            if self.target_kl is not None and float(torch.stack(stats[-self.n_minibatches:]).mean(0)[2]) > 1.5 * self.target_kl:
-                break
+            if self.target_kl is not None:
+                kl = torch.stack(stats[-self.n_minibatches:]).mean(0)[2]
+                if D.world_size() > 1:          # every rank must take the same decision: it gates the next all-reduces
+                    kl = D.allgather_payload(kl.double().reshape(1)).mean()
+                if float(kl) > 1.5 * self.target_kl:
+                    break
         s = torch.stack(stats).mean(0).tolist()
         self.logger.update({"train/policy_gradient_loss": s[0], "train/value_loss": s[1], "train/approx_kl": s[2],
                             "train/clip_fraction": s[3], "train/loss": s[0] + self.vf_coef * s[1],
