@@ -17,6 +17,8 @@ from fpv_drone_rl_agent_amd.rollout import RolloutCollector  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--task", choices=["hover", "yaw"], default="hover",
+                    help="hover: simulation/hover.py; yaw: simulation/yaw.py's yaw-setpoint task with domain randomisation")
     ap.add_argument("--drones", type=int, default=16384)
     ap.add_argument("--timesteps", type=float, default=2e8)
     ap.add_argument("--n-steps", type=int, default=32)
@@ -38,9 +40,10 @@ def main():
     torch.cuda.set_device(local % torch.cuda.device_count())
     dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.manual_seed(args.seed)                       # same initial policy on every rank
-    policy = ActorCritic(log_std_init=args.log_std_init).to(dev)
-    eng = FpvEngine(args.drones, dev, seed=args.seed, id_offset=rank * args.drones,
-                    ledger_capacity=args.drones * max(2, args.n_steps // 8))
+    obs_dim, act_dim = (20, 4) if args.task == "hover" else (12, 1)
+    policy = ActorCritic(obs_dim, act_dim, log_std_init=args.log_std_init).to(dev)
+    eng = FpvEngine(args.drones, dev, seed=args.seed, id_offset=rank * args.drones, task=args.task,
+                    domain_rand=args.task == "yaw", ledger_capacity=args.drones * max(2, args.n_steps // 8))
     col = RolloutCollector(eng, policy, n_steps=args.n_steps, policy_seed=args.seed, gamma=args.gamma)
     model = PPO(col, learning_rate=args.lr, n_epochs=args.epochs, n_minibatches=args.minibatches, ent_coef=args.ent_coef,
                 target_kl=args.target_kl, fused_update=not args.autograd_update, log_std_min=args.log_std_min)

@@ -27,6 +27,27 @@ def test_ppo_learns_to_hover():
     eng.close()
 
 
+def test_ppo_learns_the_yaw_task_under_domain_randomisation():
+    """BASELINE cfg 5 end to end: simulation/yaw.py's yaw-setpoint task with per-episode mass / drag randomisation;
+    episodes always run to the truncation limit, so learning shows in the return."""
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    from fpv_drone_rl_agent_amd.ppo import PPO
+    from fpv_drone_rl_agent_amd.rollout import RolloutCollector
+    torch.manual_seed(0)
+    n = 8192
+    eng = FpvEngine(n, 0, seed=0, task="yaw", domain_rand=True, ledger_capacity=n * 4)
+    pol = ActorCritic(12, 1, log_std_init=-2.0).cuda()
+    col = RolloutCollector(eng, pol, n_steps=32)
+    model = PPO(col, n_epochs=4, n_minibatches=8, target_kl=0.03, log_std_min=-3.5)
+    model.learn(32 * n * 30)
+    early = model.logger["rollout/ep_rew_mean"]
+    model.learn(32 * n * 400)
+    late = model.logger["rollout/ep_rew_mean"]
+    assert late > early + 50 and late > 60, (early, late)
+    eng.close()
+
+
 def test_checkpoint_cadence_roundtrip_and_playback(tmp_path):
     """train_hover.py:8-34,62-63 cadence and naming; test_hover.py:8-22 style playback of the saved pair."""
     import os
