@@ -77,6 +77,19 @@ hipError_t launch_reward_finalize(int64_t T, int64_t n, const float* raw, const 
 hipError_t launch_normalize_reward(int64_t n, const float* r, const uint8_t* done, float* ret, float* r_out,
                                    double* rms, int32_t update, float gamma, float clip, float eps, double* scratch,
                                    hipStream_t s);
+// Sum of v over the two 32-lane halves of the wave (lane i and lane i ^ 32), the same bits in both halves.
+// v_permlane32_swap_b32 (gfx950) stays on the VALU.  The LDS route (__shfl_xor -> ds_bpermute_b32) is avoided on
+// purpose: in the policy kernels it read a v_pk_fma_f32 result two instructions after the write and, with a partner
+// wave streaming MFMAs on the same SIMD, sporadically saw the stale register (fpv_policy_split.hip).
+__device__ __forceinline__ float half_sum(float v) {
+#ifdef FPV_HALFSUM_BPERMUTE
+    return v + __shfl_xor(v, 32);
+#else
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+#endif
+}
+
 // fpv_policy.hip
 hipError_t launch_policy_pack(const float* const* w, float* image, int in_dim, int act_dim, hipStream_t s);
 hipError_t launch_policy_forward(const float* image, const float* obs, const double* rms, const float* eps_in,

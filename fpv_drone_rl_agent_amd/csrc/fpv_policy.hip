@@ -262,7 +262,7 @@ __global__ __launch_bounds__(THREADS) void policy_forward_kernel(PolicyArgs p, i
         }
         // ---- combine the two lane halves, add biases
 #pragma unroll
-        for (int j = 0; j < 5; ++j) head[j] += __shfl_xor(head[j], 32);
+        for (int j = 0; j < 5; ++j) head[j] = half_sum(head[j]);
         if (do_v && live && h == 1) p.value[d] = head[4] + hb[644];
         if (!do_pi) continue;
         const float mu[4] = {head[0] + hb[640], head[1] + hb[641], head[2] + hb[642], head[3] + hb[643]};

@@ -257,11 +257,12 @@ __global__ __launch_bounds__(kSplitThreads) void policy_split_forward_kernel(Spl
 #pragma unroll
                 for (int r = 0; r < 16; ++r) c[m][r] = fast_tanh_s(c[m][r]);
 
-            // Workgroup barrier between the MFMA phase and the VALU epilogue.  Without it about 1 row in 10^4 came
-            // out with a corrupted first head component whenever a wave's epilogue (ds_read_b128 broadcasts +
-            // v_pk_fma_f32) co-executed with its SIMD partner's bf16 MFMA loop; the root cause is not established
-            // (tools/stress_policy.py: 2 x 10^7 rows clean with the barrier, same worst error as the fp32 kernel).
-            __syncthreads();
+            // The two lane halves are combined with half_sum() (v_permlane32_swap, VALU only).  The first version went
+            // through __shfl_xor -> ds_bpermute_b32 and about 1 row in 3 000 came out with a wrong FIRST head component:
+            // the ds_bpermute that read mu[0] issued two instructions after the v_pk_fma_f32 that wrote it and, while
+            // the SIMD's partner wave was streaming bf16 MFMAs, picked up the stale register (1 311 bad rows in 3.9 x 10^6
+            // with -DFPV_HALFSUM_BPERMUTE, 0 in 2 x 10^7 with the VALU swap; tools/stress_policy.py).  A workgroup
+            // barrier here used to hide it by keeping MFMA loops and epilogues apart; it is no longer needed.
             if (net == 0) {
                 // ---- action head on the VALU, sampling epilogue
                 float mu[4] = {0.f, 0.f, 0.f, 0.f};
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(kSplitThreads) void policy_split_forward_kernel(Spl
                         mu[0] += w.x * v; mu[1] += w.y * v; mu[2] += w.z * v; mu[3] += w.w * v;
                     }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mu[j] += __shfl_xor(mu[j], 32) + head[640 + j];
+                for (int j = 0; j < 4; ++j) mu[j] = half_sum(mu[j]) + head[640 + j];
                 float eps[4] = {0.f, 0.f, 0.f, 0.f};
                 if (!p.deterministic) {
                     if (p.eps_in) {
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(kSplitThreads) void policy_split_forward_kernel(Spl
                 for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) v += head[512 + (h * 4 + kt) * 16 + r] * c[kt][r];
-                v += __shfl_xor(v, 32);
+                v = half_sum(v);
                 if (live && h == 1) p.value[d] = v + head[644];
             }
         }

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(THREADS) void ppo_fwd_bwd_kernel(PpoArgs p) {
                 float z[4], lp = hb[kHLpc];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    mu[j] += __shfl_xor(mu[j], 32);
+                    mu[j] = half_sum(mu[j]);
                     mu[j] += hb[kHBa + j];
                     z[j] = (act[j] - mu[j]) * hb[kHInvStd + j];      // inv_std is 0 beyond act_dim
                     lp -= 0.5f * z[j] * z[j];
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(THREADS) void ppo_fwd_bwd_kernel(PpoArgs p) {
                         v += hb[kHWv + (h * 4 + kt) * 16 + r] * c.t[kt][r];
                         if (r == 15) __builtin_amdgcn_sched_barrier(0);
                     }
-                v += __shfl_xor(v, 32);
+                v = half_sum(v);
                 v += hb[kHBv];
                 const float ret = live ? p.ret[src] : 0.f;
                 const float err = live ? v - ret : 0.f;
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(512) void ppo_wgrad_kernel(WgradArgs p) {
         for (int r = 0; r < 4; ++r)
             if (r < nh) out[kPWh + r * kHid + 32 * w + i] = hd[r];
     }
-    sb2 += __shfl_xor(sb2, 32); sb1 += __shfl_xor(sb1, 32); sbh += __shfl_xor(sbh, 32);
+    sb2 = half_sum(sb2); sb1 = half_sum(sb1); sbh = half_sum(sbh);
     if (kk == 0) {
         out[kPB2 + 32 * w + i] = sb2;
         out[kPB1 + 32 * w + i] = sb1;

@@ -1,6 +1,9 @@
-"""Stress both policy GEMM modes: many launches, every row checked against an fp64 evaluation."""
+"""Stress both policy GEMM modes: many launches, every row checked against an fp64 evaluation.
+Building with FPV_EXTRA_HIPCC_FLAGS=-DFPV_HALFSUM_BPERMUTE brings back the ds_bpermute-after-v_pk_fma hazard that the
+kernels avoid (fpv_internal.h half_sum): the bf16x6 line then reports ~300 bad rows per 10^6."""
 import sys, copy, torch
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from fpv_drone_rl_agent_amd.policy import ActorCritic
 from fpv_drone_rl_agent_amd.ops_policy import FusedPolicy
 torch.manual_seed(5)
