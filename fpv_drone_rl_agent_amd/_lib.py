@@ -47,6 +47,8 @@ class FpvPolicyIo(C.Structure):
         ("logp", C.c_void_p), ("eps_out", C.c_void_p), ("seed", C.c_uint64), ("id_offset", C.c_uint64),
         ("clip_obs", C.c_float), ("eps_norm", C.c_float), ("deterministic", C.c_int32), ("nets", C.c_int32),
         ("narrow", C.c_int32), ("reserved", C.c_int32),
+        ("merge_partials", C.c_void_p), ("merge_rows", C.c_int64), ("merge_count", C.c_double), ("rms_out", C.c_void_p),
+        ("ret_rms", C.c_void_p), ("ret_rms_out", C.c_void_p), ("merge_snapshot", C.c_void_p),
     ]
 
 
@@ -69,6 +71,8 @@ SIGNATURES = {
     "fpv_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fpv_step_fused": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(FpvStepExtras), _vp]),
     "fpv_moments_merge": (C.c_int, [_i64, _vp, C.c_double, _vp, _vp, _vp, _vp]),
+    "fpv_partial_rows": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "fpv_moments_merge_to": (C.c_int, [_i64, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fpv_reward_finalize": (C.c_int, [_i64, _i64, _vp, _vp, _f32, _f32, _vp, _vp]),
     "fpv_dims": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "fpv_tick_ptr": (C.c_int, [_vp, C.POINTER(_vp)]),

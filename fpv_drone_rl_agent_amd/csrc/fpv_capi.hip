@@ -231,8 +231,21 @@ int fpv_moments_merge(int64_t tiles, const double* partials, double batch_count,
     if (tiles <= 0 || !partials || batch_count <= 0.0) return fail(FPV_ERR_ARG, "fpv_moments_merge: bad arguments");
     double* scratch = nullptr;
     if (int rc = scratch_for_current_device(&scratch)) return rc;
-    FPV_HIP(launch_moments_merge_tiles(tiles, partials, batch_count, obs_rms, ret_rms, snapshot, scratch,
+    FPV_HIP(launch_moments_merge_tiles(tiles, partials, batch_count, nullptr, nullptr, obs_rms, ret_rms, snapshot, scratch,
                                        (hipStream_t)stream));
+    return FPV_OK;
+}
+
+int fpv_moments_merge_to(int64_t tiles, const double* partials, double batch_count, const double* obs_rms_in,
+                         const double* ret_rms_in, double* obs_rms_out, double* ret_rms_out, double* snapshot,
+                         void* stream) {
+    if (tiles <= 0 || !partials || batch_count <= 0.0) return fail(FPV_ERR_ARG, "fpv_moments_merge_to: bad arguments");
+    if ((obs_rms_out && !obs_rms_in) || (ret_rms_out && !ret_rms_in))
+        return fail(FPV_ERR_ARG, "fpv_moments_merge_to: an output statistic needs its input");
+    double* scratch = nullptr;
+    if (int rc = scratch_for_current_device(&scratch)) return rc;
+    FPV_HIP(launch_moments_merge_tiles(tiles, partials, batch_count, obs_rms_in, ret_rms_in, obs_rms_out, ret_rms_out,
+                                       snapshot, scratch, (hipStream_t)stream));
     return FPV_OK;
 }
 
@@ -240,6 +253,14 @@ int fpv_reward_finalize(int64_t T, int64_t n, const float* raw, const double* sn
                         float* out, void* stream) {
     if (T <= 0 || n <= 0 || !raw || !snapshots || !out) return fail(FPV_ERR_ARG, "fpv_reward_finalize: bad arguments");
     FPV_HIP(launch_reward_finalize(T, n, raw, snapshots, clip, eps, out, (hipStream_t)stream));
+    return FPV_OK;
+}
+
+int fpv_partial_rows(fpv_env* e, int64_t* rows) {
+    if (!e || !rows) return fail(FPV_ERR_ARG, "fpv_partial_rows: null argument");
+    if (e->cfg.task != FPV_TASK_HOVER || e->cfg.precision != 0)
+        return fail(FPV_ERR_UNSUPPORTED, "fpv_partial_rows: fpv_step_fused serves fp32 hover handles");
+    *rows = step_partial_rows(e->cfg.num_envs, e->cfg.noise_ratio != 0.0);
     return FPV_OK;
 }
 
@@ -445,17 +466,29 @@ int fpv_policy_forward(fpv_policy* p, const fpv_policy_io* io, void* stream) {
                                                    (uintptr_t)io->eps_out) : 0;
     if (((uintptr_t)io->obs | (uintptr_t)io->obs_n | act_rows) & 15)
         return fail(FPV_ERR_ARG, "fpv_policy_forward: row buffers must be 16-byte aligned");
+    MergeArgs mg{};
+    if (io->merge_partials) {
+        if (io->merge_rows <= 0 || io->merge_rows > 1024)
+            return fail(FPV_ERR_UNSUPPORTED, "fpv_policy_forward: in-launch merge takes 1..1024 partial rows (use fpv_moments_merge beyond)");
+        if (p->in_dim != 20 || nets != 3 || io->narrow)
+            return fail(FPV_ERR_UNSUPPORTED, "fpv_policy_forward: in-launch merge needs the hover widths, both nets and 512-thread workgroups");
+        if (!(io->merge_count > 0.0)) return fail(FPV_ERR_ARG, "fpv_policy_forward: merge_count must be positive");
+        if ((io->rms && (!io->rms_out || io->rms_out == io->rms)) || (io->ret_rms && (!io->ret_rms_out || io->ret_rms_out == io->ret_rms)))
+            return fail(FPV_ERR_ARG, "fpv_policy_forward: merged statistics go to a second buffer (other workgroups still read the first)");
+        mg = MergeArgs{io->merge_partials, io->ret_rms, io->rms ? io->rms_out : nullptr, io->ret_rms ? io->ret_rms_out : nullptr,
+                       io->merge_snapshot, io->merge_count, (int32_t)io->merge_rows, 0};
+    }
     if (p->gemm == 1) {
         if (p->in_dim != 20 || p->act_dim != 4) return fail(FPV_ERR_UNSUPPORTED, "fpv_policy_forward: the bf16-split kernel is built for 20 -> 4");
         if (nets != 3 || io->narrow) return fail(FPV_ERR_UNSUPPORTED, "fpv_policy_forward: the bf16-split kernel evaluates both nets in 512-thread workgroups");
         FPV_HIP(launch_policy_split_forward(p->split_image, io->obs, io->rms, io->eps_in, io->tick, io->obs_n, io->action,
                                             io->clipped, io->value, io->logp, io->eps_out, io->n, io->seed, io->id_offset,
-                                            io->clip_obs, io->eps_norm, io->deterministic, p->cus, (hipStream_t)stream));
+                                            io->clip_obs, io->eps_norm, io->deterministic, p->cus, mg, (hipStream_t)stream));
         return FPV_OK;
     }
     FPV_HIP(launch_policy_forward(p->image, io->obs, io->rms, io->eps_in, io->tick, io->obs_n, io->action, io->clipped,
                                   io->value, io->logp, io->eps_out, io->n, io->seed, io->id_offset, io->clip_obs,
-                                  io->eps_norm, io->deterministic, p->cus, nets, io->narrow ? 1 : 0, p->in_dim, p->act_dim,
+                                  io->eps_norm, io->deterministic, p->cus, nets, io->narrow ? 1 : 0, p->in_dim, p->act_dim, mg,
                                   (hipStream_t)stream));
     return FPV_OK;
 }

@@ -62,6 +62,7 @@ template <typename T>
 hipError_t launch_yaw_convert(void* state, void* canon, int64_t n, bool to_canon, hipStream_t s);
 
 extern int64_t g_pair_max_tiles;
+int64_t step_partial_rows(int64_t n, bool noise);
 hipError_t launch_tick_fill(uint64_t* tick, int64_t tiles, uint64_t v, hipStream_t s);
 
 // fpv_rollout.hip
@@ -70,8 +71,9 @@ hipError_t launch_gae(int64_t T, int64_t n, const float* rewards, const float* v
                       float* returns, double* stats, double* scratch, hipStream_t s);
 hipError_t launch_normalize(int64_t n, int32_t d, const float* x, float* y, double* rms, int32_t update, float clip,
                             float eps, double* scratch, hipStream_t s);
-hipError_t launch_moments_merge_tiles(int64_t tiles, const double* partials, double batch_count, double* obs_rms,
-                                      double* ret_rms, double* snapshot, double* scratch, hipStream_t s);
+hipError_t launch_moments_merge_tiles(int64_t tiles, const double* partials, double batch_count, const double* obs_rms_in,
+                                      const double* ret_rms_in, double* obs_rms, double* ret_rms, double* snapshot,
+                                      double* scratch, hipStream_t s);
 hipError_t launch_reward_finalize(int64_t T, int64_t n, const float* raw, const double* snapshots, float clip, float eps,
                                   float* out, hipStream_t s);
 hipError_t launch_normalize_reward(int64_t n, const float* r, const uint8_t* done, float* ret, float* r_out,
@@ -90,13 +92,97 @@ __device__ __forceinline__ float half_sum(float v) {
 #endif
 }
 
+// ---- VecNormalize moment merge folded into the policy kernel's prologue ----
+// The rollout step is policy -> env step -> merge of the step's tile sums into the running statistics, and the next
+// policy launch needs the merged statistics.  As a kernel of its own the merge costs its 7.7 us plus a launch gap on
+// the critical path; here every policy workgroup folds the (<= 1024-row) table itself — same fixed order everywhere,
+// so all workgroups derive the same bits — and workgroup 0 publishes the new statistics to a SECOND buffer (the old
+// one is still being read by the other workgroups).
+struct MergeArgs {
+    const double* rows;      // [nrows][kPartialWords] tile sums of the previous env step; null = no merge
+    const double* ret_rms;   // [3] {mean, var, count} before the merge, or null
+    double* obs_rms_out;     // [41]; the statistics before the merge are the kernel's rms argument (may be null)
+    double* ret_rms_out;     // [3] or null
+    double* snapshot;        // [kPartialWords] or null
+    double batch_count;
+    int32_t nrows, reserved;
+};
+constexpr int kPrologueMergeWays = 9;                                   // 9 x 44 = 396 threads of a 512-thread workgroup
+constexpr int kMergeLdsBytes = kPrologueMergeWays * kPartialWords * 8;   // 3 168 B of exchange space
+
+// mean_f / inv_f: the normaliser the kernel will use (LDS, 20 floats each).  xch: kMergeLdsBytes of LDS.
+// Contains workgroup barriers: every thread of the workgroup must call it.
+__device__ __forceinline__ void merge_prologue(const MergeArgs& m, const double* __restrict__ obs_rms, double* xch,
+                                               float eps_norm, float* mean_f, float* inv_f) {
+    const int tid = threadIdx.x, j = tid / kPartialWords, c = tid - j * kPartialWords;
+    if (j < kPrologueMergeWays) {
+        constexpr int kBatch = 57;              // 2 batches cover 1 024 rows: two memory round trips
+        double acc = 0.0;
+        for (int q0 = 0; q0 * kPrologueMergeWays < m.nrows; q0 += kBatch) {
+            double v[kBatch];
+#pragma unroll
+            for (int q = 0; q < kBatch; ++q) {
+                const int b = j + (q0 + q) * kPrologueMergeWays;
+                v[q] = b < m.nrows ? m.rows[(int64_t)b * kPartialWords + c] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < kBatch; ++q) acc += v[q];
+        }
+        xch[j * kPartialWords + c] = acc;
+    }
+    __syncthreads();
+    if (tid < kPartialWords) {
+        double t = 0.0;
+        for (int w = 0; w < kPrologueMergeWays; ++w) t += xch[w * kPartialWords + tid];
+        xch[tid] = t;                           // row 0 <- column sums (each thread touches its own column only)
+    }
+    __syncthreads();
+    const bool publish = blockIdx.x == 0;
+    if (tid < 20) {
+        double nm = 0.0, nv = 1.0, tot = 0.0;
+        if (obs_rms) {
+            const double cnt = obs_rms[40], mean = obs_rms[tid], var = obs_rms[20 + tid];
+            const double bm = xch[tid] / m.batch_count;
+            double bv = xch[20 + tid] / m.batch_count - bm * bm;
+            if (bv < 0.0) bv = 0.0;
+            const double delta = bm - mean;
+            tot = cnt + m.batch_count;
+            nm = mean + delta * m.batch_count / tot;
+            nv = (var * cnt + bv * m.batch_count + delta * delta * cnt * m.batch_count / tot) / tot;
+            if (publish && m.obs_rms_out) {
+                m.obs_rms_out[tid] = nm; m.obs_rms_out[20 + tid] = nv;
+                if (tid == 0) m.obs_rms_out[40] = tot;
+            }
+            if (publish && m.snapshot) {
+                m.snapshot[tid] = nm; m.snapshot[20 + tid] = nv;
+                if (tid == 0) m.snapshot[40] = tot;
+            }
+            mean_f[tid] = (float)nm;
+            inv_f[tid] = (float)(1.0 / sqrt(nv + (double)eps_norm));
+        } else {
+            mean_f[tid] = 0.0f;
+            inv_f[tid] = 1.0f;
+        }
+    } else if (tid == 40 && m.ret_rms && publish) {
+        const double cnt = m.ret_rms[2], mean = m.ret_rms[0], var = m.ret_rms[1];
+        const double bm = xch[40] / m.batch_count;
+        double bv = xch[41] / m.batch_count - bm * bm;
+        if (bv < 0.0) bv = 0.0;
+        const double delta = bm - mean, tot = cnt + m.batch_count;
+        const double nm = mean + delta * m.batch_count / tot;
+        const double nv = (var * cnt + bv * m.batch_count + delta * delta * cnt * m.batch_count / tot) / tot;
+        if (m.ret_rms_out) { m.ret_rms_out[0] = nm; m.ret_rms_out[1] = nv; m.ret_rms_out[2] = tot; }
+        if (m.snapshot) { m.snapshot[41] = nm; m.snapshot[42] = nv; m.snapshot[43] = tot; }
+    }
+}
+
 // fpv_policy.hip
 hipError_t launch_policy_pack(const float* const* w, float* image, int in_dim, int act_dim, hipStream_t s);
 hipError_t launch_policy_forward(const float* image, const float* obs, const double* rms, const float* eps_in,
                                  const uint64_t* tick, float* obs_n, float* action, float* clipped, float* value,
                                  float* logp, float* eps_out, int64_t n, uint64_t seed, uint64_t id_offset,
                                  float clip_obs, float eps_norm, int deterministic, int max_blocks, int nets, int narrow,
-                                 int in_dim, int act_dim, hipStream_t s);
+                                 int in_dim, int act_dim, const MergeArgs& merge, hipStream_t s);
 int policy_image_floats();
 // fpv_ppo.hip
 int64_t ppo_workspace_floats(int64_t rows, int cus);
@@ -112,7 +198,8 @@ hipError_t launch_policy_split_pack(const float* const* w, unsigned char* image,
 hipError_t launch_policy_split_forward(const unsigned char* image, const float* obs, const double* rms, const float* eps_in,
                                        const uint64_t* tick, float* obs_n, float* action, float* clipped, float* value,
                                        float* logp, float* eps_out, int64_t n, uint64_t seed, uint64_t id_offset,
-                                       float clip_obs, float eps_norm, int deterministic, int max_blocks, hipStream_t s);
+                                       float clip_obs, float eps_norm, int deterministic, int max_blocks,
+                                       const MergeArgs& merge, hipStream_t s);
 int policy_split_image_bytes();
 
 constexpr int kScratchDoubles = 1024 * 80;  // per-device reduction scratch (partials)

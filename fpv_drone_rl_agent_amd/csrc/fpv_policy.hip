@@ -116,6 +116,7 @@ struct PolicyArgs {
     float clip_obs, eps_norm;
     int32_t deterministic;   // 1: action = mean (SB3 predict(deterministic=True), test_hover.py:17)
     int32_t in_dim, act_dim;
+    MergeArgs mg;            // mg.rows != null: fold the previous env step's tile sums into rms first (512 threads)
 };
 
 // one hidden layer's 64 values per lane: 4 accumulator tiles
@@ -172,11 +173,13 @@ __global__ __launch_bounds__(THREADS) void policy_forward_kernel(PolicyArgs p, i
             }
         }
         if (threadIdx.x < kHeadGran) reinterpret_cast<f32x4*>(hb)[threadIdx.x] = hv;
-        if ((int)threadIdx.x < p.in_dim) {
+        if (!p.mg.rows && (int)threadIdx.x < p.in_dim) {
             hb[660 + threadIdx.x] = p.rms ? (float)p.rms[threadIdx.x] : 0.0f;
             hb[680 + threadIdx.x] = p.rms ? (float)(1.0 / sqrt(p.rms[p.in_dim + threadIdx.x] + (double)p.eps_norm)) : 1.0f;
         }
     }
+    if (p.mg.rows)                              // uniform: the normaliser comes out of the merged statistics
+        merge_prologue(p.mg, p.rms, reinterpret_cast<double*>(hb + 700), p.eps_norm, hb + 660, hb + 680);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -333,12 +336,12 @@ hipError_t launch_policy_forward(const float* image, const float* obs, const dou
                                  const uint64_t* tick, float* obs_n, float* action, float* clipped, float* value,
                                  float* logp, float* eps_out, int64_t n, uint64_t seed, uint64_t id_offset,
                                  float clip_obs, float eps_norm, int deterministic, int max_blocks, int nets, int narrow,
-                                 int in_dim, int act_dim, hipStream_t s) {
+                                 int in_dim, int act_dim, const MergeArgs& merge, hipStream_t s) {
     // nets: 3 = pi + V (one launch), 1 = pi only (with the sampling epilogue), 2 = V only.
     // narrow: 256-thread workgroups (one wave per SIMD) so that other kernels can co-reside.
     static bool attr_set = false;
     if (!attr_set) {
-        const int full = (int)((2 * kNetFloats + (kImageFloats - kHeadBase) + 40) * sizeof(float));
+        const int full = (int)((2 * kNetFloats + (kImageFloats - kHeadBase) + 40) * sizeof(float)) + kMergeLdsBytes;
         hipError_t e = hipFuncSetAttribute((const void*)policy_forward_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, full);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)policy_forward_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, full);
@@ -346,9 +349,10 @@ hipError_t launch_policy_forward(const float* image, const float* obs, const dou
         attr_set = true;
     }
     const int net_first = nets == 2 ? 1 : 0, net_count = nets == 3 ? 2 : 1;
-    const size_t lds_bytes = (size_t)(net_count * kNetFloats + (kImageFloats - kHeadBase) + 40) * sizeof(float);
+    const size_t lds_bytes = (size_t)(net_count * kNetFloats + (kImageFloats - kHeadBase) + 40) * sizeof(float) +
+                             (merge.rows ? kMergeLdsBytes : 0);
     PolicyArgs p{image, obs, rms, eps_in, tick, obs_n, action, clipped, value, logp, eps_out,
-                 n, seed, id_offset, clip_obs, eps_norm, deterministic, in_dim, act_dim};
+                 n, seed, id_offset, clip_obs, eps_norm, deterministic, in_dim, act_dim, merge};
     const int threads = narrow ? 256 : 512, chunk = threads / 2;
     int64_t blocks = (n + chunk - 1) / chunk;
     if (blocks > max_blocks) blocks = max_blocks;

@@ -28,7 +28,7 @@ constexpr int kBiasBytes = 2 * 128 * 4;             // b1p, b2p (fp32, accumulat
 constexpr int kNetBytes = kW2Bytes + kW1Bytes + kBiasBytes;   // 123 904
 constexpr int kHeadFloats = 660;                    // Wa[512] Wv[128] ba[4] bv[1] pad log_std[4] std[4] logp_const
 constexpr int kSplitImageBytes = 2 * kNetBytes + kHeadFloats * 4;
-constexpr int kSplitLdsBytes = kNetBytes + kHeadFloats * 4 + 40 * 4;   // one net + heads + normaliser
+constexpr int kSplitLdsBytes = kNetBytes + kHeadFloats * 4 + 40 * 4 + kMergeLdsBytes;   // one net + heads + normaliser + merge exchange
 
 __host__ __device__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 // k index (inside a 32-row tile) of element j of lane half h at k-step s when an accumulator tile is the B operand
@@ -132,6 +132,7 @@ struct SplitArgs {
     uint64_t seed, id_offset;
     float clip_obs, eps_norm;
     int32_t deterministic;
+    MergeArgs mg;
 };
 
 __device__ __forceinline__ void philox_split(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
@@ -156,7 +157,9 @@ __global__ __launch_bounds__(kSplitThreads) void policy_split_forward_kernel(Spl
     // heads + normaliser once
     for (int q = threadIdx.x; q < kHeadFloats; q += kSplitThreads)
         head[q] = reinterpret_cast<const float*>(p.image + 2 * (size_t)kNetBytes)[q];
-    if (threadIdx.x < kIn) {
+    if (p.mg.rows) {                            // fold the previous env step's tile sums into the statistics first
+        merge_prologue(p.mg, p.rms, reinterpret_cast<double*>(nrm + 40), p.eps_norm, nrm, nrm + 20);
+    } else if (threadIdx.x < kIn) {
         nrm[threadIdx.x] = p.rms ? (float)p.rms[threadIdx.x] : 0.0f;
         nrm[20 + threadIdx.x] = p.rms ? (float)(1.0 / sqrt(p.rms[kIn + threadIdx.x] + (double)p.eps_norm)) : 1.0f;
     }
@@ -335,7 +338,8 @@ hipError_t launch_policy_split_pack(const float* const* w, unsigned char* image,
 hipError_t launch_policy_split_forward(const unsigned char* image, const float* obs, const double* rms, const float* eps_in,
                                        const uint64_t* tick, float* obs_n, float* action, float* clipped, float* value,
                                        float* logp, float* eps_out, int64_t n, uint64_t seed, uint64_t id_offset,
-                                       float clip_obs, float eps_norm, int deterministic, int max_blocks, hipStream_t s) {
+                                       float clip_obs, float eps_norm, int deterministic, int max_blocks,
+                                       const MergeArgs& merge, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)policy_split_forward_kernel,
@@ -344,7 +348,7 @@ hipError_t launch_policy_split_forward(const unsigned char* image, const float* 
         attr_set = true;
     }
     SplitArgs p{image, obs, rms, eps_in, tick, obs_n, action, clipped, value, logp, eps_out,
-                n, seed, id_offset, clip_obs, eps_norm, deterministic};
+                n, seed, id_offset, clip_obs, eps_norm, deterministic, merge};
     int64_t blocks = (n + kSplitDrones - 1) / kSplitDrones;
     if (blocks > max_blocks) blocks = max_blocks;
     hipLaunchKernelGGL(policy_split_forward_kernel, dim3((unsigned)blocks), dim3(kSplitThreads), kSplitLdsBytes, s, p);

@@ -242,7 +242,8 @@ __global__ __launch_bounds__(256) void tile_partials_reduce_kernel(const double*
 // thread keeps four independent accumulators so that its loads overlap.
 constexpr int kTileMergeWays = 23;
 __global__ __launch_bounds__(1024) void tile_partials_merge_kernel(const double* __restrict__ rows, int nrows,
-                                                                   double batch_count, double* obs_rms,
+                                                                   double batch_count, const double* obs_rms_in,
+                                                                   const double* ret_rms_in, double* obs_rms,
                                                                    double* ret_rms, double* snapshot) {
     __shared__ double l[kTileMergeWays][64];
     const int j = threadIdx.x / kPartialWords, c = threadIdx.x % kPartialWords;
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(1024) void tile_partials_merge_kernel(const double*
         for (int q = 0; q < kIter; ++q) acc += v[q];
         l[j][c] = acc;
     }
-    const double obs_count = obs_rms ? obs_rms[40] : 0.0, ret_count = ret_rms ? ret_rms[2] : 0.0;
+    const double obs_count = obs_rms ? obs_rms_in[40] : 0.0, ret_count = ret_rms ? ret_rms_in[2] : 0.0;
     __syncthreads();
     if (j == 0) {
         double acc = 0.0;
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(1024) void tile_partials_merge_kernel(const double*
         const double bm = l[0][c] / batch_count;
         double bv = l[0][20 + c] / batch_count - bm * bm;
         if (bv < 0.0) bv = 0.0;
-        const double mean = obs_rms[c], var = obs_rms[20 + c], delta = bm - mean, tot = obs_count + batch_count;
+        const double mean = obs_rms_in[c], var = obs_rms_in[20 + c], delta = bm - mean, tot = obs_count + batch_count;
         const double nm = mean + delta * batch_count / tot;
         const double nv = (var * obs_count + bv * batch_count + delta * delta * obs_count * batch_count / tot) / tot;
         obs_rms[c] = nm; obs_rms[20 + c] = nv;
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(1024) void tile_partials_merge_kernel(const double*
         const double bm = l[0][40] / batch_count;
         double bv = l[0][41] / batch_count - bm * bm;
         if (bv < 0.0) bv = 0.0;
-        const double mean = ret_rms[0], var = ret_rms[1], delta = bm - mean, tot = ret_count + batch_count;
+        const double mean = ret_rms_in[0], var = ret_rms_in[1], delta = bm - mean, tot = ret_count + batch_count;
         const double nm = mean + delta * batch_count / tot;
         const double nv = (var * ret_count + bv * batch_count + delta * delta * ret_count * batch_count / tot) / tot;
         ret_rms[0] = nm; ret_rms[1] = nv; ret_rms[2] = tot;
@@ -293,8 +294,9 @@ __global__ __launch_bounds__(1024) void tile_partials_merge_kernel(const double*
     }
 }
 
-hipError_t launch_moments_merge_tiles(int64_t tiles, const double* partials, double batch_count, double* obs_rms,
-                                      double* ret_rms, double* snapshot, double* scratch, hipStream_t s) {
+hipError_t launch_moments_merge_tiles(int64_t tiles, const double* partials, double batch_count, const double* obs_rms_in,
+                                      const double* ret_rms_in, double* obs_rms, double* ret_rms, double* snapshot,
+                                      double* scratch, hipStream_t s) {
     const double* rows = partials;
     int nrows = (int)tiles;
     if (tiles > 1024) {
@@ -304,8 +306,8 @@ hipError_t launch_moments_merge_tiles(int64_t tiles, const double* partials, dou
         rows = scratch;
         nrows = (int)((tiles + per_group - 1) / per_group);
     }
-    hipLaunchKernelGGL(tile_partials_merge_kernel, dim3(1), dim3(1024), 0, s, rows, nrows, batch_count, obs_rms,
-                       ret_rms, snapshot);
+    hipLaunchKernelGGL(tile_partials_merge_kernel, dim3(1), dim3(1024), 0, s, rows, nrows, batch_count,
+                       obs_rms_in ? obs_rms_in : obs_rms, ret_rms_in ? ret_rms_in : ret_rms, obs_rms, ret_rms, snapshot);
     return hipGetLastError();
 }
 

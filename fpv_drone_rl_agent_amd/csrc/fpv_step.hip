@@ -104,12 +104,18 @@ __device__ __forceinline__ void tile_moment_sums(const float* lds_w, double* xch
 }
 
 // ---------------------------------------------------------------- K1
-template <typename T, bool NOISE, bool FUSED>
-__global__ __launch_bounds__(kTile) void step_kernel(StepArgs<T> p) {
-    // observation tile; fused variant: + 64 returns + a 64 x 2 fp64 exchange area (fp32 handles only)
-    __shared__ Vec4<T> lds[kTile * kObsWords / 4 + (FUSED ? kTile / 4 + kTile : 0)];
-    const int lane = threadIdx.x;
-    const int64_t tile = blockIdx.x;
+// TPB tiles (waves) per workgroup.  The waves are independent except at the very end of the fused variant, where a
+// TPB = 4 workgroup adds its four tiles' moment sums and writes ONE partial row: the table that the statistics merge
+// (fpv_moments_merge, or the policy kernel's prologue) has to read shrinks fourfold.
+template <typename T, bool NOISE, bool FUSED, int TPB = 1>
+__global__ __launch_bounds__(kTile * TPB) void step_kernel(StepArgs<T> p) {
+    // per wave: observation tile; fused variant: + 64 returns + a 64 x 2 fp64 exchange area (fp32 handles only)
+    constexpr int kLdsPerTile = kTile * kObsWords / 4 + (FUSED ? kTile / 4 + kTile : 0);
+    __shared__ Vec4<T> lds_all[TPB * kLdsPerTile];
+    __shared__ double bsum[TPB > 1 ? TPB * kPartialWords : 1];
+    const int lane = threadIdx.x & (kTile - 1), wv = threadIdx.x / kTile;
+    Vec4<T>* lds = lds_all + wv * kLdsPerTile;
+    const int64_t tile = (int64_t)blockIdx.x * TPB + wv;
     const int64_t i = tile * kTile + lane;
     const bool live = i < p.n;
 
@@ -208,7 +214,13 @@ __global__ __launch_bounds__(kTile) void step_kernel(StepArgs<T> p) {
             if constexpr (sizeof(T) == 4) {
                 const int rows = (int)((p.n - tile * kTile) < kTile ? (p.n - tile * kTile) : kTile);
                 tile_moment_sums(reinterpret_cast<const float*>(lds), reinterpret_cast<double*>(lds_w + kTile * kObsWords + kTile),
-                                 rows, lane, p.partials + tile * kPartialWords);
+                                 rows, lane, TPB > 1 ? bsum + wv * kPartialWords : p.partials + tile * kPartialWords);
+                if constexpr (TPB == 4) {
+                    __syncthreads();
+                    if (wv == 0 && lane < kPartialWords)
+                        p.partials[(int64_t)blockIdx.x * kPartialWords + lane] =
+                            (bsum[lane] + bsum[kPartialWords + lane]) + (bsum[2 * kPartialWords + lane] + bsum[3 * kPartialWords + lane]);
+                }
             }
         }
     } else {
@@ -445,6 +457,11 @@ hipError_t launch_step(const StepArgs<T>& a, bool noise, hipStream_t s) {
             return hipGetLastError();
         }
         if (fused) {
+            if (tiles % 4 == 0) {               // four tiles per workgroup, one partial row per workgroup (step_partial_rows)
+                if (noise) hipLaunchKernelGGL((step_kernel<T, true, true, 4>), dim3((unsigned)(tiles / 4)), dim3(4 * kTile), 0, s, a);
+                else hipLaunchKernelGGL((step_kernel<T, false, true, 4>), dim3((unsigned)(tiles / 4)), dim3(4 * kTile), 0, s, a);
+                return hipGetLastError();
+            }
             if (noise) hipLaunchKernelGGL((step_kernel<T, true, true>), dim3((unsigned)tiles), dim3(kTile), 0, s, a);
             else hipLaunchKernelGGL((step_kernel<T, false, true>), dim3((unsigned)tiles), dim3(kTile), 0, s, a);
             return hipGetLastError();
@@ -454,6 +471,13 @@ hipError_t launch_step(const StepArgs<T>& a, bool noise, hipStream_t s) {
     else hipLaunchKernelGGL((step_kernel<T, false, false>), dim3((unsigned)tiles), dim3(kTile), 0, s, a);
     return hipGetLastError();
 }
+// rows of extras.partials that a fused fp32 step of n drones writes (mirrors the dispatch above)
+int64_t step_partial_rows(int64_t n, bool noise) {
+    const int64_t tiles = (n + kTile - 1) / kTile;
+    if (noise && g_pair_max_tiles > 0 && tiles <= g_pair_max_tiles) return tiles;
+    return tiles % 4 == 0 ? tiles / 4 : tiles;
+}
+
 template hipError_t launch_step<float>(const StepArgs<float>&, bool, hipStream_t);
 template hipError_t launch_step<double>(const StepArgs<double>&, bool, hipStream_t);
 

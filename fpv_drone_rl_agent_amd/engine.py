@@ -113,11 +113,22 @@ class FpvEngine:
                    _stream(self.device)), "fpv_step")
         return obs, reward, terminated, truncated
 
+    @property
+    def partial_rows(self) -> int:
+        """Rows of `partials` that step_fused writes (one per 64-drone tile, or per four tiles): fpv_partial_rows."""
+        r = C.c_int64()
+        L.check(self.lib.fpv_partial_rows(self._h, C.byref(r)), "fpv_partial_rows")
+        return int(r.value)
+
     def step_fused(self, actions, *, done=None, ret=None, partials=None, gamma: float = 0.99, obs=None, reward=None):
         """fpv_step_fused: the env step plus VecNormalize's per-step bookkeeping (done mask, discounted-return
-        accumulator, per-tile moment sums) in the same kernel.  fp32 engines only."""
+        accumulator, moment sums in the first `partial_rows` rows of partials [tiles, 44]) in the same kernel.
+        fp32 engines only."""
         if self._f64:
             raise ValueError("step_fused runs on fp32 engines")
+        if partials is not None and (partials.dtype != torch.float64 or not partials.is_contiguous()
+                                     or partials.shape[0] < self.partial_rows or partials.shape[1] != 44):
+            raise ValueError("partials must be a contiguous float64 [>= partial_rows, 44] device tensor")
         if actions.dtype != self.dtype or actions.device != self.device or not actions.is_contiguous() \
                 or actions.shape != (self.num_envs, self.act_words) or self.task != "hover":
             raise ValueError("actions must be a contiguous [num_envs, 4] device tensor of the engine's dtype")

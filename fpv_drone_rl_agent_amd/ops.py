@@ -108,11 +108,18 @@ class RewardNorm:
         return out
 
 
-def moments_merge(partials, batch_count, obs_rms=None, ret_rms=None, snapshot=None):
-    """Fold the per-tile sums written by FpvEngine.step_fused into the running statistics (fpv_moments_merge)."""
+def moments_merge(partials, batch_count, obs_rms=None, ret_rms=None, snapshot=None, obs_rms_in=None, ret_rms_in=None):
+    """Fold the per-tile sums written by FpvEngine.step_fused into the running statistics (fpv_moments_merge).
+    obs_rms_in / ret_rms_in: read the statistics from these buffers instead and write obs_rms / ret_rms."""
     _need(partials, torch.float64, "partials")
-    L.check(L.load().fpv_moments_merge(partials.shape[0], _ptr(partials), float(batch_count), _ptr(obs_rms),
-                                       _ptr(ret_rms), _ptr(snapshot), _stream(partials.device)), "fpv_moments_merge")
+    if obs_rms_in is None and ret_rms_in is None:
+        L.check(L.load().fpv_moments_merge(partials.shape[0], _ptr(partials), float(batch_count), _ptr(obs_rms),
+                                           _ptr(ret_rms), _ptr(snapshot), _stream(partials.device)), "fpv_moments_merge")
+        return
+    L.check(L.load().fpv_moments_merge_to(partials.shape[0], _ptr(partials), float(batch_count),
+                                          _ptr(obs_rms_in if obs_rms is not None else None),
+                                          _ptr(ret_rms_in if ret_rms is not None else None), _ptr(obs_rms), _ptr(ret_rms),
+                                          _ptr(snapshot), _stream(partials.device)), "fpv_moments_merge_to")
 
 
 def reward_finalize(raw, snapshots, clip=10.0, eps=1e-8, out=None):

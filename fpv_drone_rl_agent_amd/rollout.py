@@ -37,7 +37,7 @@ class RolloutCollector:
     def __init__(self, engine: FpvEngine, policy: ActorCritic, n_steps: int = 32, gamma: float = 0.99,
                  lam: float = 0.95, norm_obs: bool = True, norm_reward: bool = True, use_graph: bool = True,
                  clip_obs: float = 10.0, clip_reward: float = 10.0, fused: bool = True, policy_seed: int = 0,
-                 policy_gemm: str = "f32", overlap_critic: bool = False):
+                 policy_gemm: str = "f32", overlap_critic: bool = False, merge_in_policy: bool = True):
         if engine.dtype != torch.float32:
             raise ValueError("the rollout collector runs on an fp32 engine")
         self.engine, self.policy = engine, policy
@@ -78,7 +78,8 @@ class RolloutCollector:
             self.fp = FusedPolicy(policy, seed=policy_seed, id_offset=engine.id_offset,
                                   gemm=policy_gemm if self.fused else "f32")
         if self.fused:
-            self.partials = torch.zeros((engine.tiles, 44), dtype=torch.float64, device=dev)
+            self._partials_full = torch.zeros((engine.tiles, 44), dtype=torch.float64, device=dev)
+            self.partials = self._partials_full[:engine.partial_rows]       # the rows fpv_step_fused writes
             self.raw_rew = torch.zeros((T, N), dtype=f32, device=dev)
             # overlap_critic: the env step needs pi only, so the critic pass (MFMA-bound) can run on a second stream
             # beside the env-step kernel (VALU-bound).  Measured on MI355X (profiles/r01_overlap_experiment.txt): alone
@@ -86,6 +87,11 @@ class RolloutCollector:
             # issue slots and the instruction cache — so the serial schedule is faster and this stays off by default.
             self.overlap_critic = bool(overlap_critic) and policy_gemm == "f32"
             self._vstream = torch.cuda.Stream(dev) if self.overlap_critic else None
+            # VecNormalize's statistics update inside the next policy launch (fpv_policy_io.merge_*): up to 1 024 tiles
+            self._merge_in_policy = (bool(merge_in_policy) and engine.tiles <= 1024 and (self.norm_obs or self.norm_reward)
+                                     and not self.overlap_critic)   # (the table is <= 1 024 rows by construction)
+            self._obs_rms_alt = torch.zeros_like(self.obs_norm.rms)
+            self._ret_rms_alt = torch.zeros_like(self.rew_norm.rms)
         self.stats = torch.zeros((3,), dtype=torch.float64, device=dev)
         self._graph = None
         self._tick0 = 0
@@ -135,14 +141,41 @@ class RolloutCollector:
             self._vstream.wait_stream(main)
             with torch.cuda.stream(self._vstream):     # V(s_t) from the normalised row the pi pass just wrote
                 self.fp.forward(self.buf_obs[t], value=self.buf_val[t], nets="v", narrow=True, deterministic=True)
+        elif self._merge_in_policy:
+            # the statistics update of step t - 1 rides in this policy launch's prologue (no merge launch on the
+            # critical path); the statistics ping-pong between two buffers because workgroup 0 publishes the merged
+            # values while the other workgroups still read the previous ones
+            (o_in, r_in), (o_out, r_out) = self._stat_bufs(t - 1), self._stat_bufs(t)
+            merge = None if t == 0 else {"partials": self.partials, "count": self.N, "rms_out": o_out, "ret_rms": r_in,
+                                         "ret_rms_out": r_out, "snapshot": self.snap[t - 1]}
+            self.fp.forward(eng.obs, rms=self._stat_bufs(0)[0] if t == 0 else o_in, tick=eng.tick_ptr, obs_n=self.buf_obs[t],
+                            action=self.buf_act[t], clipped=self.clipped, value=self.buf_val[t], logp=self.buf_logp[t],
+                            clip_obs=self.obs_norm.clip, eps_norm=self.obs_norm.eps, merge=merge)
         else:
             self.fp.forward(eng.obs, rms=rms, tick=eng.tick_ptr, obs_n=self.buf_obs[t], action=self.buf_act[t],
                             clipped=self.clipped, value=self.buf_val[t], logp=self.buf_logp[t],
                             clip_obs=self.obs_norm.clip, eps_norm=self.obs_norm.eps)
         eng.step_fused(self.clipped, done=self._starts[t + 1], ret=self.rew_norm.ret, partials=self.partials,
                        gamma=self.gamma, reward=self.raw_rew[t])
+        if not self._merge_in_policy:
+            ops.moments_merge(self.partials, self.N, obs_rms=self.obs_norm.rms if self.norm_obs else None,
+                              ret_rms=self.rew_norm.rms if self.norm_reward else None, snapshot=self.snap[t])
+
+    def _stat_bufs(self, merges_done: int):
+        """(obs statistics, return statistics) as they stand after `merges_done` in-launch merges of this rollout:
+        the canonical tensors after an even number, the alternates after an odd one (None where normalisation is off)."""
+        k = max(merges_done, 0) % 2
+        return ((self.obs_norm.rms, self._obs_rms_alt)[k] if self.norm_obs else None,
+                (self.rew_norm.rms, self._ret_rms_alt)[k] if self.norm_reward else None)
+
+    def _merge_tail(self, t_last: int) -> None:
+        """Fold the tile sums of step t_last (the last one executed) and leave the result in the canonical tensors."""
+        if not (self.fused and self._merge_in_policy):
+            return
+        o_in, r_in = self._stat_bufs(t_last)
         ops.moments_merge(self.partials, self.N, obs_rms=self.obs_norm.rms if self.norm_obs else None,
-                          ret_rms=self.rew_norm.rms if self.norm_reward else None, snapshot=self.snap[t])
+                          ret_rms=self.rew_norm.rms if self.norm_reward else None, snapshot=self.snap[t_last],
+                          obs_rms_in=o_in, ret_rms_in=r_in)
 
     def _step_torch(self, t: int) -> None:
         eng, pol = self.engine, self.policy
@@ -167,6 +200,7 @@ class RolloutCollector:
         self._starts[0].copy_(self._starts[self.T])
         for t in range(self.T):
             self._step(t)
+        self._merge_tail(self.T - 1)
         if self.fused and self.overlap_critic:
             torch.cuda.current_stream(self.device).wait_stream(self._vstream)   # join the critic passes
 
@@ -185,6 +219,7 @@ class RolloutCollector:
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):       # warm-up outside capture: lazy allocations, rocBLAS handles
             self._step(0)
+            self._merge_tail(0)
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         self._tick0 += 1

@@ -111,9 +111,11 @@ int fpv_step_f64(fpv_env* env, const double* actions, double* obs, double* rewar
 /* fpv_step plus SB3 VecNormalize's per-step bookkeeping in the same kernel (simulation/train_hover.py:43):
  * extras.done [num_envs] = terminated | truncated; extras.ret [num_envs] is VecNormalize's discounted-return
  * accumulator (ret = ret * gamma + reward, cleared where an episode ended); extras.partials
- * [ceil(num_envs/64)][FPV_PARTIAL_WORDS] receives, per 64-drone tile, the fp64 sums
- * {sum obs[20], sum obs^2[20], sum ret, sum ret^2, 0, 0} of the returned observations and of ret, to be
- * folded into the running statistics by fpv_moments_merge.  Any of the three may be NULL.  fp32 handles. */
+ * [ceil(num_envs/64)][FPV_PARTIAL_WORDS] (capacity) receives fp64 sums
+ * {sum obs[20], sum obs^2[20], sum ret, sum ret^2, 0, 0} of the returned observations and of ret, one row per
+ * 64-drone tile or per group of four tiles: fpv_partial_rows() says how many rows are written (ask again after
+ * fpv_set_pair_threshold); they are folded into the running statistics by fpv_moments_merge(rows, ...) or by
+ * the next fpv_policy_forward (merge_* fields).  Any of the three may be NULL.  fp32 hover handles. */
 #define FPV_PARTIAL_WORDS 44
 typedef struct {
     uint8_t* done;
@@ -125,11 +127,17 @@ typedef struct {
 int fpv_step_fused(fpv_env* env, const float* actions, float* obs, float* reward, uint8_t* terminated,
                    uint8_t* truncated, const fpv_step_extras* extras, void* stream);
 
+int fpv_partial_rows(fpv_env* env, int64_t* rows);
+
 /* RunningMeanStd.update for both VecNormalize statistics from the per-tile sums of fpv_step_fused:
  * obs_rms = double[41] {mean[20], var[20], count}, ret_rms = double[3] {mean, var, count} (either may be
  * NULL); snapshot (optional double[FPV_PARTIAL_WORDS]) receives {obs_rms[41], ret_rms[3]} after the merge. */
 int fpv_moments_merge(int64_t tiles, const double* partials, double batch_count, double* obs_rms,
                       double* ret_rms, double* snapshot, void* stream);
+/* The same with separate inputs and outputs (in == out is allowed). */
+int fpv_moments_merge_to(int64_t tiles, const double* partials, double batch_count, const double* obs_rms_in,
+                         const double* ret_rms_in, double* obs_rms_out, double* ret_rms_out, double* snapshot,
+                         void* stream);
 
 /* VecNormalize.normalize_reward applied after the fact: out[t][i] = clip(raw[t][i] / sqrt(var_t + eps)) with
  * var_t = snapshots[t][42], the return variance as it stood after step t.  raw/out are [T][n]; out may alias raw. */
@@ -223,6 +231,18 @@ typedef struct {
     int32_t narrow;          /* 1: 256-thread workgroups (one wave per SIMD) so that a VALU-bound kernel such as
                                 fpv_step can co-execute on another stream; 0: 512-thread workgroups */
     int32_t reserved;
+    /* Optional in-launch VecNormalize update (all NULL / 0 to skip): fold the tile sums that the PREVIOUS fpv_step_fused
+     * wrote (extras.partials, merge_rows <= 1024 rows) into the statistics before normalising — what fpv_moments_merge
+     * does, without its launch on the rollout's critical path.  `rms` (and `ret_rms`) are read; the merged statistics
+     * are written to rms_out / ret_rms_out, which must be different buffers; merge_snapshot as in fpv_moments_merge.
+     * Needs the hover widths, nets = 0 / 3 and narrow = 0. */
+    const double* merge_partials;
+    int64_t merge_rows;
+    double merge_count;      /* drones behind the sums (batch count of the RunningMeanStd update) */
+    double* rms_out;         /* [41] */
+    const double* ret_rms;   /* [3] or NULL */
+    double* ret_rms_out;     /* [3] */
+    double* merge_snapshot;  /* [FPV_PARTIAL_WORDS] or NULL */
 } fpv_policy_io;
 
 int fpv_policy_forward(fpv_policy* pol, const fpv_policy_io* io, void* stream);
