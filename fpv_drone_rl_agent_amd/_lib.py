@@ -48,7 +48,7 @@ class FpvPolicyIo(C.Structure):
         ("clip_obs", C.c_float), ("eps_norm", C.c_float), ("deterministic", C.c_int32), ("nets", C.c_int32),
         ("narrow", C.c_int32), ("reserved", C.c_int32),
         ("merge_partials", C.c_void_p), ("merge_rows", C.c_int64), ("merge_count", C.c_double), ("rms_out", C.c_void_p),
-        ("ret_rms", C.c_void_p), ("ret_rms_out", C.c_void_p), ("merge_snapshot", C.c_void_p),
+        ("ret_rms", C.c_void_p), ("ret_rms_out", C.c_void_p), ("merge_snapshot", C.c_void_p), ("n_dev", C.c_void_p),
     ]
 
 
@@ -84,6 +84,8 @@ SIGNATURES = {
     "fpv_ledger_view": (C.c_int, [_vp, C.POINTER(FpvLedger)]),
     "fpv_ledger_clear": (C.c_int, [_vp, _vp]),
     "fpv_ledger_bind": (C.c_int, [_vp, C.POINTER(FpvLedger)]),
+    "fpv_ledger_scan": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "fpv_ledger_scatter": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _vp, _i64, _i64, _vp]),
     "fpv_gae": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp]),
     "fpv_normalize": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _i32, _f32, _f32, _vp]),
     "fpv_normalize_reward": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _vp]),

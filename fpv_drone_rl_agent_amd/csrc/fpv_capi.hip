@@ -359,7 +359,27 @@ int fpv_ledger_bind(fpv_env* e, const fpv_ledger* b) {
 
 int fpv_ledger_clear(fpv_env* e, void* stream) {
     if (!e) return fail(FPV_ERR_ARG, "fpv_ledger_clear: null handle");
-    FPV_HIP(hipMemsetAsync(e->led_count, 0, (size_t)e->tiles * sizeof(uint32_t), (hipStream_t)stream));
+    FPV_HIP(launch_zero_words(e->led_count, e->tiles, (hipStream_t)stream));   // a kernel: safe inside a captured graph
+    return FPV_OK;
+}
+
+int fpv_ledger_scan(fpv_env* e, const double* snapshots, int64_t snapshot_stride, int32_t T, float clip_obs, float eps_norm,
+                    float* tobs, int32_t* t_idx, int32_t* d_idx, int64_t cap, int32_t* counters, double* sums, void* stream) {
+    if (!e || !tobs || !t_idx || !d_idx || !counters || !sums || cap <= 0 || T <= 0)
+        return fail(FPV_ERR_ARG, "fpv_ledger_scan: null argument, cap <= 0 or T <= 0");
+    if (e->cfg.precision != FPV_F32) return fail(FPV_ERR_UNSUPPORTED, "fpv_ledger_scan: fp32 handles");
+    if (snapshots && snapshot_stride < 2 * e->obs_words) return fail(FPV_ERR_ARG, "fpv_ledger_scan: snapshot rows hold {mean[O], var[O], ...}");
+    FPV_HIP(launch_ledger_scan(e->led_count, e->led_idx, e->led_info, e->led_tag, (const float*)e->led_ret, (const float*)e->led_obs,
+                               e->tick, e->tiles, (int)e->led_rows, e->obs_words, snapshots, snapshot_stride, T, clip_obs, eps_norm,
+                               tobs, t_idx, d_idx, cap, counters, sums, (hipStream_t)stream));
+    return FPV_OK;
+}
+
+int fpv_ledger_scatter(const int32_t* counters, const int32_t* t_idx, const int32_t* d_idx, const float* values, float gamma,
+                       float* rewards, int64_t n, int64_t cap, void* stream) {
+    if (!counters || !t_idx || !d_idx || !values || !rewards || n <= 0 || cap <= 0)
+        return fail(FPV_ERR_ARG, "fpv_ledger_scatter: null argument or non-positive size");
+    FPV_HIP(launch_ledger_scatter(counters, t_idx, d_idx, values, gamma, rewards, n, cap, (hipStream_t)stream));
     return FPV_OK;
 }
 
@@ -478,9 +498,9 @@ int fpv_policy_forward(fpv_policy* p, const fpv_policy_io* io, void* stream) {
         mg = MergeArgs{io->merge_partials, io->ret_rms, io->rms ? io->rms_out : nullptr, io->ret_rms ? io->ret_rms_out : nullptr,
                        io->merge_snapshot, io->merge_count, (int32_t)io->merge_rows, 0};
     }
-    if (p->gemm == 1) {
-        if (p->in_dim != 20 || p->act_dim != 4) return fail(FPV_ERR_UNSUPPORTED, "fpv_policy_forward: the bf16-split kernel is built for 20 -> 4");
-        if (nets != 3 || io->narrow) return fail(FPV_ERR_UNSUPPORTED, "fpv_policy_forward: the bf16-split kernel evaluates both nets in 512-thread workgroups");
+    // the bf16-split kernel evaluates both nets of the hover widths in 512-thread workgroups over a host-side row count;
+    // any other request is served by the exact-fp32 kernel (its image is always packed)
+    if (p->gemm == 1 && p->in_dim == 20 && p->act_dim == 4 && nets == 3 && !io->narrow && !io->n_dev) {
         FPV_HIP(launch_policy_split_forward(p->split_image, io->obs, io->rms, io->eps_in, io->tick, io->obs_n, io->action,
                                             io->clipped, io->value, io->logp, io->eps_out, io->n, io->seed, io->id_offset,
                                             io->clip_obs, io->eps_norm, io->deterministic, p->cus, mg, (hipStream_t)stream));
@@ -489,7 +509,7 @@ int fpv_policy_forward(fpv_policy* p, const fpv_policy_io* io, void* stream) {
     FPV_HIP(launch_policy_forward(p->image, io->obs, io->rms, io->eps_in, io->tick, io->obs_n, io->action, io->clipped,
                                   io->value, io->logp, io->eps_out, io->n, io->seed, io->id_offset, io->clip_obs,
                                   io->eps_norm, io->deterministic, p->cus, nets, io->narrow ? 1 : 0, p->in_dim, p->act_dim, mg,
-                                  (hipStream_t)stream));
+                                  io->n_dev, (hipStream_t)stream));
     return FPV_OK;
 }
 

@@ -92,6 +92,15 @@ __device__ __forceinline__ float half_sum(float v) {
 #endif
 }
 
+hipError_t launch_zero_words(uint32_t* a, int64_t n, hipStream_t s);
+hipError_t launch_ledger_scan(const uint32_t* led_count, const int32_t* led_idx, const uint32_t* led_info, const uint32_t* led_tag,
+                              const float* led_ret, const float* led_obs, const uint64_t* tick, int64_t tiles, int rows,
+                              int obs_words, const double* snapshots, int64_t stride, int T, float clip_obs, float eps,
+                              float* tobs, int32_t* t_idx, int32_t* d_idx, int64_t cap, int32_t* counters, double* sums,
+                              hipStream_t s);
+hipError_t launch_ledger_scatter(const int32_t* counters, const int32_t* t_idx, const int32_t* d_idx, const float* v, float gamma,
+                                 float* rewards, int64_t n, int64_t cap, hipStream_t s);
+
 // ---- VecNormalize moment merge folded into the policy kernel's prologue ----
 // The rollout step is policy -> env step -> merge of the step's tile sums into the running statistics, and the next
 // policy launch needs the merged statistics.  As a kernel of its own the merge costs its 7.7 us plus a launch gap on
@@ -110,23 +119,40 @@ struct MergeArgs {
 constexpr int kPrologueMergeWays = 9;                                   // 9 x 44 = 396 threads of a 512-thread workgroup
 constexpr int kMergeLdsBytes = kPrologueMergeWays * kPartialWords * 8;   // 3 168 B of exchange space
 
+// Two phases so that the table's first batch travels together with whatever the caller requests in between (the
+// weight image): merge_request() only issues loads, merge_prologue() adds them up and derives the statistics.
+constexpr int kMergeBatch = 57;                 // rows per way and batch: one batch covers 513 rows
+struct MergeRegs {
+    double v[kMergeBatch];
+};
+
+__device__ __forceinline__ void merge_request(const MergeArgs& m, MergeRegs& r) {
+    const int tid = threadIdx.x, j = tid / kPartialWords, c = tid - j * kPartialWords;
+#pragma unroll
+    for (int q = 0; q < kMergeBatch; ++q) {
+        const int b = j + q * kPrologueMergeWays;
+        r.v[q] = (j < kPrologueMergeWays && b < m.nrows) ? m.rows[(int64_t)b * kPartialWords + c] : 0.0;
+    }
+}
+
 // mean_f / inv_f: the normaliser the kernel will use (LDS, 20 floats each).  xch: kMergeLdsBytes of LDS.
 // Contains workgroup barriers: every thread of the workgroup must call it.
-__device__ __forceinline__ void merge_prologue(const MergeArgs& m, const double* __restrict__ obs_rms, double* xch,
-                                               float eps_norm, float* mean_f, float* inv_f) {
+__device__ __forceinline__ void merge_prologue(const MergeArgs& m, const MergeRegs& r, const double* __restrict__ obs_rms,
+                                               double* xch, float eps_norm, float* mean_f, float* inv_f) {
     const int tid = threadIdx.x, j = tid / kPartialWords, c = tid - j * kPartialWords;
     if (j < kPrologueMergeWays) {
-        constexpr int kBatch = 57;              // 2 batches cover 1 024 rows: two memory round trips
         double acc = 0.0;
-        for (int q0 = 0; q0 * kPrologueMergeWays < m.nrows; q0 += kBatch) {
-            double v[kBatch];
 #pragma unroll
-            for (int q = 0; q < kBatch; ++q) {
+        for (int q = 0; q < kMergeBatch; ++q) acc += r.v[q];
+        for (int q0 = kMergeBatch; q0 * kPrologueMergeWays < m.nrows; q0 += kMergeBatch) {   // tables beyond 513 rows
+            double v[kMergeBatch];
+#pragma unroll
+            for (int q = 0; q < kMergeBatch; ++q) {
                 const int b = j + (q0 + q) * kPrologueMergeWays;
                 v[q] = b < m.nrows ? m.rows[(int64_t)b * kPartialWords + c] : 0.0;
             }
 #pragma unroll
-            for (int q = 0; q < kBatch; ++q) acc += v[q];
+            for (int q = 0; q < kMergeBatch; ++q) acc += v[q];
         }
         xch[j * kPartialWords + c] = acc;
     }
@@ -182,7 +208,7 @@ hipError_t launch_policy_forward(const float* image, const float* obs, const dou
                                  const uint64_t* tick, float* obs_n, float* action, float* clipped, float* value,
                                  float* logp, float* eps_out, int64_t n, uint64_t seed, uint64_t id_offset,
                                  float clip_obs, float eps_norm, int deterministic, int max_blocks, int nets, int narrow,
-                                 int in_dim, int act_dim, const MergeArgs& merge, hipStream_t s);
+                                 int in_dim, int act_dim, const MergeArgs& merge, const int32_t* n_dev, hipStream_t s);
 int policy_image_floats();
 // fpv_ppo.hip
 int64_t ppo_workspace_floats(int64_t rows, int cus);

@@ -117,6 +117,7 @@ struct PolicyArgs {
     int32_t deterministic;   // 1: action = mean (SB3 predict(deterministic=True), test_hover.py:17)
     int32_t in_dim, act_dim;
     MergeArgs mg;            // mg.rows != null: fold the previous env step's tile sums into rms first (512 threads)
+    const int32_t* n_dev;    // optional device-side row count: rows = min(n, *n_dev)
 };
 
 // one hidden layer's 64 values per lane: 4 accumulator tiles
@@ -153,6 +154,8 @@ __global__ __launch_bounds__(THREADS) void policy_forward_kernel(PolicyArgs p, i
     float* hb = lds + net_count * kNetFloats;        // heads [660], then normaliser mean[20], inv[20]
     // ---- stage the weight image (L2-resident after the first workgroups) and the normaliser: every granule of a
     // thread is requested before the first one is written to LDS, so the block pays one L2 round trip
+    MergeRegs mr;
+    if (p.mg.rows) merge_request(p.mg, mr);     // the tile sums travel together with the weight image
     {
         const f32x4* src = reinterpret_cast<const f32x4*>(p.image + (size_t)net_first * kNetFloats);
         f32x4* dst = reinterpret_cast<f32x4*>(lds);
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(THREADS) void policy_forward_kernel(PolicyArgs p, i
         }
     }
     if (p.mg.rows)                              // uniform: the normaliser comes out of the merged statistics
-        merge_prologue(p.mg, p.rms, reinterpret_cast<double*>(hb + 700), p.eps_norm, hb + 660, hb + 680);
+        merge_prologue(p.mg, mr, p.rms, reinterpret_cast<double*>(hb + 700), p.eps_norm, hb + 660, hb + 680);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -188,9 +191,14 @@ __global__ __launch_bounds__(THREADS) void policy_forward_kernel(PolicyArgs p, i
     const bool do_pi = net_first == 0, do_v = net_first + net_count == 2;
     constexpr int kChunk = THREADS / 2;              // 32 drones per wave
 
-    for (int64_t base = (int64_t)blockIdx.x * kChunk; base < p.n; base += (int64_t)gridDim.x * kChunk) {
+    int64_t rows = p.n;
+    if (p.n_dev) {
+        const int64_t nd = *p.n_dev;
+        rows = nd < rows ? (nd > 0 ? nd : 0) : rows;
+    }
+    for (int64_t base = (int64_t)blockIdx.x * kChunk; base < rows; base += (int64_t)gridDim.x * kChunk) {
         const int64_t d = base + wave * 32 + col;   // this lane's drone (both halves of the wave share it)
-        const bool live = d < p.n;
+        const bool live = d < rows;
         // ---- observation: half 0 holds k = 0..11, half 1 holds k = 12..23 (20..23 are zero padding)
         float x[12];
         {
@@ -336,7 +344,7 @@ hipError_t launch_policy_forward(const float* image, const float* obs, const dou
                                  const uint64_t* tick, float* obs_n, float* action, float* clipped, float* value,
                                  float* logp, float* eps_out, int64_t n, uint64_t seed, uint64_t id_offset,
                                  float clip_obs, float eps_norm, int deterministic, int max_blocks, int nets, int narrow,
-                                 int in_dim, int act_dim, const MergeArgs& merge, hipStream_t s) {
+                                 int in_dim, int act_dim, const MergeArgs& merge, const int32_t* n_dev, hipStream_t s) {
     // nets: 3 = pi + V (one launch), 1 = pi only (with the sampling epilogue), 2 = V only.
     // narrow: 256-thread workgroups (one wave per SIMD) so that other kernels can co-reside.
     static bool attr_set = false;
@@ -352,7 +360,7 @@ hipError_t launch_policy_forward(const float* image, const float* obs, const dou
     const size_t lds_bytes = (size_t)(net_count * kNetFloats + (kImageFloats - kHeadBase) + 40) * sizeof(float) +
                              (merge.rows ? kMergeLdsBytes : 0);
     PolicyArgs p{image, obs, rms, eps_in, tick, obs_n, action, clipped, value, logp, eps_out,
-                 n, seed, id_offset, clip_obs, eps_norm, deterministic, in_dim, act_dim, merge};
+                 n, seed, id_offset, clip_obs, eps_norm, deterministic, in_dim, act_dim, merge, n_dev};
     const int threads = narrow ? 256 : 512, chunk = threads / 2;
     int64_t blocks = (n + chunk - 1) / chunk;
     if (blocks > max_blocks) blocks = max_blocks;

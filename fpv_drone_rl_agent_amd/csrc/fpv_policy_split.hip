@@ -158,7 +158,9 @@ __global__ __launch_bounds__(kSplitThreads) void policy_split_forward_kernel(Spl
     for (int q = threadIdx.x; q < kHeadFloats; q += kSplitThreads)
         head[q] = reinterpret_cast<const float*>(p.image + 2 * (size_t)kNetBytes)[q];
     if (p.mg.rows) {                            // fold the previous env step's tile sums into the statistics first
-        merge_prologue(p.mg, p.rms, reinterpret_cast<double*>(nrm + 40), p.eps_norm, nrm, nrm + 20);
+        MergeRegs mr;
+        merge_request(p.mg, mr);
+        merge_prologue(p.mg, mr, p.rms, reinterpret_cast<double*>(nrm + 40), p.eps_norm, nrm, nrm + 20);
     } else if (threadIdx.x < kIn) {
         nrm[threadIdx.x] = p.rms ? (float)p.rms[threadIdx.x] : 0.0f;
         nrm[20 + threadIdx.x] = p.rms ? (float)(1.0 / sqrt(p.rms[kIn + threadIdx.x] + (double)p.eps_norm)) : 1.0f;

@@ -331,6 +331,146 @@ hipError_t launch_reward_finalize(int64_t T, int64_t n, const float* raw, const 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- timeout bootstrap without a host round trip
+// SB3's on-policy collector adds gamma * V(terminal observation) to the reward of an episode end that is a truncation
+// and not a termination (stable_baselines3 OnPolicyAlgorithm.collect_rollouts; the truncation of hover.py:275).  The
+// episode ends of a rollout sit in the per-tile done ledger.  ledger_scan walks every ledger slot, counts episodes
+// (Monitor statistics), and compacts the truncated-not-terminated entries — terminal observation normalised with the
+// statistics of ITS step — into a dense list; the V net then runs over that list with a device-side row count and
+// ledger_scatter adds gamma * V.  The list order depends on atomics, the result does not: every entry lands on its own
+// (step, drone) cell.
+__global__ void zero_words_kernel(uint32_t* __restrict__ a, int64_t na, uint32_t* __restrict__ b, int64_t nb) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < na) a[i] = 0u;
+        else b[i - na] = 0u;
+    }
+}
+
+hipError_t launch_zero_words(uint32_t* a, int64_t n, hipStream_t s) {
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, n, (uint32_t*)nullptr, (int64_t)0);
+    return hipGetLastError();
+}
+
+struct LedgerScanArgs {
+    const uint32_t* led_count;
+    const int32_t* led_idx;
+    const uint32_t* led_info;
+    const uint32_t* led_tag;
+    const float* led_ret;
+    const float* led_obs;
+    const uint64_t* tick;     // the handle's tile-0 agent tick AFTER the rollout
+    const double* snapshots;  // [T][stride]: {mean[O], var[O], ...} after each step, or null (no normalisation)
+    int64_t tiles, stride, cap;
+    int32_t rows, T, obs_words, pad;
+    float clip_obs, eps;
+    float* tobs;              // [cap][O]
+    int32_t* t_idx;           // [cap]
+    int32_t* d_idx;           // [cap]
+    int32_t* counters;        // {K, valid rows, episodes (incl. overflowed), flags: 1 ledger overflow, 2 tag outside rollout, 4 list overflow}
+    double* sums;             // {sum ep_return, sum ep_len}
+};
+
+__global__ __launch_bounds__(256) void ledger_scan_kernel(LedgerScanArgs a) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool valid = false, trunc = false;
+    int episodes = 0, flags = 0;
+    uint32_t info = 0;
+    int32_t t = 0;
+    if (s < a.tiles * a.rows) {
+        const int64_t tile = s / a.rows;
+        const int row = (int)(s - tile * a.rows);
+        const uint32_t cnt = a.led_count[tile];
+        if (row == 0) {
+            episodes = (int)cnt;
+            if (cnt > (uint32_t)a.rows) flags |= 1;
+        }
+        valid = (uint32_t)row < (cnt < (uint32_t)a.rows ? cnt : (uint32_t)a.rows);
+        if (valid) {
+            info = a.led_info[s];
+            const uint32_t tick0 = (uint32_t)(a.tick[0] - (uint64_t)a.T);
+            t = (int32_t)(a.led_tag[s] - tick0);
+            trunc = (info & kInfoTrunc) && !(info & kInfoTerm);
+            if (trunc && (t < 0 || t >= a.T)) { flags |= 2; trunc = false; }
+        }
+    }
+    // ---- per-wave statistics, one atomic each
+    double sr = valid ? (double)a.led_ret[s] : 0.0, sl = valid ? (double)(info >> 8) : 0.0;
+    int nv = valid ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        sr += __shfl_xor(sr, off); sl += __shfl_xor(sl, off);
+        nv += __shfl_xor(nv, off); episodes += __shfl_xor(episodes, off); flags |= __shfl_xor(flags, off);
+    }
+    const unsigned long long m = __ballot(trunc);
+    int base = 0;
+    if (lane == 0) {
+        if (nv) { atomicAdd(&a.counters[1], nv); atomicAdd(&a.sums[0], sr); atomicAdd(&a.sums[1], sl); }
+        if (episodes) atomicAdd(&a.counters[2], episodes);
+        if (m) base = atomicAdd(&a.counters[0], __popcll(m));
+    }
+    base = __shfl(base, 0);
+    if (trunc) {
+        const int64_t pos = (int64_t)base + __popcll(m & ((1ull << lane) - 1ull));
+        if (pos < a.cap) {
+            a.t_idx[pos] = t;
+            a.d_idx[pos] = a.led_idx[s];
+            const float* src = a.led_obs + s * a.obs_words;
+            float* dst = a.tobs + pos * a.obs_words;
+            for (int j = 0; j < a.obs_words; ++j) {
+                float x = src[j];
+                if (a.snapshots) {
+                    const double mean = a.snapshots[(int64_t)t * a.stride + j], var = a.snapshots[(int64_t)t * a.stride + a.obs_words + j];
+                    const double z = ((double)x - mean) / sqrt(var + (double)a.eps);
+                    x = (float)fmin(fmax(z, -(double)a.clip_obs), (double)a.clip_obs);
+                }
+                dst[j] = x;
+            }
+        } else {
+            flags |= 4;
+        }
+    }
+    flags |= __shfl_xor(flags, 32);   // list overflow can only add bit 4 after the reduction above: fold it in again
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) flags |= __shfl_xor(flags, off);
+    if (lane == 0 && flags) atomicOr(&a.counters[3], flags);
+}
+
+__global__ __launch_bounds__(256) void ledger_scatter_kernel(const int32_t* __restrict__ counters, const int32_t* __restrict__ t_idx,
+                                                             const int32_t* __restrict__ d_idx, const float* __restrict__ v,
+                                                             float gamma, float* __restrict__ rewards, int64_t n, int64_t cap) {
+    int64_t k_end = counters[0];
+    if (k_end > cap) k_end = cap;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < k_end; k += (int64_t)gridDim.x * 256)
+        rewards[(int64_t)t_idx[k] * n + d_idx[k]] += gamma * v[k];
+}
+
+hipError_t launch_ledger_scan(const uint32_t* led_count, const int32_t* led_idx, const uint32_t* led_info, const uint32_t* led_tag,
+                              const float* led_ret, const float* led_obs, const uint64_t* tick, int64_t tiles, int rows,
+                              int obs_words, const double* snapshots, int64_t stride, int T, float clip_obs, float eps,
+                              float* tobs, int32_t* t_idx, int32_t* d_idx, int64_t cap, int32_t* counters, double* sums,
+                              hipStream_t s) {
+    // zeroed by a kernel, not hipMemsetAsync: memset nodes captured into a HIP graph left these words holding garbage
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<uint32_t*>(counters), (int64_t)4,
+                       reinterpret_cast<uint32_t*>(sums), (int64_t)4);
+    LedgerScanArgs a{led_count, led_idx, led_info, led_tag, led_ret, led_obs, tick, snapshots, tiles, stride, cap,
+                     rows, T, obs_words, 0, clip_obs, eps, tobs, t_idx, d_idx, counters, sums};
+    const int64_t slots = tiles * rows;
+    hipLaunchKernelGGL(ledger_scan_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_ledger_scatter(const int32_t* counters, const int32_t* t_idx, const int32_t* d_idx, const float* v, float gamma,
+                                 float* rewards, int64_t n, int64_t cap, hipStream_t s) {
+    int64_t blocks = (cap + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL(ledger_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, s, counters, t_idx, d_idx, v, gamma, rewards, n, cap);
+    return hipGetLastError();
+}
+
 hipError_t launch_normalize_reward(int64_t n, const float* r, const uint8_t* done, float* ret, float* r_out,
                                    double* rms, int32_t update, float gamma, float clip, float eps, double* scratch,
                                    hipStream_t s) {

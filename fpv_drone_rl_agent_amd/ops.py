@@ -122,6 +122,20 @@ def moments_merge(partials, batch_count, obs_rms=None, ret_rms=None, snapshot=No
                                           _ptr(snapshot), _stream(partials.device)), "fpv_moments_merge_to")
 
 
+def ledger_scan(engine, T, *, snapshots, clip_obs, eps, tobs, t_idx, d_idx, counters, sums):
+    """fpv_ledger_scan on the engine's done ledger: episode statistics + the dense list of truncated-not-terminated
+    episode ends of the last T agent steps (see include/fpv_env.h).  No host synchronisation."""
+    L.check(L.load().fpv_ledger_scan(engine._h, _ptr(snapshots), snapshots.shape[1] if snapshots is not None else 0, int(T),
+                                     float(clip_obs), float(eps), _ptr(tobs), _ptr(t_idx), _ptr(d_idx), tobs.shape[0],
+                                     _ptr(counters), _ptr(sums), _stream(tobs.device)), "fpv_ledger_scan")
+
+
+def ledger_scatter(counters, t_idx, d_idx, values, gamma, rewards):
+    """rewards[t_idx[k], d_idx[k]] += gamma * values[k] for k < counters[0] (fpv_ledger_scatter)."""
+    L.check(L.load().fpv_ledger_scatter(_ptr(counters), _ptr(t_idx), _ptr(d_idx), _ptr(values), float(gamma), _ptr(rewards),
+                                        rewards.shape[1], t_idx.shape[0], _stream(rewards.device)), "fpv_ledger_scatter")
+
+
 def reward_finalize(raw, snapshots, clip=10.0, eps=1e-8, out=None):
     """out[t] = clip(raw[t] / sqrt(ret_var_t + eps)) with ret_var_t = snapshots[t, 42] (fpv_reward_finalize)."""
     _need(raw, torch.float32, "raw")

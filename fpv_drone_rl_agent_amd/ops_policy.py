@@ -64,11 +64,12 @@ class FusedPolicy:
 
     def forward(self, obs, *, rms=None, eps_in=None, tick=None, obs_n=None, action=None, clipped=None, value=None,
                 logp=None, eps_out=None, clip_obs: float = 10.0, eps_norm: float = 1e-8, deterministic: bool = False,
-                nets: str = "both", narrow: bool = False, merge: dict | None = None):
+                nets: str = "both", narrow: bool = False, merge: dict | None = None, n_dev=None):
         """obs [n,20] fp32 raw observations; rms = fp64[41] VecNormalize statistics or None.  Output tensors
         are written in place when given; value is always produced.  Returns dict of the outputs.
         merge = {partials [rows,44] f64, count, rms_out, ret_rms, ret_rms_out, snapshot}: fold the previous
-        fpv_step_fused's tile sums into the statistics in this launch (rms / ret_rms are read, *_out written)."""
+        fpv_step_fused's tile sums into the statistics in this launch (rms / ret_rms are read, *_out written).
+        n_dev: int32 device scalar; only the first min(n, n_dev) rows are evaluated."""
         n = obs.shape[0]
         if obs.dtype != torch.float32 or not obs.is_contiguous() or obs.shape[1] != self.obs_dim:
             raise ValueError(f"obs must be a contiguous [n,{self.obs_dim}] fp32 device tensor")
@@ -78,6 +79,7 @@ class FusedPolicy:
         io = L.FpvPolicyIo(n, _ptr(obs), _ptr(rms), _ptr(eps_in), _ptr(tick), _ptr(obs_n), _ptr(action), _ptr(clipped),
                            _ptr(value), _ptr(logp), _ptr(eps_out), self.seed, self.id_offset, float(clip_obs),
                            float(eps_norm), 1 if deterministic else 0, mask, 1 if narrow else 0, 0)
+        io.n_dev = _ptr(n_dev)
         if merge is not None:
             io.merge_partials, io.merge_rows = _ptr(merge["partials"]), merge["partials"].shape[0]
             io.merge_count = float(merge["count"])

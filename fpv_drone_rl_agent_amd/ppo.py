@@ -200,9 +200,9 @@ class PPO:
             batch = self.col.collect()
             self.num_timesteps += per_iter
             ep = self.col.episodes
-            if ep["count"] > 0 and ep["ep_len"] is not None and ep["ep_len"].numel() > 0:
-                self.logger["rollout/ep_len_mean"] = float(ep["ep_len"].float().mean())
-                self.logger["rollout/ep_rew_mean"] = float(ep["ep_return"].float().mean())
+            if ep["count"] > 0 and ep["ep_len_mean"] == ep["ep_len_mean"]:
+                self.logger["rollout/ep_len_mean"] = ep["ep_len_mean"]
+                self.logger["rollout/ep_rew_mean"] = ep["ep_rew_mean"]
             self.train_on(batch)
             it += 1
             if callback is not None:

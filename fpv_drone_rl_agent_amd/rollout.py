@@ -93,11 +93,26 @@ class RolloutCollector:
             self._obs_rms_alt = torch.zeros_like(self.obs_norm.rms)
             self._ret_rms_alt = torch.zeros_like(self.rew_norm.rms)
         self.stats = torch.zeros((3,), dtype=torch.float64, device=dev)
+        if self.fused_policy:
+            # sync-free timeout bootstrap (fpv_ledger_scan / fpv_ledger_scatter): a drone is truncated at most once per
+            # 401 steps, so the dense list never needs more than N * ceil(T / 401) rows
+            cap = N * ((T + 400) // 401)
+            self._tobs = torch.zeros((cap, O), dtype=f32, device=dev)
+            self._t_idx = torch.zeros((cap,), dtype=torch.int32, device=dev)
+            self._d_idx = torch.zeros((cap,), dtype=torch.int32, device=dev)
+            self._tv = torch.zeros((cap,), dtype=f32, device=dev)
+            self._led_status = torch.zeros((8,), dtype=torch.float64, device=dev)   # counters[4] as int32 in [0:2], sums in [2:4]
+            self._led_counters = self._led_status[:2].view(torch.int32)
+            self._led_sums = self._led_status[2:4]
+            self._status_host = [torch.zeros((8,), dtype=torch.float64).pin_memory() for _ in range(2)]
+            self._status_event = [torch.cuda.Event() for _ in range(2)]
+            self._status_pending = [False, False]
+        self._rollouts = 0
+        self._episodes_host = {"count": 0, "ep_len_mean": float("nan"), "ep_rew_mean": float("nan"), "truncated": 0}
         self._graph = None
         self._tick0 = 0
         self._started = False
         self.adv_mean = self.adv_std = None
-        self.episodes = {"count": 0, "ep_return": None, "ep_len": None}
 
     # ------------------------------------------------------------------ one vectorised step
     def _normalise_obs(self, raw, out, update=True):
@@ -197,12 +212,35 @@ class RolloutCollector:
         self._starts[t + 1].copy_(self.done)
 
     def _all_steps(self) -> None:
+        if self.fused_policy:
+            self.engine.ledger_clear()
         self._starts[0].copy_(self._starts[self.T])
         for t in range(self.T):
             self._step(t)
         self._merge_tail(self.T - 1)
         if self.fused and self.overlap_critic:
             torch.cuda.current_stream(self.device).wait_stream(self._vstream)   # join the critic passes
+        if self.fused_policy:
+            self._tail()
+
+    def _tail(self) -> None:
+        """Everything between the last env step and the collective, without a host round trip (so it is part of the
+        captured graph): V(s_T), deferred reward scaling, timeout bootstrap from the done ledger, GAE + its moments."""
+        eng = self.engine
+        self.fp.forward(eng.obs, rms=self.obs_norm.rms if self.norm_obs else None, obs_n=self.cur_obs, value=self.last_val,
+                        deterministic=True, nets="v", clip_obs=self.obs_norm.clip, eps_norm=self.obs_norm.eps)
+        if self.fused:
+            if self.norm_reward:
+                ops.reward_finalize(self.raw_rew, self.snap, clip=self.rew_norm.clip, eps=self.rew_norm.eps, out=self.buf_rew)
+            else:
+                self.buf_rew.copy_(self.raw_rew)
+        ops.ledger_scan(eng, self.T, snapshots=self.snap if self.norm_obs else None, clip_obs=self.obs_norm.clip,
+                        eps=self.obs_norm.eps, tobs=self._tobs, t_idx=self._t_idx, d_idx=self._d_idx,
+                        counters=self._led_counters, sums=self._led_sums)
+        self.fp.forward(self._tobs, value=self._tv, deterministic=True, nets="v", n_dev=self._led_counters[0:1])
+        ops.ledger_scatter(self._led_counters, self._t_idx, self._d_idx, self._tv, self.gamma, self.buf_rew)
+        ops.gae(self.buf_rew, self.buf_val, self.buf_start, self.last_val, self.episode_start, self.gamma,
+                self.lam, advantages=self.adv, returns=self.ret, stats=self.stats)
 
     # ------------------------------------------------------------------ public API
     def start(self) -> None:
@@ -220,6 +258,8 @@ class RolloutCollector:
         with torch.cuda.stream(side):       # warm-up outside capture: lazy allocations, rocBLAS handles
             self._step(0)
             self._merge_tail(0)
+            if self.fused_policy:
+                self._tail()                # first-call allocations of the tail (reduction scratch) happen here
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         self._tick0 += 1
@@ -248,48 +288,79 @@ class RolloutCollector:
         eng = self.engine
         if self.use_graph and self._graph is None:
             self._capture()
-        eng.ledger_clear()
-        if self.use_graph:
-            self._graph.replay()
-        else:
-            self._all_steps()
         if self.fused_policy:
-            self.fp.forward(eng.obs, rms=self.obs_norm.rms if self.norm_obs else None, obs_n=self.cur_obs,
-                            value=self.last_val, deterministic=True, clip_obs=self.obs_norm.clip,
-                            eps_norm=self.obs_norm.eps)
-        if self.fused:
-            if self.norm_reward:
-                ops.reward_finalize(self.raw_rew, self.snap, clip=self.rew_norm.clip, eps=self.rew_norm.eps,
-                                    out=self.buf_rew)
+            slot = self._rollouts % 2
+            self._check_status(slot)        # what this slot still holds is two rollouts old: no stall
+            if self.use_graph:
+                self._graph.replay()
             else:
-                self.buf_rew.copy_(self.raw_rew)
-        elif not self.fused_policy:
+                self._all_steps()
+            self._status_host[slot].copy_(self._led_status, non_blocking=True)
+            self._status_event[slot].record()
+            self._status_pending[slot] = True
+        else:
+            eng.ledger_clear()
+            self._all_steps()
             with torch.no_grad():
                 self.last_val.copy_(self.policy.value(self.cur_obs))
-        self._bootstrap_timeouts()
-        ops.gae(self.buf_rew, self.buf_val, self.buf_start, self.last_val, self.episode_start, self.gamma,
-                self.lam, advantages=self.adv, returns=self.ret, stats=self.stats)
+            self._bootstrap_timeouts()
+            ops.gae(self.buf_rew, self.buf_val, self.buf_start, self.last_val, self.episode_start, self.gamma,
+                    self.lam, advantages=self.adv, returns=self.ret, stats=self.stats)
+        self._rollouts += 1
         gathered = D.allgather_payload(self.stats)          # the one collective per update
         self.adv_mean, self.adv_std = D.merge_advantage_stats(gathered)
         self._tick0 += self.T
         return {"obs": self.buf_obs, "actions": self.buf_act, "values": self.buf_val, "log_probs": self.buf_logp,
                 "advantages": self.adv, "returns": self.ret, "adv_mean": self.adv_mean, "adv_std": self.adv_std}
 
+    def _check_status(self, slot: int) -> None:
+        """Wait for the status words copied out after an earlier rollout and turn its flags into exceptions."""
+        if not self._status_pending[slot]:
+            return
+        self._status_event[slot].synchronize()
+        self._status_pending[slot] = False
+        host = self._status_host[slot]
+        k, valid, episodes, flags = (int(x) for x in host[:2].view(torch.int32))
+        if flags & 1:
+            raise RuntimeError(f"done ledger overflow: {episodes} episode ends but only {valid} rows fit "
+                               f"({self.engine.ledger_rows_per_tile} per 64-drone tile); create the engine with a larger "
+                               "ledger_capacity or collect shorter rollouts")
+        if flags & 2:
+            raise RuntimeError("done-ledger tag outside this rollout: tick bookkeeping is out of sync")
+        if flags & 4:
+            raise RuntimeError("more truncated episodes in one rollout than drones x ceil(T / 401): ledger inconsistent")
+        sums = host[2:4]
+        self._episodes_host = {"count": episodes, "truncated": k,
+                               "ep_rew_mean": float(sums[0]) / valid if valid else float("nan"),
+                               "ep_len_mean": float(sums[1]) / valid if valid else float("nan")}
+
+    @property
+    def episodes(self) -> dict:
+        """Monitor-style statistics of the last collected rollout: {count, ep_len_mean, ep_rew_mean, truncated}.
+        Waits for that rollout to finish (the only host synchronisation of the collector)."""
+        if self.fused_policy and self._rollouts:
+            self._check_status((self._rollouts - 1) % 2)
+        return self._episodes_host
+
     def _bootstrap_timeouts(self) -> None:
         """r_t += gamma * V(terminal obs) for truncated-but-not-terminated episode ends; also harvests
-        the Monitor-style episode statistics from the done ledger.  One synchronising compaction per rollout."""
+        the Monitor-style episode statistics from the done ledger.  The torch reference of fpv_ledger_scan /
+        fpv_ledger_scatter (several host synchronisations); used by the unfused collector only."""
         eng = self.engine
         total, all_rows = eng.ledger_rows()
         if int(total.item()) != all_rows.numel():
             raise RuntimeError(f"done ledger overflow: {int(total.item())} episode ends but {all_rows.numel()} rows fit "
                                f"({eng.ledger_rows_per_tile} per 64-drone tile); create the engine with a larger "
                                "ledger_capacity or collect shorter rollouts")
-        self.episodes = {"count": int(total.item()), "ep_return": eng.led_ret[all_rows],
-                         "ep_len": eng.led_info[all_rows] >> 8}
-        if all_rows.numel() == 0:
+        k = all_rows.numel()
+        self._episodes_host = {"count": int(total.item()), "truncated": 0,
+                               "ep_rew_mean": float(eng.led_ret[all_rows].double().mean()) if k else float("nan"),
+                               "ep_len_mean": float((eng.led_info[all_rows] >> 8).double().mean()) if k else float("nan")}
+        if k == 0:
             return
         info = eng.led_info[all_rows]
         rows = all_rows[((info & 2) != 0) & ((info & 1) == 0)]
+        self._episodes_host["truncated"] = int(rows.numel())
         if rows.numel() == 0:
             return
         t_idx = (eng.led_tag[rows].to(torch.int64) - (self._tick0 & 0xFFFFFFFF)) & 0xFFFFFFFF

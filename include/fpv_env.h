@@ -194,6 +194,20 @@ int fpv_normalize_reward(int64_t n, const float* r, const uint8_t* done, float* 
                          double* rms, int32_t update, float gamma, float clip, float eps,
                          void* stream);
 
+/* ---- timeout bootstrap (SB3 OnPolicyAlgorithm.collect_rollouts: reward += gamma * V(terminal observation) where an
+ * episode was truncated, hover.py:275, and not terminated) without a host round trip ----
+ * fpv_ledger_scan walks the handle's done ledger after a rollout of T agent steps: counters[4] = {K, valid rows,
+ * episodes appended (including rows that did not fit), flags: 1 ledger overflow | 2 tag outside the rollout | 4 more
+ * than cap list entries}, sums[2] = {sum of episode returns, sum of episode lengths} (Monitor statistics), and the K
+ * truncated-not-terminated entries as a dense list: t_idx[k] (step within the rollout), d_idx[k] (drone), tobs[k][O]
+ * (terminal observation, normalised with snapshots[t_idx[k]] = {mean[O], var[O], ...} when snapshots != NULL).
+ * The value net then runs over tobs with fpv_policy_io.n_dev = &counters[0], and fpv_ledger_scatter adds
+ * gamma * values[k] to rewards[t_idx[k]][d_idx[k]] ([T][n]).  The list order is arbitrary, the result is not. */
+int fpv_ledger_scan(fpv_env* env, const double* snapshots, int64_t snapshot_stride, int32_t T, float clip_obs, float eps_norm,
+                    float* tobs, int32_t* t_idx, int32_t* d_idx, int64_t cap, int32_t* counters, double* sums, void* stream);
+int fpv_ledger_scatter(const int32_t* counters, const int32_t* t_idx, const int32_t* d_idx, const float* values, float gamma,
+                       float* rewards, int64_t n, int64_t cap, void* stream);
+
 /* ---- fused actor-critic forward (SB3 MlpPolicy, net_arch pi/vf [128,128], tanh) ----
  * Stands under model.policy.forward(obs) / model.predict(obs, deterministic) of the SB3 learner in
  * simulation/train_hover.py:47-60 and simulation/test_hover.py:17 during rollout collection; the
@@ -243,6 +257,7 @@ typedef struct {
     const double* ret_rms;   /* [3] or NULL */
     double* ret_rms_out;     /* [3] */
     double* merge_snapshot;  /* [FPV_PARTIAL_WORDS] or NULL */
+    const int32_t* n_dev;    /* optional DEVICE row count: rows = min(n, *n_dev) (lists whose length only the device knows) */
 } fpv_policy_io;
 
 int fpv_policy_forward(fpv_policy* pol, const fpv_policy_io* io, void* stream);
