@@ -167,3 +167,73 @@ def test_rollout_collector_matches_oracle_replay(oracle, use_graph, fused):
     assert np.allclose(out["returns"].cpu().numpy(), ret_ref, atol=1e-4)
     assert abs(float(out["adv_mean"]) - adv_ref.mean()) < 1e-5 and abs(float(out["adv_std"]) - adv_ref.std()) < 1e-5
     eng.close()
+
+
+def test_ledger_scan_and_scatter_match_a_torch_restatement(oracle):
+    """fpv_ledger_scan / fpv_ledger_scatter (SB3's timeout bootstrap, no host round trip) against the same rule
+    written with torch indexing on the ledger read back to the host."""
+    from fpv_drone_rl_agent_amd import ops
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.ops_policy import FusedPolicy
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    n, T, gamma = 4096, 6, 0.99
+    torch.manual_seed(11)
+    eng = FpvEngine(n, 0, seed=4, ledger_capacity=4 * n)
+    st = oracle.synthetic_states(n, seed=4)
+    rng = np.random.default_rng(2)
+    st[: n // 3, 34] = rng.integers(396, 402, n // 3)                 # truncations inside the window
+    st[n // 3: n // 2, 2] = 0.12; st[n // 3: n // 2, 9] = -1.0; st[n // 3: n // 2, 34] = 100   # floor terminations
+    eng.set_state(torch.from_numpy(st.astype(np.float32)))
+    eng.set_tick(1000)
+    eng.ledger_clear()
+    for t in range(T):
+        eng.step(torch.rand(n, 4, device="cuda") * 2 - 1)
+    led = eng.ledger_read()
+    snap = torch.zeros((T, 44), dtype=torch.float64, device="cuda")
+    snap[:, :20] = torch.randn(T, 20, dtype=torch.float64, device="cuda") * 0.3
+    snap[:, 20:40] = torch.rand(T, 20, dtype=torch.float64, device="cuda") + 0.5
+    pol = ActorCritic().cuda()
+    fp = FusedPolicy(pol)
+    cap = n
+    tobs = torch.zeros((cap, 20), device="cuda"); t_idx = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    d_idx = torch.zeros(cap, dtype=torch.int32, device="cuda"); tv = torch.zeros(cap, device="cuda")
+    counters = torch.full((4,), 77, dtype=torch.int32, device="cuda"); sums = torch.full((2,), 5.0, dtype=torch.float64, device="cuda")
+    ops.ledger_scan(eng, T, snapshots=snap, clip_obs=10.0, eps=1e-8, tobs=tobs, t_idx=t_idx, d_idx=d_idx, counters=counters, sums=sums)
+    fp.forward(tobs, value=tv, deterministic=True, nets="v", n_dev=counters[0:1])
+    rew = torch.zeros((T, n), device="cuda")
+    ops.ledger_scatter(counters, t_idx, d_idx, tv, gamma, rew)
+    torch.cuda.synchronize()
+    info, tag, idx = led["info"], led["tag"], led["idx"]
+    mask = ((info & 2) != 0) & ((info & 1) == 0)
+    k, valid, episodes, flags = counters.tolist()
+    assert (k, valid, episodes, flags) == (int(mask.sum()), len(idx), led["count"], 0) and k > 100 and valid > k
+    assert np.isclose(float(sums[0]), led["ep_return"].astype(np.float64).sum()) and float(sums[1]) == float((info >> 8).sum())
+    tt = (tag[mask].astype(np.int64) - 1000)
+    assert tt.min() >= 0 and tt.max() < T
+    sn = snap.cpu().numpy()
+    tn = np.clip((led["obs"][mask].astype(np.float64) - sn[tt, :20]) / np.sqrt(sn[tt, 20:40] + 1e-8), -10, 10).astype(np.float32)
+    with torch.no_grad():
+        v = pol.value(torch.from_numpy(tn).cuda()).cpu().numpy()
+    ref = np.zeros((T, n), np.float32)
+    ref[tt, idx[mask]] = gamma * v
+    assert np.allclose(rew.cpu().numpy(), ref, atol=2e-5)
+    eng.close()
+
+
+def test_collector_turns_a_ledger_overflow_into_an_error():
+    """One ledger row per 64-drone tile, every drone truncating inside the rollout: the scan raises flag 1 and the
+    collector reports it when the status words are read."""
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    from fpv_drone_rl_agent_amd.rollout import RolloutCollector
+    n = 1024
+    eng = FpvEngine(n, 0, seed=0, ledger_capacity=n // 64)
+    col = RolloutCollector(eng, ActorCritic().cuda(), n_steps=8, use_graph=False)
+    col.start()
+    st = eng.get_state()
+    st[:, 34] = 399.0                                                   # step counters: all truncate within 8 steps
+    eng.set_state(st)
+    col.collect()
+    with pytest.raises(RuntimeError, match="ledger overflow"):
+        col.episodes
+    eng.close()
