@@ -5,8 +5,8 @@
 //   1 KiB contiguous per wave instruction), one 16-B action load, 80 B of observation staged
 //   through LDS so that the [N][20] rows leave as five 1-KiB contiguous stores per wave, 4 B
 //   reward, 2 flag bytes.  All 12 physics sub-steps run in registers.
-//   Episode ends are compacted into the done ledger with one wave ballot + one atomic per
-//   wave that has any; the reset state is a constant template (docs/SPEC.md §8), so a
+//   Episode ends are compacted into the tile's own region of the done ledger with one wave
+//   ballot (no atomic); the reset state is a constant template (docs/SPEC.md §8), so a
 //   finished drone costs its wave a few selects, not a divergent warm-up loop.
 //
 // Reference path replaced: QuadXHoverEnv.step()/reset() simulation/hover.py:72-114,334-358
