@@ -237,3 +237,34 @@ def test_collector_turns_a_ledger_overflow_into_an_error():
     with pytest.raises(RuntimeError, match="ledger overflow"):
         col.episodes
     eng.close()
+
+
+@pytest.mark.parametrize("T", [7, 8])
+@pytest.mark.parametrize("norm", [(True, True), (True, False), (False, True)])
+def test_in_launch_statistics_merge_equals_the_merge_kernel(T, norm):
+    """fpv_policy_io.merge_* (statistics folded into the next policy launch, ping-pong buffers: odd and even rollout
+    lengths end in different buffers) against the stand-alone fpv_moments_merge launches, two rollouts each."""
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    from fpv_drone_rl_agent_amd.rollout import RolloutCollector
+    n = 2048
+    outs = []
+    for mip in (True, False):
+        torch.manual_seed(1)
+        pol = ActorCritic(log_std_init=-1.0).cuda()
+        eng = FpvEngine(n, 0, seed=5, ledger_capacity=4 * n)
+        col = RolloutCollector(eng, pol, n_steps=T, norm_obs=norm[0], norm_reward=norm[1], merge_in_policy=mip)
+        assert col._merge_in_policy == mip
+        col.collect()
+        b = col.collect()
+        torch.cuda.synchronize()
+        outs.append({"obs": b["obs"].clone(), "rew": col.buf_rew.clone(), "adv": b["advantages"].clone(),
+                     "obs_rms": col.obs_norm.rms.clone(), "ret_rms": col.rew_norm.rms.clone(), "snap": col.snap.clone(),
+                     "episodes": col.episodes["count"]})
+        eng.close()
+    a, b = outs
+    assert a["episodes"] == b["episodes"] and a["episodes"] > 0
+    for k in ("obs_rms", "ret_rms", "snap"):
+        assert torch.allclose(a[k], b[k], rtol=1e-6, atol=1e-9), k
+    for k in ("obs", "rew", "adv"):
+        assert torch.allclose(a[k], b[k], rtol=1e-3, atol=2e-3), k
