@@ -363,6 +363,12 @@ int fpv_ledger_clear(fpv_env* e, void* stream) {
     return FPV_OK;
 }
 
+int fpv_advantage_stats(const double* gathered, int32_t world, int32_t stride, double* mean_std, void* stream) {
+    if (!gathered || !mean_std || world <= 0 || stride < 3) return fail(FPV_ERR_ARG, "fpv_advantage_stats: bad arguments");
+    FPV_HIP(launch_advantage_stats(gathered, world, stride, mean_std, (hipStream_t)stream));
+    return FPV_OK;
+}
+
 int fpv_ledger_scan(fpv_env* e, const double* snapshots, int64_t snapshot_stride, int32_t T, float clip_obs, float eps_norm,
                     float* tobs, int32_t* t_idx, int32_t* d_idx, int64_t cap, int32_t* counters, double* sums, void* stream) {
     if (!e || !tobs || !t_idx || !d_idx || !counters || !sums || cap <= 0 || T <= 0)

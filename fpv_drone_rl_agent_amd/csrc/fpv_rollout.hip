@@ -80,6 +80,23 @@ __global__ __launch_bounds__(64) void gae_stats_kernel(const double* __restrict_
     stats[0] = count; stats[1] = s1; stats[2] = s2;
 }
 
+// {count, sum A, sum A^2} per rank, added in rank order -> {mean, std} (population std, as SB3 normalises advantages)
+__global__ void advantage_stats_kernel(const double* __restrict__ gathered, int world, int stride, double* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double c = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < world; ++r) { c += gathered[r * stride]; s1 += gathered[r * stride + 1]; s2 += gathered[r * stride + 2]; }
+    const double mean = s1 / c;
+    double var = s2 / c - mean * mean;
+    if (var < 0.0) var = 0.0;
+    out[0] = mean;
+    out[1] = sqrt(var);
+}
+
+hipError_t launch_advantage_stats(const double* gathered, int world, int stride, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(advantage_stats_kernel, dim3(1), dim3(64), 0, s, gathered, world, stride, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_gae(int64_t T, int64_t n, const float* rewards, const float* values, const uint8_t* episode_starts,
                       const float* last_values, const uint8_t* last_dones, float gamma, float lam, float* adv,
                       float* returns, double* stats, double* scratch, hipStream_t s) {

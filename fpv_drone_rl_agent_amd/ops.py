@@ -122,6 +122,13 @@ def moments_merge(partials, batch_count, obs_rms=None, ret_rms=None, snapshot=No
                                           _ptr(snapshot), _stream(partials.device)), "fpv_moments_merge_to")
 
 
+def advantage_stats(gathered, out):
+    """gathered [world, >=3] f64 rows {count, sum, sum_sq} -> out[2] = {mean, population std} (fpv_advantage_stats)."""
+    _need(gathered, torch.float64, "gathered")
+    L.check(L.load().fpv_advantage_stats(_ptr(gathered), gathered.shape[0], gathered.shape[1], _ptr(out),
+                                         _stream(gathered.device)), "fpv_advantage_stats")
+
+
 def ledger_scan(engine, T, *, snapshots, clip_obs, eps, tobs, t_idx, d_idx, counters, sums):
     """fpv_ledger_scan on the engine's done ledger: episode statistics + the dense list of truncated-not-terminated
     episode ends of the last T agent steps (see include/fpv_env.h).  No host synchronisation."""

@@ -33,6 +33,20 @@ from .ops_policy import FusedPolicy
 from .policy import ActorCritic
 
 
+class _Batch(dict):
+    """collect()'s result.  "adv_mean" / "adv_std" come from the collective on the collector's side stream: reading
+    them orders the current stream after it (everything else is ready in main-stream order)."""
+
+    def __init__(self, col, items):
+        super().__init__(items)
+        self._col = col
+
+    def __getitem__(self, key):
+        if key in ("adv_mean", "adv_std"):
+            self._col.wait_stats()
+        return super().__getitem__(key)
+
+
 class RolloutCollector:
     def __init__(self, engine: FpvEngine, policy: ActorCritic, n_steps: int = 32, gamma: float = 0.99,
                  lam: float = 0.95, norm_obs: bool = True, norm_reward: bool = True, use_graph: bool = True,
@@ -107,12 +121,20 @@ class RolloutCollector:
             self._status_host = [torch.zeros((8,), dtype=torch.float64).pin_memory() for _ in range(2)]
             self._status_event = [torch.cuda.Event() for _ in range(2)]
             self._status_pending = [False, False]
+        # the collective and the advantage statistics run on a side stream: nothing on the main stream waits for them
+        # until a consumer asks (the batch's "adv_mean" / "adv_std" items), so consecutive rollouts stay back to back
+        # and ranks are not forced into lock-step every n_steps
+        self._side = torch.cuda.Stream(dev)
+        self._stats_slot = [torch.zeros((3,), dtype=torch.float64, device=dev) for _ in range(2)]
+        self._adv_ms = [torch.zeros((2,), dtype=torch.float64, device=dev) for _ in range(2)]
+        self._stats_ready = [torch.cuda.Event() for _ in range(2)]
+        self._stats_done = [torch.cuda.Event() for _ in range(2)]
+        self._stats_last = 0
         self._rollouts = 0
         self._episodes_host = {"count": 0, "ep_len_mean": float("nan"), "ep_rew_mean": float("nan"), "truncated": 0}
         self._graph = None
         self._tick0 = 0
         self._started = False
-        self.adv_mean = self.adv_std = None
 
     # ------------------------------------------------------------------ one vectorised step
     def _normalise_obs(self, raw, out, update=True):
@@ -306,12 +328,36 @@ class RolloutCollector:
             self._bootstrap_timeouts()
             ops.gae(self.buf_rew, self.buf_val, self.buf_start, self.last_val, self.episode_start, self.gamma,
                     self.lam, advantages=self.adv, returns=self.ret, stats=self.stats)
+        k = self._rollouts % 2
         self._rollouts += 1
-        gathered = D.allgather_payload(self.stats)          # the one collective per update
-        self.adv_mean, self.adv_std = D.merge_advantage_stats(gathered)
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(self._stats_done[k])                # this slot's previous user is two rollouts old: no stall
+        self._stats_slot[k].copy_(self.stats)
+        self._stats_ready[k].record(main)
+        with torch.cuda.stream(self._side):
+            self._side.wait_event(self._stats_ready[k])
+            gathered = D.allgather_payload(self._stats_slot[k])     # the one collective per update
+            ops.advantage_stats(gathered, self._adv_ms[k])
+            self._stats_done[k].record(self._side)
+        self._stats_last = k
         self._tick0 += self.T
-        return {"obs": self.buf_obs, "actions": self.buf_act, "values": self.buf_val, "log_probs": self.buf_logp,
-                "advantages": self.adv, "returns": self.ret, "adv_mean": self.adv_mean, "adv_std": self.adv_std}
+        return _Batch(self, {"obs": self.buf_obs, "actions": self.buf_act, "values": self.buf_val, "log_probs": self.buf_logp,
+                             "advantages": self.adv, "returns": self.ret, "adv_mean": self._adv_ms[k][0],
+                             "adv_std": self._adv_ms[k][1]})
+
+    def wait_stats(self) -> None:
+        """Order the current stream after the collective + advantage statistics of the last collect()."""
+        torch.cuda.current_stream(self.device).wait_event(self._stats_done[self._stats_last])
+
+    @property
+    def adv_mean(self):
+        self.wait_stats()
+        return self._adv_ms[self._stats_last][0]
+
+    @property
+    def adv_std(self):
+        self.wait_stats()
+        return self._adv_ms[self._stats_last][1]
 
     def _check_status(self, slot: int) -> None:
         """Wait for the status words copied out after an earlier rollout and turn its flags into exceptions."""

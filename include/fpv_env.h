@@ -194,6 +194,11 @@ int fpv_normalize_reward(int64_t n, const float* r, const uint8_t* done, float* 
                          double* rms, int32_t update, float gamma, float clip, float eps,
                          void* stream);
 
+/* The single collective of the rollout path is an all-gather of fpv_gae's stats = {count, sum A, sum A^2} per rank
+ * (SURVEY 8e).  gathered [world][stride] (stride >= 3) -> mean_std[2] = {mean, population std} of the advantages over all
+ * ranks, added in rank order (every rank derives the same bits). */
+int fpv_advantage_stats(const double* gathered, int32_t world, int32_t stride, double* mean_std, void* stream);
+
 /* ---- timeout bootstrap (SB3 OnPolicyAlgorithm.collect_rollouts: reward += gamma * V(terminal observation) where an
  * episode was truncated, hover.py:275, and not terminated) without a host round trip ----
  * fpv_ledger_scan walks the handle's done ledger after a rollout of T agent steps: counters[4] = {K, valid rows,
