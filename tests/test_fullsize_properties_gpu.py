@@ -94,3 +94,66 @@ def test_reset_is_idempotent_and_total():
     assert torch.equal(a, b) and torch.equal(s1, eng.get_state())
     assert (a == a[0]).all()                                      # SPEC §8: the reset state is a constant
     eng.close()
+
+
+def test_fullsize_rollout_fused_vs_torch_reference_collector():
+    """65 536 drones, one rollout with thousands of truncations and terminations inside it: the two-kernel HIP path
+    (statistics merge in the policy launch, ledger scan / scatter for the timeout bootstrap, everything graph-captured)
+    against the torch reference collector (stand-alone kernels + torch indexing) on the same policy actions.
+    The reference collector draws its own action noise, so the comparison replays the fused collector's actions:
+    rewards, episode starts and GAE must agree."""
+    from fpv_drone_rl_agent_amd import ops
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    from fpv_drone_rl_agent_amd.rollout import RolloutCollector
+    from fpv_drone_rl_agent_amd.synthetic import synthetic_states
+    n, T = 65536, 16
+    torch.manual_seed(2)
+    pol = ActorCritic(log_std_init=-1.5).cuda()
+    st = synthetic_states(n, seed=3).astype(np.float32)
+    st[:, 34] = np.random.default_rng(1).integers(380, 402, n)          # every drone truncates within ~22 steps
+    eng = FpvEngine(n, 0, seed=7, ledger_capacity=4 * n)
+    col = RolloutCollector(eng, pol, n_steps=T)
+    col.start()
+    col._capture()
+    eng.set_state(torch.from_numpy(st))
+    obs_rms0, ret_rms0, ret0 = col.obs_norm.rms.clone(), col.rew_norm.rms.clone(), col.rew_norm.ret.clone()
+    start0 = col.episode_start.clone()
+    tick0 = eng.get_tick()
+    b = col.collect()
+    ep = col.episodes
+    assert ep["truncated"] > 0.5 * n * T / 22 and ep["count"] >= ep["truncated"]
+    acts = b["actions"].clone()
+
+    # torch-side replay of the same actions through the plain step + stand-alone normaliser ops
+    eng2 = FpvEngine(n, 0, seed=7, ledger_capacity=4 * n)
+    eng2.set_state(torch.from_numpy(st)); eng2.set_tick(tick0)
+    obs_norm = ops.RunningNorm(20, eng2.device); obs_norm.rms.copy_(obs_rms0)
+    rew_norm = ops.RewardNorm(n, eng2.device, gamma=0.99); rew_norm.rms.copy_(ret_rms0); rew_norm.ret.copy_(ret0)
+    rew = torch.zeros((T, n), device="cuda"); starts = torch.zeros((T + 1, n), dtype=torch.uint8, device="cuda")
+    starts[0] = start0
+    snaps = []
+    eng2.ledger_clear()
+    for t in range(T):
+        eng2.step(torch.clamp(acts[t], -1, 1))
+        torch.bitwise_or(eng2.terminated, eng2.truncated, out=starts[t + 1])
+        obs_norm.update_only(eng2.obs)
+        snaps.append(obs_norm.rms.clone())
+        rew_norm(eng2.reward, starts[t + 1], out=rew[t])
+    led = eng2.ledger_read()
+    info, tag, idx = led["info"], led["tag"], led["idx"]
+    mask = ((info & 2) != 0) & ((info & 1) == 0)
+    tt = tag[mask].astype(np.int64) - tick0
+    sn = torch.stack(snaps).cpu().numpy()
+    tn = np.clip((led["obs"][mask].astype(np.float64) - sn[tt, :20]) / np.sqrt(sn[tt, 20:40] + 1e-8), -10, 10).astype(np.float32)
+    with torch.no_grad():
+        v = pol.value(torch.from_numpy(tn).cuda())
+    rew.index_put_((torch.from_numpy(tt).cuda(), torch.from_numpy(idx[mask].astype(np.int64)).cuda()), 0.99 * v, accumulate=True)
+    torch.cuda.synchronize()
+    assert int(mask.sum()) == ep["truncated"] and led["count"] == ep["count"]
+    assert torch.equal(col.buf_start, starts[:T])
+    assert torch.allclose(col.buf_rew, rew, atol=2e-4, rtol=1e-4)
+    adv, ret = ops.gae(rew, b["values"], starts[:T], col.last_val, starts[T], 0.99, 0.95)[:2]
+    assert torch.allclose(b["advantages"], adv, atol=5e-4, rtol=1e-4)
+    assert abs(float(b["adv_mean"]) - float(adv.double().mean())) < 1e-5
+    eng.close(); eng2.close()
