@@ -236,6 +236,7 @@ def main() -> None:
                                                         partials=col.partials, gamma=col.gamma, reward=col.raw_rew[0]))
                 in_graph = graph_kernel_times()
                 us_pol = pick(in_graph, "policy_forward_kernel", at_least=0.75 * ev_pol) or ev_pol
+                us_pol_all = pick(in_graph, "policy_forward_kernel")     # what a per-symbol profiler average shows
                 us_fused = pick(in_graph, "step_kernel<float,true,true") or ev_fused
                 if not (0.6 * ev_pol < us_pol < 1.6 * ev_pol and 0.6 * ev_fused < us_fused < 1.6 * ev_fused):
                     in_graph, us_pol, us_fused = {}, ev_pol, ev_fused     # tracer output implausible: trust the events
@@ -249,6 +250,10 @@ def main() -> None:
                             "traffic": traffic_of("fpv::policy_forward_kernel"), "us_per_launch": round(us_pol, 2),
                             "launches": L, "algorithmic_flop_per_launch": POLICY_FLOP_PER_ROW * n, "dtype": "f32",
                             "measured": how, "us_per_launch_hip_events_back_to_back": round(ev_pol, 2)}
+                if in_graph and us_pol_all:
+                    # rocprofv3 --stats averages over ALL launches of the symbol: per rollout of n_steps that is n_steps
+                    # full launches plus the tail's V-only launch and the short done-ledger launch
+                    roofline["us_per_launch_all_launches_of_the_symbol"] = round(us_pol_all, 2)
             else:
                 roofline = roofline_env_plain
 

@@ -72,7 +72,7 @@ SIGNATURES = {
     "fpv_step_fused": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(FpvStepExtras), _vp]),
     "fpv_moments_merge": (C.c_int, [_i64, _vp, C.c_double, _vp, _vp, _vp, _vp]),
     "fpv_partial_rows": (C.c_int, [_vp, C.POINTER(_i64)]),
-    "fpv_moments_merge_to": (C.c_int, [_i64, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fpv_moments_merge_to": (C.c_int, [_i64, _i32, _vp, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fpv_reward_finalize": (C.c_int, [_i64, _i64, _vp, _vp, _f32, _f32, _vp, _vp]),
     "fpv_dims": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "fpv_tick_ptr": (C.c_int, [_vp, C.POINTER(_vp)]),

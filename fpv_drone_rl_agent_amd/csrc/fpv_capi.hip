@@ -80,7 +80,7 @@ static int step_impl(fpv_env* e, const T* actions, T* obs, T* reward, uint8_t* t
         return fail(FPV_ERR_ARG, "fpv_step: handle precision does not match this entry point");
     if (((uintptr_t)obs | (e->act_words == 4 ? (uintptr_t)actions : 0)) & (sizeof(T) * 4 - 1))
         return fail(FPV_ERR_ARG, "fpv_step: actions/obs must be %zu-byte aligned", sizeof(T) * 4);
-    if (ex && e->cfg.task != FPV_TASK_HOVER) return fail(FPV_ERR_UNSUPPORTED, "fpv_step_fused: hover task only");
+
     StepArgs<T> a;
     a.state = (Vec4<T>*)e->state;
     a.actions = actions; a.obs = obs; a.reward = reward; a.terminated = term; a.truncated = trunc;
@@ -232,20 +232,21 @@ int fpv_moments_merge(int64_t tiles, const double* partials, double batch_count,
     double* scratch = nullptr;
     if (int rc = scratch_for_current_device(&scratch)) return rc;
     FPV_HIP(launch_moments_merge_tiles(tiles, partials, batch_count, nullptr, nullptr, obs_rms, ret_rms, snapshot, scratch,
-                                       (hipStream_t)stream));
+                                       20, (hipStream_t)stream));
     return FPV_OK;
 }
 
-int fpv_moments_merge_to(int64_t tiles, const double* partials, double batch_count, const double* obs_rms_in,
-                         const double* ret_rms_in, double* obs_rms_out, double* ret_rms_out, double* snapshot,
-                         void* stream) {
+int fpv_moments_merge_to(int64_t tiles, int32_t obs_words, const double* partials, double batch_count,
+                         const double* obs_rms_in, const double* ret_rms_in, double* obs_rms_out, double* ret_rms_out,
+                         double* snapshot, void* stream) {
     if (tiles <= 0 || !partials || batch_count <= 0.0) return fail(FPV_ERR_ARG, "fpv_moments_merge_to: bad arguments");
+    if (obs_words < 1 || obs_words > 20) return fail(FPV_ERR_ARG, "fpv_moments_merge_to: obs_words must be 1..20");
     if ((obs_rms_out && !obs_rms_in) || (ret_rms_out && !ret_rms_in))
         return fail(FPV_ERR_ARG, "fpv_moments_merge_to: an output statistic needs its input");
     double* scratch = nullptr;
     if (int rc = scratch_for_current_device(&scratch)) return rc;
     FPV_HIP(launch_moments_merge_tiles(tiles, partials, batch_count, obs_rms_in, ret_rms_in, obs_rms_out, ret_rms_out,
-                                       snapshot, scratch, (hipStream_t)stream));
+                                       snapshot, scratch, obs_words, (hipStream_t)stream));
     return FPV_OK;
 }
 
@@ -258,9 +259,9 @@ int fpv_reward_finalize(int64_t T, int64_t n, const float* raw, const double* sn
 
 int fpv_partial_rows(fpv_env* e, int64_t* rows) {
     if (!e || !rows) return fail(FPV_ERR_ARG, "fpv_partial_rows: null argument");
-    if (e->cfg.task != FPV_TASK_HOVER || e->cfg.precision != 0)
-        return fail(FPV_ERR_UNSUPPORTED, "fpv_partial_rows: fpv_step_fused serves fp32 hover handles");
-    *rows = step_partial_rows(e->cfg.num_envs, e->cfg.noise_ratio != 0.0);
+    if (e->cfg.precision != 0) return fail(FPV_ERR_UNSUPPORTED, "fpv_partial_rows: fpv_step_fused serves fp32 handles");
+    *rows = e->cfg.task == FPV_TASK_YAW ? yaw_partial_rows(e->cfg.num_envs)
+                                        : step_partial_rows(e->cfg.num_envs, e->cfg.noise_ratio != 0.0);
     return FPV_OK;
 }
 
@@ -496,13 +497,13 @@ int fpv_policy_forward(fpv_policy* p, const fpv_policy_io* io, void* stream) {
     if (io->merge_partials) {
         if (io->merge_rows <= 0 || io->merge_rows > 1024)
             return fail(FPV_ERR_UNSUPPORTED, "fpv_policy_forward: in-launch merge takes 1..1024 partial rows (use fpv_moments_merge beyond)");
-        if (p->in_dim != 20 || nets != 3 || io->narrow)
-            return fail(FPV_ERR_UNSUPPORTED, "fpv_policy_forward: in-launch merge needs the hover widths, both nets and 512-thread workgroups");
+        if (p->in_dim > 20 || nets != 3 || io->narrow)
+            return fail(FPV_ERR_UNSUPPORTED, "fpv_policy_forward: in-launch merge needs in_dim <= 20, both nets and 512-thread workgroups");
         if (!(io->merge_count > 0.0)) return fail(FPV_ERR_ARG, "fpv_policy_forward: merge_count must be positive");
         if ((io->rms && (!io->rms_out || io->rms_out == io->rms)) || (io->ret_rms && (!io->ret_rms_out || io->ret_rms_out == io->ret_rms)))
             return fail(FPV_ERR_ARG, "fpv_policy_forward: merged statistics go to a second buffer (other workgroups still read the first)");
         mg = MergeArgs{io->merge_partials, io->ret_rms, io->rms ? io->rms_out : nullptr, io->ret_rms ? io->ret_rms_out : nullptr,
-                       io->merge_snapshot, io->merge_count, (int32_t)io->merge_rows, 0};
+                       io->merge_snapshot, io->merge_count, (int32_t)io->merge_rows, p->in_dim};
     }
     // the bf16-split kernel evaluates both nets of the hover widths in 512-thread workgroups over a host-side row count;
     // any other request is served by the exact-fp32 kernel (its image is always packed)

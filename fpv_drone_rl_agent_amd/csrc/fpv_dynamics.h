@@ -473,4 +473,56 @@ __device__ __forceinline__ void store_obs_tile(const T (&o)[W], T* __restrict__ 
     }
 }
 
+// VecNormalize's per-tile fp64 sums {sum obs[W], sum obs^2[W], sum ret, sum ret^2, 0, 0} (2 W + 4 words) from the
+// LDS-staged tile ([64][W] observations followed by 64 returns), by ONE wave: 60 lanes = G row groups x W channels
+// (G = 3 for the hover task's 20 words, 5 for the yaw task's 12) walk the tile with fixed trip counts + selects so that
+// the LDS reads issue back to back, lanes 60..63 take the returns, and the groups are folded in a fixed order through a
+// small LDS exchange (xch: 128 doubles).  Shared by every fused step kernel, so the sums do not depend on which ran.
+template <int W>
+__device__ __forceinline__ void tile_moment_sums(const float* lds_w, double* xch, int rows, int lane, double* row) {
+    constexpr int G = 60 / W, Q = (kTile + G - 1) / G;
+    static_assert(G * W == 60, "observation width must divide 60");
+    double s1 = 0.0, s2 = 0.0;
+    if (lane < G * W) {
+        const int g = lane / W, c = lane - g * W;
+        float v[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int r = G * q + g;
+            v[q] = r < rows ? lds_w[(r < kTile ? r : 0) * W + c] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < Q; ++q) { const double d = (double)v[q]; s1 += d; s2 += d * d; }
+    } else {
+        const int g = lane - G * W;
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int r = 4 * q + g;
+            v[q] = r < rows ? lds_w[kTile * W + r] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const double d = (double)v[q]; s1 += d; s2 += d * d; }
+    }
+    xch[2 * lane] = s1;
+    xch[2 * lane + 1] = s2;
+    // the 64 lanes of this wave exchange through LDS: a wave's LDS operations complete in order, so only the
+    // compiler has to be kept from moving the reads above the writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < W) {
+        double a = xch[2 * lane], b = xch[2 * lane + 1];
+#pragma unroll
+        for (int g = 1; g < G; ++g) { a += xch[2 * (lane + g * W)]; b += xch[2 * (lane + g * W) + 1]; }
+        row[lane] = a;
+        row[W + lane] = b;
+    } else if (lane == 60) {
+        row[2 * W] = (xch[120] + xch[122]) + (xch[124] + xch[126]);
+        row[2 * W + 1] = (xch[121] + xch[123]) + (xch[125] + xch[127]);
+        row[2 * W + 2] = 0.0;
+        row[2 * W + 3] = 0.0;
+    }
+}
+
 }  // namespace fpv

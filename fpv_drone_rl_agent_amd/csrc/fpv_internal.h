@@ -63,6 +63,7 @@ hipError_t launch_yaw_convert(void* state, void* canon, int64_t n, bool to_canon
 
 extern int64_t g_pair_max_tiles;
 int64_t step_partial_rows(int64_t n, bool noise);
+int64_t yaw_partial_rows(int64_t n);
 hipError_t launch_tick_fill(uint64_t* tick, int64_t tiles, uint64_t v, hipStream_t s);
 
 // fpv_rollout.hip
@@ -73,7 +74,7 @@ hipError_t launch_normalize(int64_t n, int32_t d, const float* x, float* y, doub
                             float eps, double* scratch, hipStream_t s);
 hipError_t launch_moments_merge_tiles(int64_t tiles, const double* partials, double batch_count, const double* obs_rms_in,
                                       const double* ret_rms_in, double* obs_rms, double* ret_rms, double* snapshot,
-                                      double* scratch, hipStream_t s);
+                                      double* scratch, int obs_words, hipStream_t s);
 hipError_t launch_reward_finalize(int64_t T, int64_t n, const float* raw, const double* snapshots, float clip, float eps,
                                   float* out, hipStream_t s);
 hipError_t launch_normalize_reward(int64_t n, const float* r, const uint8_t* done, float* ret, float* r_out,
@@ -115,7 +116,7 @@ struct MergeArgs {
     double* ret_rms_out;     // [3] or null
     double* snapshot;        // [kPartialWords] or null
     double batch_count;
-    int32_t nrows, reserved;
+    int32_t nrows, obs_words;   // rows of 2 O + 4 words (O = obs_words <= 20)
 };
 constexpr int kPrologueMergeWays = 9;                                   // 9 x 44 = 396 threads of a 512-thread workgroup
 constexpr int kMergeLdsBytes = kPrologueMergeWays * kPartialWords * 8;   // 3 168 B of exchange space
@@ -128,11 +129,12 @@ struct MergeRegs {
 };
 
 __device__ __forceinline__ void merge_request(const MergeArgs& m, MergeRegs& r) {
-    const int tid = threadIdx.x, j = tid / kPartialWords, c = tid - j * kPartialWords;
+    const int P = 2 * m.obs_words + 4;
+    const int tid = threadIdx.x, j = tid / P, c = tid - j * P;
 #pragma unroll
     for (int q = 0; q < kMergeBatch; ++q) {
         const int b = j + q * kPrologueMergeWays;
-        r.v[q] = (j < kPrologueMergeWays && b < m.nrows) ? m.rows[(int64_t)b * kPartialWords + c] : 0.0;
+        r.v[q] = (j < kPrologueMergeWays && b < m.nrows) ? m.rows[(int64_t)b * P + c] : 0.0;
     }
 }
 
@@ -140,7 +142,8 @@ __device__ __forceinline__ void merge_request(const MergeArgs& m, MergeRegs& r) 
 // Contains workgroup barriers: every thread of the workgroup must call it.
 __device__ __forceinline__ void merge_prologue(const MergeArgs& m, const MergeRegs& r, const double* __restrict__ obs_rms,
                                                double* xch, float eps_norm, float* mean_f, float* inv_f) {
-    const int tid = threadIdx.x, j = tid / kPartialWords, c = tid - j * kPartialWords;
+    const int O = m.obs_words, P = 2 * O + 4;
+    const int tid = threadIdx.x, j = tid / P, c = tid - j * P;
     if (j < kPrologueMergeWays) {
         double acc = 0.0;
 #pragma unroll
@@ -150,7 +153,7 @@ __device__ __forceinline__ void merge_prologue(const MergeArgs& m, const MergeRe
 #pragma unroll
             for (int q = 0; q < kMergeBatch; ++q) {
                 const int b = j + (q0 + q) * kPrologueMergeWays;
-                v[q] = b < m.nrows ? m.rows[(int64_t)b * kPartialWords + c] : 0.0;
+                v[q] = b < m.nrows ? m.rows[(int64_t)b * P + c] : 0.0;
             }
 #pragma unroll
             for (int q = 0; q < kMergeBatch; ++q) acc += v[q];
@@ -158,31 +161,29 @@ __device__ __forceinline__ void merge_prologue(const MergeArgs& m, const MergeRe
         xch[j * kPartialWords + c] = acc;
     }
     __syncthreads();
-    if (tid < kPartialWords) {
+    if (tid < P) {
         double t = 0.0;
         for (int w = 0; w < kPrologueMergeWays; ++w) t += xch[w * kPartialWords + tid];
         xch[tid] = t;                           // row 0 <- column sums (each thread touches its own column only)
     }
     __syncthreads();
     const bool publish = blockIdx.x == 0;
-    if (tid < 20) {
-        double nm = 0.0, nv = 1.0, tot = 0.0;
+    if (tid < O) {
         if (obs_rms) {
-            const double cnt = obs_rms[40], mean = obs_rms[tid], var = obs_rms[20 + tid];
+            const double cnt = obs_rms[2 * O], mean = obs_rms[tid], var = obs_rms[O + tid];
             const double bm = xch[tid] / m.batch_count;
-            double bv = xch[20 + tid] / m.batch_count - bm * bm;
+            double bv = xch[O + tid] / m.batch_count - bm * bm;
             if (bv < 0.0) bv = 0.0;
-            const double delta = bm - mean;
-            tot = cnt + m.batch_count;
-            nm = mean + delta * m.batch_count / tot;
-            nv = (var * cnt + bv * m.batch_count + delta * delta * cnt * m.batch_count / tot) / tot;
+            const double delta = bm - mean, tot = cnt + m.batch_count;
+            const double nm = mean + delta * m.batch_count / tot;
+            const double nv = (var * cnt + bv * m.batch_count + delta * delta * cnt * m.batch_count / tot) / tot;
             if (publish && m.obs_rms_out) {
-                m.obs_rms_out[tid] = nm; m.obs_rms_out[20 + tid] = nv;
-                if (tid == 0) m.obs_rms_out[40] = tot;
+                m.obs_rms_out[tid] = nm; m.obs_rms_out[O + tid] = nv;
+                if (tid == 0) m.obs_rms_out[2 * O] = tot;
             }
             if (publish && m.snapshot) {
-                m.snapshot[tid] = nm; m.snapshot[20 + tid] = nv;
-                if (tid == 0) m.snapshot[40] = tot;
+                m.snapshot[tid] = nm; m.snapshot[O + tid] = nv;
+                if (tid == 0) m.snapshot[2 * O] = tot;
             }
             mean_f[tid] = (float)nm;
             inv_f[tid] = (float)(1.0 / sqrt(nv + (double)eps_norm));
@@ -190,10 +191,10 @@ __device__ __forceinline__ void merge_prologue(const MergeArgs& m, const MergeRe
             mean_f[tid] = 0.0f;
             inv_f[tid] = 1.0f;
         }
-    } else if (tid == 40 && m.ret_rms && publish) {
+    } else if (tid == 2 * O && m.ret_rms && publish) {
         const double cnt = m.ret_rms[2], mean = m.ret_rms[0], var = m.ret_rms[1];
-        const double bm = xch[40] / m.batch_count;
-        double bv = xch[41] / m.batch_count - bm * bm;
+        const double bm = xch[2 * O] / m.batch_count;
+        double bv = xch[2 * O + 1] / m.batch_count - bm * bm;
         if (bv < 0.0) bv = 0.0;
         const double delta = bm - mean, tot = cnt + m.batch_count;
         const double nm = mean + delta * m.batch_count / tot;

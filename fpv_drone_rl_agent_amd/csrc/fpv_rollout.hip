@@ -241,29 +241,31 @@ __global__ __launch_bounds__(kRedBlock) void reward_apply_kernel(int64_t n, cons
 // ---------------------------------------------------------------- fused-step moment merge
 // Stage 1 (only when there are many tiles): G workgroups each fold a contiguous range of tile rows.
 __global__ __launch_bounds__(256) void tile_partials_reduce_kernel(const double* __restrict__ partials, int64_t tiles,
-                                                                   int64_t per_group, double* __restrict__ group) {
+                                                                   int64_t per_group, double* __restrict__ group, int P) {
     __shared__ double l[4][kPartialWords];
-    const int c = threadIdx.x % 64, j = threadIdx.x / 64;   // 4 ways x 64 lanes (44 used)
+    const int c = threadIdx.x % 64, j = threadIdx.x / 64;   // 4 ways x 64 lanes (P = 2 O + 4 <= 44 used)
     const int64_t t0 = (int64_t)blockIdx.x * per_group, t1 = t0 + per_group < tiles ? t0 + per_group : tiles;
     double acc = 0.0;
-    if (c < kPartialWords)
-        for (int64_t t = t0 + j; t < t1; t += 4) acc += partials[t * kPartialWords + c];
-    if (c < kPartialWords) l[j][c] = acc;
+    if (c < P)
+        for (int64_t t = t0 + j; t < t1; t += 4) acc += partials[t * P + c];
+    if (c < P) l[j][c] = acc;
     __syncthreads();
-    if (j == 0 && c < kPartialWords) group[(int64_t)blockIdx.x * kPartialWords + c] = (l[0][c] + l[1][c]) + (l[2][c] + l[3][c]);
+    if (j == 0 && c < P) group[(int64_t)blockIdx.x * P + c] = (l[0][c] + l[1][c]) + (l[2][c] + l[3][c]);
 }
 
-// Stage 2: one workgroup merges the rows into the running statistics of SB3's RunningMeanStd (obs: 20
-// channels, ret: 1 channel) and snapshots {obs mean[20], obs var[20], obs count, ret mean, ret var, ret count}.
-// 23 ways x 44 channels = 1012 of the 1024 threads; consecutive threads read consecutive doubles, and each
-// thread keeps four independent accumulators so that its loads overlap.
+// Stage 2: one workgroup merges the rows (P = 2 O + 4 words: {sum obs[O], sum obs^2[O], sum ret, sum ret^2, 0, 0}) into
+// the running statistics of SB3's RunningMeanStd (obs: O channels, {mean[O], var[O], count}; ret: {mean, var, count}) and
+// snapshots {obs statistics [2 O + 1] from word 0, ret statistics at words 41..43}.
+// 23 ways x P channels (1 012 of the 1 024 threads for the hover task's P = 44); consecutive threads read consecutive
+// doubles, and each thread keeps its loads independent so that the whole table costs one memory round trip.
 constexpr int kTileMergeWays = 23;
 __global__ __launch_bounds__(1024) void tile_partials_merge_kernel(const double* __restrict__ rows, int nrows,
                                                                    double batch_count, const double* obs_rms_in,
                                                                    const double* ret_rms_in, double* obs_rms,
-                                                                   double* ret_rms, double* snapshot) {
+                                                                   double* ret_rms, double* snapshot, int O) {
     __shared__ double l[kTileMergeWays][64];
-    const int j = threadIdx.x / kPartialWords, c = threadIdx.x % kPartialWords;
+    const int P = 2 * O + 4;
+    const int j = threadIdx.x / P, c = threadIdx.x % P;
     if (j < kTileMergeWays) {
         // nrows <= 1024 (more tiles go through stage 1): every load of this thread is requested before the first
         // add, so the whole table costs one memory round trip; the adds then run in row order
@@ -272,14 +274,14 @@ __global__ __launch_bounds__(1024) void tile_partials_merge_kernel(const double*
 #pragma unroll
         for (int q = 0; q < kIter; ++q) {
             const int b = j + q * kTileMergeWays;
-            v[q] = b < nrows ? rows[(int64_t)b * kPartialWords + c] : 0.0;
+            v[q] = b < nrows ? rows[(int64_t)b * P + c] : 0.0;
         }
         double acc = 0.0;
 #pragma unroll
         for (int q = 0; q < kIter; ++q) acc += v[q];
         l[j][c] = acc;
     }
-    const double obs_count = obs_rms ? obs_rms_in[40] : 0.0, ret_count = ret_rms ? ret_rms_in[2] : 0.0;
+    const double obs_count = obs_rms ? obs_rms_in[2 * O] : 0.0, ret_count = ret_rms ? ret_rms_in[2] : 0.0;
     __syncthreads();
     if (j == 0) {
         double acc = 0.0;
@@ -288,20 +290,20 @@ __global__ __launch_bounds__(1024) void tile_partials_merge_kernel(const double*
     }
     __syncthreads();
     if (j != 0) return;
-    if (c < 20 && obs_rms) {
+    if (c < O && obs_rms) {
         const double bm = l[0][c] / batch_count;
-        double bv = l[0][20 + c] / batch_count - bm * bm;
+        double bv = l[0][O + c] / batch_count - bm * bm;
         if (bv < 0.0) bv = 0.0;
-        const double mean = obs_rms_in[c], var = obs_rms_in[20 + c], delta = bm - mean, tot = obs_count + batch_count;
+        const double mean = obs_rms_in[c], var = obs_rms_in[O + c], delta = bm - mean, tot = obs_count + batch_count;
         const double nm = mean + delta * batch_count / tot;
         const double nv = (var * obs_count + bv * batch_count + delta * delta * obs_count * batch_count / tot) / tot;
-        obs_rms[c] = nm; obs_rms[20 + c] = nv;
-        if (snapshot) { snapshot[c] = nm; snapshot[20 + c] = nv; }
-        if (c == 0) { obs_rms[40] = tot; if (snapshot) snapshot[40] = tot; }
+        obs_rms[c] = nm; obs_rms[O + c] = nv;
+        if (snapshot) { snapshot[c] = nm; snapshot[O + c] = nv; }
+        if (c == 0) { obs_rms[2 * O] = tot; if (snapshot) snapshot[2 * O] = tot; }
     }
-    if (c == 40 && ret_rms) {
-        const double bm = l[0][40] / batch_count;
-        double bv = l[0][41] / batch_count - bm * bm;
+    if (c == 2 * O && ret_rms) {
+        const double bm = l[0][2 * O] / batch_count;
+        double bv = l[0][2 * O + 1] / batch_count - bm * bm;
         if (bv < 0.0) bv = 0.0;
         const double mean = ret_rms_in[0], var = ret_rms_in[1], delta = bm - mean, tot = ret_count + batch_count;
         const double nm = mean + delta * batch_count / tot;
@@ -313,18 +315,20 @@ __global__ __launch_bounds__(1024) void tile_partials_merge_kernel(const double*
 
 hipError_t launch_moments_merge_tiles(int64_t tiles, const double* partials, double batch_count, const double* obs_rms_in,
                                       const double* ret_rms_in, double* obs_rms, double* ret_rms, double* snapshot,
-                                      double* scratch, hipStream_t s) {
+                                      double* scratch, int obs_words, hipStream_t s) {
     const double* rows = partials;
     int nrows = (int)tiles;
+    const int P = 2 * obs_words + 4;
     if (tiles > 1024) {
         const int groups = 256;
         const int64_t per_group = (tiles + groups - 1) / groups;
-        hipLaunchKernelGGL(tile_partials_reduce_kernel, dim3(groups), dim3(256), 0, s, partials, tiles, per_group, scratch);
+        hipLaunchKernelGGL(tile_partials_reduce_kernel, dim3(groups), dim3(256), 0, s, partials, tiles, per_group, scratch, P);
         rows = scratch;
         nrows = (int)((tiles + per_group - 1) / per_group);
     }
     hipLaunchKernelGGL(tile_partials_merge_kernel, dim3(1), dim3(1024), 0, s, rows, nrows, batch_count,
-                       obs_rms_in ? obs_rms_in : obs_rms, ret_rms_in ? ret_rms_in : ret_rms, obs_rms, ret_rms, snapshot);
+                       obs_rms_in ? obs_rms_in : obs_rms, ret_rms_in ? ret_rms_in : ret_rms, obs_rms, ret_rms, snapshot,
+                       obs_words);
     return hipGetLastError();
 }
 

@@ -58,51 +58,6 @@ __device__ __forceinline__ void drone_from_template(Drone<T>& d, T tv) {
     d.er = __shfl(tv, 28); d.ep = __shfl(tv, 29); d.eyaw = __shfl(tv, 30); d.prev_cy = __shfl(tv, 31);
 }
 
-// VecNormalize's per-tile fp64 sums {sum obs[20], sum obs^2[20], sum ret, sum ret^2} from the LDS-staged tile, by ONE
-// wave: 60 lanes = 3 row groups x 20 channels walk the tile (fixed trip counts + selects so that the LDS reads issue
-// back to back), lanes 60..63 take the returns, and the groups are folded in a fixed order through a small LDS
-// exchange.  Used by both step kernels, so the sums do not depend on which of them ran.
-__device__ __forceinline__ void tile_moment_sums(const float* lds_w, double* xch, int rows, int lane, double* row) {
-    double s1 = 0.0, s2 = 0.0;
-    if (lane < 3 * kObsWords) {
-        const int g = lane / kObsWords, c = lane - g * kObsWords;
-        float v[22];
-#pragma unroll
-        for (int q = 0; q < 22; ++q) {
-            const int r = 3 * q + g;
-            v[q] = r < rows ? lds_w[(r < kTile ? r : 0) * kObsWords + c] : 0.0f;
-        }
-#pragma unroll
-        for (int q = 0; q < 22; ++q) { const double d = (double)v[q]; s1 += d; s2 += d * d; }
-    } else {
-        const int g = lane - 3 * kObsWords;
-        float v[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int r = 4 * q + g;
-            v[q] = r < rows ? lds_w[kTile * kObsWords + r] : 0.0f;
-        }
-#pragma unroll
-        for (int q = 0; q < 16; ++q) { const double d = (double)v[q]; s1 += d; s2 += d * d; }
-    }
-    xch[2 * lane] = s1;
-    xch[2 * lane + 1] = s2;
-    // the 64 lanes of this wave exchange through LDS: a wave's LDS operations complete in order, so only the
-    // compiler has to be kept from moving the reads above the writes
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane < kObsWords) {
-        row[lane] = (xch[2 * lane] + xch[2 * (lane + kObsWords)]) + xch[2 * (lane + 2 * kObsWords)];
-        row[kObsWords + lane] = (xch[2 * lane + 1] + xch[2 * (lane + kObsWords) + 1]) + xch[2 * (lane + 2 * kObsWords) + 1];
-    } else if (lane == 60) {
-        row[2 * kObsWords] = (xch[120] + xch[122]) + (xch[124] + xch[126]);
-        row[2 * kObsWords + 1] = (xch[121] + xch[123]) + (xch[125] + xch[127]);
-        row[2 * kObsWords + 2] = 0.0;
-        row[2 * kObsWords + 3] = 0.0;
-    }
-}
-
 // ---------------------------------------------------------------- K1
 // TPB tiles (waves) per workgroup.  The waves are independent except at the very end of the fused variant, where a
 // TPB = 4 workgroup adds its four tiles' moment sums and writes ONE partial row: the table that the statistics merge
@@ -213,7 +168,7 @@ __global__ __launch_bounds__(kTile * TPB) void step_kernel(StepArgs<T> p) {
         if (p.partials) {
             if constexpr (sizeof(T) == 4) {
                 const int rows = (int)((p.n - tile * kTile) < kTile ? (p.n - tile * kTile) : kTile);
-                tile_moment_sums(reinterpret_cast<const float*>(lds), reinterpret_cast<double*>(lds_w + kTile * kObsWords + kTile),
+                tile_moment_sums<kObsWords>(reinterpret_cast<const float*>(lds), reinterpret_cast<double*>(lds_w + kTile * kObsWords + kTile),
                                  rows, lane, TPB > 1 ? bsum + wv * kPartialWords : p.partials + tile * kPartialWords);
                 if constexpr (TPB == 4) {
                     __syncthreads();
@@ -274,7 +229,7 @@ __global__ __launch_bounds__(2 * kTile) void step_kernel_pair(StepArgs<float> p)
         if constexpr (FUSED) {
             if (p.partials) {
                 const int rows = (int)(rows_left < kTile ? rows_left : kTile);
-                tile_moment_sums(reinterpret_cast<const float*>(lds), reinterpret_cast<double*>(&nz[0][0][0]), rows, lane,
+                tile_moment_sums<kObsWords>(reinterpret_cast<const float*>(lds), reinterpret_cast<double*>(&nz[0][0][0]), rows, lane,
                                  p.partials + tile * kPartialWords);   // the noise slots are free by now: reuse as exchange
             }
         }

@@ -67,13 +67,23 @@ __device__ __forceinline__ T warm_throttle() {
     return thr;
 }
 
-template <typename T, bool NOISE>
-__global__ __launch_bounds__(kTile) void yaw_step_kernel(StepArgs<T> p) {
-    __shared__ Vec4<T> lds[kTile * kYawObsWords / 4];
-    const int lane = threadIdx.x;
-    const int64_t tile = blockIdx.x;
+// FUSED / TPB as in the hover step (fpv_step.hip): VecNormalize's done mask, discounted return and moment sums in the same
+// pass, TPB tiles per workgroup with one partial row (2 x 12 + 4 words) per workgroup.
+template <typename T, bool NOISE, bool FUSED = false, int TPB = 1>
+__global__ __launch_bounds__(kTile * TPB) void yaw_step_kernel(StepArgs<T> p) {
+    constexpr int kLdsPerTile = kTile * kYawObsWords / 4 + (FUSED ? kTile / 4 + kTile : 0);
+    constexpr int kRow = 2 * kYawObsWords + 4;
+    __shared__ Vec4<T> lds_all[TPB * kLdsPerTile];
+    __shared__ double bsum[TPB > 1 ? TPB * kRow : 1];
+    const int lane = threadIdx.x & (kTile - 1), wv = threadIdx.x / kTile;
+    Vec4<T>* lds = lds_all + wv * kLdsPerTile;
+    const int64_t tile = (int64_t)blockIdx.x * TPB + wv;
     const int64_t i = tile * kTile + lane;
     const bool live = i < p.n;
+    T ret_in = T(0);
+    if constexpr (FUSED) {
+        if (p.ret && live) ret_in = p.ret[i];
+    }
 
     Drone<T> d;
     load_drone<T, kYawGranules>(d, p.state, tile, lane);
@@ -141,7 +151,33 @@ __global__ __launch_bounds__(kTile) void yaw_step_kernel(StepArgs<T> p) {
         p.terminated[i] = (bits & kInfoTerm) ? 1 : 0;
         p.truncated[i] = (bits & kInfoTrunc) ? 1 : 0;
     }
-    store_obs_tile<T, kYawObsWords>(o, p.obs, tile, lane, p.n, lds);
+    if constexpr (FUSED) {
+        T* lds_w = reinterpret_cast<T*>(lds);
+        if (live && p.done) p.done[i] = done ? 1 : 0;
+        T ret = T(0);
+        if (p.ret) {
+            ret = live ? ret_in * (T)p.gamma + reward : T(0);
+            if (live) p.ret[i] = done ? T(0) : ret;
+        }
+        lds_w[kTile * kYawObsWords + lane] = ret;
+        store_obs_tile<T, kYawObsWords>(o, p.obs, tile, lane, p.n, lds);
+        if (p.partials) {
+            if constexpr (sizeof(T) == 4) {
+                const int rows = (int)((p.n - tile * kTile) < kTile ? (p.n - tile * kTile) : kTile);
+                tile_moment_sums<kYawObsWords>(reinterpret_cast<const float*>(lds),
+                                               reinterpret_cast<double*>(lds_w + kTile * kYawObsWords + kTile), rows, lane,
+                                               TPB > 1 ? bsum + wv * kRow : p.partials + tile * kRow);
+                if constexpr (TPB == 4) {
+                    __syncthreads();
+                    if (wv == 0 && lane < kRow)
+                        p.partials[(int64_t)blockIdx.x * kRow + lane] =
+                            (bsum[lane] + bsum[kRow + lane]) + (bsum[2 * kRow + lane] + bsum[3 * kRow + lane]);
+                }
+            }
+        }
+    } else {
+        store_obs_tile<T, kYawObsWords>(o, p.obs, tile, lane, p.n, lds);
+    }
 }
 
 template <typename T>
@@ -185,9 +221,27 @@ __global__ void yaw_convert_kernel(Vec4<T>* state, T* canon, int64_t n) {
 template <typename T>
 hipError_t launch_yaw_step(const StepArgs<T>& a, bool noise, hipStream_t s) {
     const int64_t tiles = (a.n + kTile - 1) / kTile;
+    const bool fused = a.done || a.ret || a.partials;
+    if constexpr (sizeof(T) == 4) {
+        if (fused) {
+            if (tiles % 4 == 0) {               // four tiles per workgroup, one partial row per workgroup (yaw_partial_rows)
+                if (noise) hipLaunchKernelGGL((yaw_step_kernel<T, true, true, 4>), dim3((unsigned)(tiles / 4)), dim3(4 * kTile), 0, s, a);
+                else hipLaunchKernelGGL((yaw_step_kernel<T, false, true, 4>), dim3((unsigned)(tiles / 4)), dim3(4 * kTile), 0, s, a);
+            } else {
+                if (noise) hipLaunchKernelGGL((yaw_step_kernel<T, true, true, 1>), dim3((unsigned)tiles), dim3(kTile), 0, s, a);
+                else hipLaunchKernelGGL((yaw_step_kernel<T, false, true, 1>), dim3((unsigned)tiles), dim3(kTile), 0, s, a);
+            }
+            return hipGetLastError();
+        }
+    }
     if (noise) hipLaunchKernelGGL((yaw_step_kernel<T, true>), dim3((unsigned)tiles), dim3(kTile), 0, s, a);
     else hipLaunchKernelGGL((yaw_step_kernel<T, false>), dim3((unsigned)tiles), dim3(kTile), 0, s, a);
     return hipGetLastError();
+}
+
+int64_t yaw_partial_rows(int64_t n) {
+    const int64_t tiles = (n + kTile - 1) / kTile;
+    return tiles % 4 == 0 ? tiles / 4 : tiles;
 }
 template hipError_t launch_yaw_step<float>(const StepArgs<float>&, bool, hipStream_t);
 template hipError_t launch_yaw_step<double>(const StepArgs<double>&, bool, hipStream_t);

@@ -122,16 +122,17 @@ class FpvEngine:
 
     def step_fused(self, actions, *, done=None, ret=None, partials=None, gamma: float = 0.99, obs=None, reward=None):
         """fpv_step_fused: the env step plus VecNormalize's per-step bookkeeping (done mask, discounted-return
-        accumulator, moment sums in the first `partial_rows` rows of partials [tiles, 44]) in the same kernel.
-        fp32 engines only."""
+        accumulator, moment sums in the first `partial_rows` rows of partials [tiles, 2 * obs_words + 4]) in the same
+        kernel.  fp32 engines only."""
         if self._f64:
             raise ValueError("step_fused runs on fp32 engines")
         if partials is not None and (partials.dtype != torch.float64 or not partials.is_contiguous()
-                                     or partials.shape[0] < self.partial_rows or partials.shape[1] != 44):
-            raise ValueError("partials must be a contiguous float64 [>= partial_rows, 44] device tensor")
+                                     or partials.shape[0] < self.partial_rows
+                                     or partials.shape[1] != 2 * self.obs_words + 4):
+            raise ValueError(f"partials must be a contiguous float64 [>= partial_rows, {2 * self.obs_words + 4}] device tensor")
         if actions.dtype != self.dtype or actions.device != self.device or not actions.is_contiguous() \
-                or actions.shape != (self.num_envs, self.act_words) or self.task != "hover":
-            raise ValueError("actions must be a contiguous [num_envs, 4] device tensor of the engine's dtype")
+                or actions.shape != (self.num_envs, self.act_words):
+            raise ValueError(f"actions must be a contiguous [num_envs, {self.act_words}] device tensor of the engine's dtype")
         obs = self.obs if obs is None else obs
         reward = self.reward if reward is None else reward
         ex = L.FpvStepExtras(done.data_ptr() if done is not None else None, ret.data_ptr() if ret is not None else None,

@@ -109,17 +109,16 @@ class RewardNorm:
 
 
 def moments_merge(partials, batch_count, obs_rms=None, ret_rms=None, snapshot=None, obs_rms_in=None, ret_rms_in=None):
-    """Fold the per-tile sums written by FpvEngine.step_fused into the running statistics (fpv_moments_merge).
-    obs_rms_in / ret_rms_in: read the statistics from these buffers instead and write obs_rms / ret_rms."""
+    """Fold the per-tile sums written by FpvEngine.step_fused into the running statistics (fpv_moments_merge_to).
+    The observation width follows from the row width (2 O + 4).  obs_rms_in / ret_rms_in: read the statistics from
+    these buffers instead and write obs_rms / ret_rms."""
     _need(partials, torch.float64, "partials")
-    if obs_rms_in is None and ret_rms_in is None:
-        L.check(L.load().fpv_moments_merge(partials.shape[0], _ptr(partials), float(batch_count), _ptr(obs_rms),
-                                           _ptr(ret_rms), _ptr(snapshot), _stream(partials.device)), "fpv_moments_merge")
-        return
-    L.check(L.load().fpv_moments_merge_to(partials.shape[0], _ptr(partials), float(batch_count),
-                                          _ptr(obs_rms_in if obs_rms is not None else None),
-                                          _ptr(ret_rms_in if ret_rms is not None else None), _ptr(obs_rms), _ptr(ret_rms),
-                                          _ptr(snapshot), _stream(partials.device)), "fpv_moments_merge_to")
+    o = (partials.shape[1] - 4) // 2
+    L.check(L.load().fpv_moments_merge_to(partials.shape[0], o, _ptr(partials), float(batch_count),
+                                          _ptr((obs_rms_in if obs_rms_in is not None else obs_rms) if obs_rms is not None else None),
+                                          _ptr((ret_rms_in if ret_rms_in is not None else ret_rms) if ret_rms is not None else None),
+                                          _ptr(obs_rms), _ptr(ret_rms), _ptr(snapshot), _stream(partials.device)),
+            "fpv_moments_merge_to")
 
 
 def advantage_stats(gathered, out):

@@ -51,7 +51,8 @@ class RolloutCollector:
     def __init__(self, engine: FpvEngine, policy: ActorCritic, n_steps: int = 32, gamma: float = 0.99,
                  lam: float = 0.95, norm_obs: bool = True, norm_reward: bool = True, use_graph: bool = True,
                  clip_obs: float = 10.0, clip_reward: float = 10.0, fused: bool = True, policy_seed: int = 0,
-                 policy_gemm: str = "f32", overlap_critic: bool = False, merge_in_policy: bool = True):
+                 policy_gemm: str = "f32", overlap_critic: bool = False, merge_in_policy: bool = True,
+                 fused_step: bool = True):
         if engine.dtype != torch.float32:
             raise ValueError("the rollout collector runs on an fp32 engine")
         self.engine, self.policy = engine, policy
@@ -66,8 +67,8 @@ class RolloutCollector:
         self.O, self.A = O, A
         if (policy.obs_dim, policy.act_dim) != (O, A):
             raise ValueError(f"policy is {policy.obs_dim}->{policy.act_dim} but the task needs {O}->{A}")
-        fused_policy = bool(fused)                       # fpv_policy_forward takes both tasks' widths
-        fused = bool(fused) and engine.task == "hover"   # fpv_step_fused (VecNormalize bookkeeping in-kernel): hover only
+        fused_policy = bool(fused)                       # fpv_policy_forward and fpv_step_fused take both tasks' widths
+        fused = bool(fused) and bool(fused_step)         # fused_step=False: stand-alone env-step + normaliser kernels
         self.obs_norm = ops.RunningNorm(O, dev, clip=clip_obs)
         self.rew_norm = ops.RewardNorm(N, dev, gamma=gamma, clip=clip_reward)
         self.buf_obs = torch.zeros((T, N, O), dtype=f32, device=dev)
@@ -92,7 +93,7 @@ class RolloutCollector:
             self.fp = FusedPolicy(policy, seed=policy_seed, id_offset=engine.id_offset,
                                   gemm=policy_gemm if self.fused else "f32")
         if self.fused:
-            self._partials_full = torch.zeros((engine.tiles, 44), dtype=torch.float64, device=dev)
+            self._partials_full = torch.zeros((engine.tiles, 2 * O + 4), dtype=torch.float64, device=dev)
             self.partials = self._partials_full[:engine.partial_rows]       # the rows fpv_step_fused writes
             self.raw_rew = torch.zeros((T, N), dtype=f32, device=dev)
             # overlap_critic: the env step needs pi only, so the critic pass (MFMA-bound) can run on a second stream
@@ -152,7 +153,8 @@ class RolloutCollector:
             self._step_torch(t)
 
     def _step_semifused(self, t: int) -> None:
-        """Fused policy kernel + the stand-alone env-step / normaliser kernels (the yaw task's path)."""
+        """Fused policy kernel + the stand-alone env-step / normaliser kernels (`fused_step=False`: the reference of the
+        in-kernel VecNormalize bookkeeping)."""
         eng = self.engine
         self.fp.forward(eng.obs, rms=self.obs_norm.rms if self.norm_obs else None, tick=eng.tick_ptr,
                         obs_n=self.buf_obs[t], action=self.buf_act[t], clipped=self.clipped, value=self.buf_val[t],

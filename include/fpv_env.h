@@ -115,7 +115,8 @@ int fpv_step_f64(fpv_env* env, const double* actions, double* obs, double* rewar
  * {sum obs[20], sum obs^2[20], sum ret, sum ret^2, 0, 0} of the returned observations and of ret, one row per
  * 64-drone tile or per group of four tiles: fpv_partial_rows() says how many rows are written (ask again after
  * fpv_set_pair_threshold); they are folded into the running statistics by fpv_moments_merge(rows, ...) or by
- * the next fpv_policy_forward (merge_* fields).  Any of the three may be NULL.  fp32 hover handles. */
+ * the next fpv_policy_forward (merge_* fields).  Any of the three may be NULL.  fp32 handles; the yaw task's rows are
+ * 2 x 12 + 4 = 28 words ({sum obs[12], sum obs^2[12], sum ret, sum ret^2, 0, 0}), the hover task's 44. */
 #define FPV_PARTIAL_WORDS 44
 typedef struct {
     uint8_t* done;
@@ -134,10 +135,12 @@ int fpv_partial_rows(fpv_env* env, int64_t* rows);
  * NULL); snapshot (optional double[FPV_PARTIAL_WORDS]) receives {obs_rms[41], ret_rms[3]} after the merge. */
 int fpv_moments_merge(int64_t tiles, const double* partials, double batch_count, double* obs_rms,
                       double* ret_rms, double* snapshot, void* stream);
-/* The same with separate inputs and outputs (in == out is allowed). */
-int fpv_moments_merge_to(int64_t tiles, const double* partials, double batch_count, const double* obs_rms_in,
-                         const double* ret_rms_in, double* obs_rms_out, double* ret_rms_out, double* snapshot,
-                         void* stream);
+/* The same with separate inputs and outputs (in == out is allowed) and for any observation width O = obs_words <= 20
+ * (12 for the yaw task): rows of 2 O + 4 words, obs statistics double[2 O + 1] = {mean[O], var[O], count}; the
+ * snapshot holds the obs statistics from word 0 and the ret statistics at words 41..43. */
+int fpv_moments_merge_to(int64_t tiles, int32_t obs_words, const double* partials, double batch_count,
+                         const double* obs_rms_in, const double* ret_rms_in, double* obs_rms_out, double* ret_rms_out,
+                         double* snapshot, void* stream);
 
 /* VecNormalize.normalize_reward applied after the fact: out[t][i] = clip(raw[t][i] / sqrt(var_t + eps)) with
  * var_t = snapshots[t][42], the return variance as it stood after step t.  raw/out are [T][n]; out may alias raw. */
@@ -254,7 +257,7 @@ typedef struct {
      * wrote (extras.partials, merge_rows <= 1024 rows) into the statistics before normalising — what fpv_moments_merge
      * does, without its launch on the rollout's critical path.  `rms` (and `ret_rms`) are read; the merged statistics
      * are written to rms_out / ret_rms_out, which must be different buffers; merge_snapshot as in fpv_moments_merge.
-     * Needs the hover widths, nets = 0 / 3 and narrow = 0. */
+     * Rows are 2 in_dim + 4 words wide (fpv_policy_set_dims).  Needs nets = 0 / 3 and narrow = 0. */
     const double* merge_partials;
     int64_t merge_rows;
     double merge_count;      /* drones behind the sums (batch count of the RunningMeanStd update) */

@@ -70,8 +70,11 @@ def test_abi_argument_errors_on_device():
     assert lib.fpv_create(C.byref(cfg), C.byref(h)) == -1 and b"not present" in lib.fpv_last_error()
     cfg = L.FpvConfig(64, 0, 0, 1, 7, 0.02, 0, 0, 0, 0, 0)                # unknown task
     assert lib.fpv_create(C.byref(cfg), C.byref(h)) == -1 and b"task" in lib.fpv_last_error()
-    with pytest.raises(ValueError):
-        FpvEngine(64, 0, task="yaw").step_fused(torch.zeros(64, 1, device="cuda"))
+    with pytest.raises(ValueError):                                       # yaw actions are [n, 1]
+        FpvEngine(64, 0, task="yaw").step_fused(torch.zeros(64, 4, device="cuda"))
+    with pytest.raises(ValueError):                                       # yaw partial rows are 28 words wide
+        FpvEngine(64, 0, task="yaw").step_fused(torch.zeros(64, 1, device="cuda"),
+                                                 partials=torch.zeros(1, 44, dtype=torch.float64, device="cuda"))
     with pytest.raises(ValueError):
         FpvEngine(64, 0, precision="f64").step_fused(torch.zeros(64, 4, device="cuda", dtype=torch.float64))
     eng.step(a)                                                           # the handle is still usable after errors

@@ -143,7 +143,44 @@ def test_yaw_fused_policy_matches_torch_and_collects():
     # the collector picks the fused policy for the yaw task (stand-alone env / normaliser kernels) and stays finite
     eng = FpvEngine(2048, 0, task="yaw", domain_rand=True, ledger_capacity=8192)
     col = RolloutCollector(eng, m, n_steps=16)
-    assert col.fused_policy and not col.fused
+    assert col.fused_policy and col.fused
     b = col.collect()
     assert torch.isfinite(b["advantages"]).all() and torch.isfinite(b["returns"]).all() and float(b["adv_std"]) > 0
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("T", [5, 8])
+def test_yaw_fused_step_equals_the_stand_alone_normaliser_path(T):
+    """cfg 5 through the two-kernel rollout step (VecNormalize bookkeeping inside yaw_step_kernel, 28-word partial rows,
+    statistics merge in the policy launch) against the stand-alone env-step + normaliser kernels, two rollouts each."""
+    import torch
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    from fpv_drone_rl_agent_amd.rollout import RolloutCollector
+    n = 4096
+    outs = []
+    for fused_step in (True, False):
+        torch.manual_seed(1)
+        pol = ActorCritic(12, 1, log_std_init=-1.0).cuda()
+        eng = FpvEngine(n, 0, seed=5, task="yaw", domain_rand=True, ledger_capacity=4 * n)
+        col = RolloutCollector(eng, pol, n_steps=T, fused_step=fused_step)
+        assert col.fused == fused_step
+        col.start()
+        st = eng.get_state()
+        st[:, 34] = torch.randint(380, 400, (n,), device="cuda", generator=torch.Generator(device="cuda").manual_seed(3)).to(st.dtype)
+        eng.set_state(st)                       # step counters: truncations (step >= 400) inside the window
+        col.collect()
+        b = col.collect()
+        torch.cuda.synchronize()
+        outs.append({"obs": b["obs"].clone(), "rew": col.buf_rew.clone(), "adv": b["advantages"].clone(),
+                     "obs_rms": col.obs_norm.rms.clone(), "ret_rms": col.rew_norm.rms.clone(),
+                     "starts": col.buf_start.clone(), "episodes": dict(col.episodes)})
+        eng.close()
+    a, b = outs
+    assert a["episodes"]["count"] == b["episodes"]["count"] > 0 and a["episodes"]["truncated"] == b["episodes"]["truncated"] > 0
+    assert torch.equal(a["starts"], b["starts"])
+    for k in ("obs_rms", "ret_rms"):
+        assert torch.allclose(a[k], b[k], rtol=1e-6, atol=1e-9), k
+    for k in ("obs", "rew", "adv"):
+        assert torch.allclose(a[k], b[k], rtol=1e-3, atol=2e-3), k
