@@ -144,73 +144,6 @@ __device__ __forceinline__ void tanh_all(Hidden& a) {
         for (int r = 0; r < 16; ++r) a.t[m][r] = fast_tanh(a.t[m][r]);
 }
 
-// One net (NET 0 = pi, 1 = V) for this wave's 32 drones: accumulates the head dot products into head[0..3] / head[4].
-template <int NET>
-__device__ __forceinline__ void policy_net(const float* __restrict__ nb, const float* __restrict__ hb, int lane, int h,
-                                           const float (&x)[12], float (&head)[5]) {
-    // The matrix pipe and the vector ALU are separate: a wave that has issued a product can go on issuing VALU
-    // work while the product runs (64 cycles).  So every layer is accumulated tile by tile (one dependent chain
-    // — they run at full rate, tools/mfma_peak) and the finished tile's tanh (and, after layer 2, its share of
-    // the head dot products) is interleaved, element by element, with the next tile's products.  With the
-    // layer-at-a-time order the two waves of a SIMD ran in lock-step — both in the products, then both in
-    // tanh — and the two pipes took turns: 112 k cycles per launch, of which the products are 78 k.
-    Hidden a;
-    bias_init(a, nb + kOffB1, h);
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int s = 0; s < 12; ++s) {
-            a.t[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(nb[kOffW1 + (m * 12 + s) * 64 + lane], x[s], a.t[m], 0, 0, 0);
-            if (m > 0) {                // 16 elements of the previous tile over 12 products
-                a.t[m - 1][s] = fast_tanh(a.t[m - 1][s]);
-                if (s + 12 < 16) a.t[m - 1][s + 12] = fast_tanh(a.t[m - 1][s + 12]);
-            }
-        }
-    Hidden c;
-    bias_init(c, nb + kOffB2, h);
-    {
-        // 64 steps of four products (tile m, k-slice kt, quarter r4); the weight fragment of step t + 1 is requested
-        // before the products of step t, so its LDS latency is never waited for
-        f32x4 wc = *reinterpret_cast<const f32x4*>(nb + kOffW2 + lane * 4), wn = wc;
-#pragma unroll
-        for (int t = 0; t < 64; ++t) {
-            const int m = t >> 4, kt = (t >> 2) & 3, r4 = t & 3;
-            if (t < 63) wn = *reinterpret_cast<const f32x4*>(nb + kOffW2 + (((t + 1) * 64 + lane) * 4));
-            __builtin_amdgcn_sched_barrier(0);          // (left alone, the scheduler sinks the request next to its use)
-            if (m == 0 && kt == 3) {        // the last layer-1 tile is first needed here: its tanh rides in tile 0's products
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) a.t[3][4 * r4 + rr] = fast_tanh(a.t[3][4 * r4 + rr]);
-            }
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-                c.t[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[rr], a.t[kt][4 * r4 + rr], c.t[m], 0, 0, 0);
-            if (m > 0) {                    // one element of the previous tile per step: tanh + its head terms
-                const int e = kt * 4 + r4;
-                const float v = fast_tanh(c.t[m - 1][e]);
-                c.t[m - 1][e] = v;
-                if constexpr (NET == 0) {
-                    const f32x4 hw = *reinterpret_cast<const f32x4*>(hb + (((h * 4 + (m - 1)) * 16 + e) * 4));
-                    head[0] += hw.x * v; head[1] += hw.y * v; head[2] += hw.z * v; head[3] += hw.w * v;
-                } else {
-                    head[4] += hb[512 + (h * 4 + (m - 1)) * 16 + e] * v;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            wc = wn;
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {          // the last tile has nothing to hide behind
-        const float v = fast_tanh(c.t[3][e]);
-        if constexpr (NET == 0) {
-            const f32x4 hw = *reinterpret_cast<const f32x4*>(hb + (((h * 4 + 3) * 16 + e) * 4));
-            head[0] += hw.x * v; head[1] += hw.y * v; head[2] += hw.z * v; head[3] += hw.w * v;
-        } else {
-            head[4] += hb[512 + (h * 4 + 3) * 16 + e] * v;
-        }
-    }
-}
-
 // THREADS = 512: two waves per SIMD (the stand-alone shape).  THREADS = 256: one wave per SIMD and <= 256 VGPRs of
 // the 512-entry file, which leaves room for the VALU-bound env-step waves to co-reside: the critic pass is run that
 // way on a second stream beside fpv_step (matrix pipe and vector pipe are separate on CDNA4).
@@ -294,7 +227,6 @@ __global__ __launch_bounds__(THREADS) void policy_forward_kernel(PolicyArgs p, i
         for (int sl = 0; sl < net_count; ++sl) {
             const int net = net_first + sl;
             const float* nb = lds + sl * kNetFloats;
-#ifdef FPV_POLICY_LOCKSTEP
             // ---- layer 1: 20 (padded 24) -> 128
             Hidden a;
             bias_init(a, nb + kOffB1, h);
@@ -338,11 +270,7 @@ __global__ __launch_bounds__(THREADS) void policy_forward_kernel(PolicyArgs p, i
 #pragma unroll
                     for (int r = 0; r < 16; ++r) head[4] += hb[512 + (h * 4 + kt) * 16 + r] * c.t[kt][r];
             }
-#else
-            if (net == 0) policy_net<0>(nb, hb, lane, h, x, head);
-            else policy_net<1>(nb, hb, lane, h, x, head);
         }
-#endif
         // ---- combine the two lane halves, add biases
 #pragma unroll
         for (int j = 0; j < 5; ++j) head[j] = half_sum(head[j]);
