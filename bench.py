@@ -250,6 +250,8 @@ def main() -> None:
                             "traffic": traffic_of("fpv::policy_forward_kernel"), "us_per_launch": round(us_pol, 2),
                             "launches": L, "algorithmic_flop_per_launch": POLICY_FLOP_PER_ROW * n, "dtype": "f32",
                             "measured": how, "us_per_launch_hip_events_back_to_back": round(ev_pol, 2)}
+                roofline["note"] = ("peak is the nominal dense fp32 MFMA rate; on operands with real mantissas the instruction "
+                                    "itself sustains 115-127 TFLOP/s on this chip (tools/mfma_peak, profiles/r01_mfma_ceiling.txt)")
                 if in_graph and us_pol_all:
                     # rocprofv3 --stats averages over ALL launches of the symbol: per rollout of n_steps that is n_steps
                     # full launches plus the tail's V-only launch and the short done-ledger launch
