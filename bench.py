@@ -66,8 +66,8 @@ def cpu_baseline(n: int, seed: int, budget_s: float = 12.0):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256)
-    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=1024)
+    ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--drones", type=int, default=65536, help="drones per GPU (BASELINE.json configs[2])")
     ap.add_argument("--n-steps", type=int, default=32, help="rollout length between GAE passes")
     ap.add_argument("--no-graph", action="store_true")
