@@ -421,9 +421,6 @@ class RolloutCollector:
             mean, var = rms[:, :self.O], rms[:, self.O:2 * self.O]
             tobs = torch.clamp((tobs.double() - mean) / torch.sqrt(var + self.obs_norm.eps), -self.obs_norm.clip,
                                self.obs_norm.clip).float()
-        if self.fused_policy:
-            v = self.fp.forward(tobs.contiguous(), deterministic=True)["value"]
-        else:
-            with torch.no_grad():
-                v = self.policy.value(tobs)
+        with torch.no_grad():
+            v = self.policy.value(tobs)
         self.buf_rew.index_put_((t_idx, d_idx), self.gamma * v, accumulate=True)
