@@ -268,3 +268,33 @@ def test_in_launch_statistics_merge_equals_the_merge_kernel(T, norm):
         assert torch.allclose(a[k], b[k], rtol=1e-6, atol=1e-9), k
     for k in ("obs", "rew", "adv"):
         assert torch.allclose(a[k], b[k], rtol=1e-3, atol=2e-3), k
+
+
+@pytest.mark.parametrize("n", [100, 4160, 70000])
+def test_collector_at_ragged_sizes(n):
+    """Drone counts that exercise the other dispatch branches of the rollout step: 100 (wave-pair kernel, one partial
+    row per tile, ragged last tile), 4 160 = 65 tiles (not a multiple of four: one tile per workgroup), 70 000 = 1 094
+    tiles (more than the in-launch merge takes: stand-alone merge kernel).  Both statistics paths must agree."""
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    from fpv_drone_rl_agent_amd.rollout import RolloutCollector
+    outs = []
+    for mip in (True, False):
+        torch.manual_seed(4)
+        pol = ActorCritic(log_std_init=-1.0).cuda()
+        eng = FpvEngine(n, 0, seed=2, ledger_capacity=8 * n)
+        col = RolloutCollector(eng, pol, n_steps=6, merge_in_policy=mip)
+        assert col._merge_in_policy == (mip and n <= 65536)
+        col.collect()
+        b = col.collect()
+        torch.cuda.synchronize()
+        assert torch.isfinite(b["advantages"]).all() and torch.isfinite(b["adv_std"])
+        outs.append({"obs_rms": col.obs_norm.rms.clone(), "ret_rms": col.rew_norm.rms.clone(), "rew": col.buf_rew.clone(),
+                     "episodes": col.episodes["count"], "rows": col.partials.shape[0]})
+        eng.close()
+    a, b = outs
+    tiles = (n + 63) // 64
+    assert a["rows"] == (tiles if (n <= 32768 or tiles % 4) else tiles // 4)
+    assert a["episodes"] == b["episodes"]
+    assert torch.allclose(a["obs_rms"], b["obs_rms"], rtol=1e-6, atol=1e-9) and torch.allclose(a["ret_rms"], b["ret_rms"], rtol=1e-6, atol=1e-9)
+    assert torch.allclose(a["rew"], b["rew"], rtol=1e-3, atol=2e-3)
