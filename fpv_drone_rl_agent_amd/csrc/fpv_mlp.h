@@ -1,0 +1,47 @@
+// fpv_mlp.h — pieces shared by the MFMA kernels of the actor-critic (fpv_policy.hip, fpv_policy_split.hip, fpv_ppo.hip):
+// accumulator-tile bookkeeping of v_mfma_f32_32x32x2_f32 in the transposed formulation (H^T = W . X^T), tanh, Philox.
+#pragma once
+#include "fpv_dynamics.h"   // philox4x32_10
+#include "fpv_internal.h"
+
+namespace fpv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Row of a 32 x 32 accumulator tile held by register r of a lane in half h (lane >> 5): rows come in quads, so
+// four consecutive registers are four consecutive rows and a register quad is one 16-byte store.
+__host__ __device__ constexpr int tile_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// one hidden layer's 64 values per lane: 4 accumulator tiles
+struct Hidden {
+    f32x16 t[4];
+};
+
+__device__ __forceinline__ float fast_tanh(float x) {
+    // 1 - 2 / (1 + e^{2x}); v_exp_f32 is 2^x.  |error| < 3e-7 absolute.
+    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// bias image [m][h][16] -> accumulator tiles
+__device__ __forceinline__ void bias_init(Hidden& a, const float* __restrict__ lb, int h) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const f32x4* b = reinterpret_cast<const f32x4*>(lb + (m * 2 + h) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = b[q];
+            a.t[m][4 * q] = v.x; a.t[m][4 * q + 1] = v.y; a.t[m][4 * q + 2] = v.z; a.t[m][4 * q + 3] = v.w;
+        }
+    }
+}
+
+__device__ __forceinline__ void tanh_all(Hidden& a) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a.t[m][r] = fast_tanh(a.t[m][r]);
+}
+
+}  // namespace fpv

@@ -11,12 +11,9 @@
 // B operand as it stands — no LDS round trip, no lane movement between layers.  The K order that
 // this induces is baked into the weight image by pack_kernel.  A 512-thread workgroup keeps the
 // whole 160 KB weight image in LDS and walks over 256-drone chunks (32 drones per wave).
-#include "fpv_internal.h"
+#include "fpv_mlp.h"
 
 namespace fpv {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kHid = 128, kIn = 20, kInPad = 24, kAct = 4;
 constexpr int kNetFloats = 4 * 12 * 64 + 128 + 4 * 4 * 4 * 64 * 4 + 128;  // 19712
@@ -26,8 +23,6 @@ constexpr int kOffWa = kHeadBase, kOffWv = kHeadBase + 512, kOffBa = kHeadBase +
               kOffLogStd = kHeadBase + 648, kOffStd = kHeadBase + 652, kOffLogpConst = kHeadBase + 656;
 constexpr int kImageFloats = kHeadBase + 660;                               // packed image
 // LDS: the staged nets, then the 660 head floats, then the normaliser mean[20] / inv_std[20] (160 496 B for both nets)
-
-__host__ __device__ constexpr int tile_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // ---------------------------------------------------------------- weight image
 // nn.Linear layouts: w1 [128][20], w2 [128][128], wa [4][128], wv [1][128] (row = output).
@@ -80,25 +75,6 @@ __global__ void policy_pack_kernel(PolicyParams p, float* __restrict__ img) {
     img[e] = v;
 }
 
-// ---------------------------------------------------------------- device helpers
-__device__ __forceinline__ float fast_tanh(float x) {
-    // 1 - 2 / (1 + e^{2x}); v_exp_f32 is 2^x.  |error| < 3e-7 absolute.
-    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
-}
-
-__device__ __forceinline__ void philox_pol(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
-                                           uint32_t (&out)[4]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
 struct PolicyArgs {
     const float* image;      // packed weights (kImageFloats)
     const float* obs;        // [n][20] raw observations
@@ -119,30 +95,6 @@ struct PolicyArgs {
     MergeArgs mg;            // mg.rows != null: fold the previous env step's tile sums into rms first (512 threads)
     const int32_t* n_dev;    // optional device-side row count: rows = min(n, *n_dev)
 };
-
-// one hidden layer's 64 values per lane: 4 accumulator tiles
-struct Hidden {
-    f32x16 t[4];
-};
-
-__device__ __forceinline__ void bias_init(Hidden& a, const float* __restrict__ lb, int h) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const f32x4* b = reinterpret_cast<const f32x4*>(lb + (m * 2 + h) * 16);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = b[q];
-            a.t[m][4 * q] = v.x; a.t[m][4 * q + 1] = v.y; a.t[m][4 * q + 2] = v.z; a.t[m][4 * q + 3] = v.w;
-        }
-    }
-}
-
-__device__ __forceinline__ void tanh_all(Hidden& a) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a.t[m][r] = fast_tanh(a.t[m][r]);
-}
 
 // THREADS = 512: two waves per SIMD (the stand-alone shape).  THREADS = 256: one wave per SIMD and <= 256 VGPRs of
 // the 512-entry file, which leaves room for the VALU-bound env-step waves to co-reside: the critic pass is run that
@@ -291,7 +243,7 @@ __global__ __launch_bounds__(THREADS) void policy_forward_kernel(PolicyArgs p, i
             } else {
                 const uint64_t t = p.tick ? p.tick[0] : 0ull;
                 uint32_t xr[4];
-                philox_pol((uint32_t)(p.id_offset + (uint64_t)d), (uint32_t)t, (uint32_t)(t >> 32), 0x504F4C31u,
+                philox4x32_10((uint32_t)(p.id_offset + (uint64_t)d), (uint32_t)t, (uint32_t)(t >> 32), 0x504F4C31u,
                            (uint32_t)p.seed, (uint32_t)(p.seed >> 32), xr);
                 constexpr float k24 = 5.9604644775390625e-8f, m2ln2 = -1.3862943611198906f;
                 const float u0 = ((float)(xr[0] >> 8) + 0.5f) * k24, u1 = ((float)(xr[1] >> 8) + 0.5f) * k24;

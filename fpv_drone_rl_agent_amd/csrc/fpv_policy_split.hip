@@ -10,12 +10,10 @@
 // kernel (accumulator tile -> next layer's B fragment; k order baked into the weight image).  The split weight
 // image of one net is 121 KB, so the workgroup makes two passes over its drones: pi (and the sampling epilogue)
 // with the pi image resident, then V with the V image.
-#include "fpv_internal.h"
+#include "fpv_mlp.h"
 
 namespace fpv {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kIn = 20;
@@ -91,10 +89,6 @@ __global__ void policy_split_pack_kernel(SplitParams p, unsigned char* __restric
     reinterpret_cast<float*>(img + 2 * (size_t)kNetBytes)[q] = v;
 }
 
-__device__ __forceinline__ float fast_tanh_s(float x) {
-    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
-}
 
 // three bf16 fragments of eight fp32 values
 __device__ __forceinline__ void split8(const float (&v)[8], bf16x8& p1, bf16x8& p2, bf16x8& p3) {
@@ -134,18 +128,6 @@ struct SplitArgs {
     int32_t deterministic;
     MergeArgs mg;
 };
-
-__device__ __forceinline__ void philox_split(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
-                                             uint32_t (&out)[4]) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
 
 __global__ __launch_bounds__(kSplitThreads) void policy_split_forward_kernel(SplitArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -236,7 +218,7 @@ __global__ __launch_bounds__(kSplitThreads) void policy_split_forward_kernel(Spl
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) a[m][r] = fast_tanh_s(a[m][r]);
+                for (int r = 0; r < 16; ++r) a[m][r] = fast_tanh(a[m][r]);
             // ---- layer 2: accumulator tiles of layer 1 are the B operands (registers 8 s .. 8 s + 7 per k-step)
             f32x16 c[4];
 #pragma unroll
@@ -260,7 +242,7 @@ __global__ __launch_bounds__(kSplitThreads) void policy_split_forward_kernel(Spl
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) c[m][r] = fast_tanh_s(c[m][r]);
+                for (int r = 0; r < 16; ++r) c[m][r] = fast_tanh(c[m][r]);
 
             // The two lane halves are combined with half_sum() (v_permlane32_swap, VALU only).  The first version went
             // through __shfl_xor -> ds_bpermute_b32 and about 1 row in 3 000 came out with a wrong FIRST head component:
@@ -289,7 +271,7 @@ __global__ __launch_bounds__(kSplitThreads) void policy_split_forward_kernel(Spl
                     } else {
                         const uint64_t t = p.tick ? p.tick[0] : 0ull;
                         uint32_t xr[4];
-                        philox_split((uint32_t)(p.id_offset + (uint64_t)d), (uint32_t)t, (uint32_t)(t >> 32), 0x504F4C31u,
+                        philox4x32_10((uint32_t)(p.id_offset + (uint64_t)d), (uint32_t)t, (uint32_t)(t >> 32), 0x504F4C31u,
                                      (uint32_t)p.seed, (uint32_t)(p.seed >> 32), xr);
                         constexpr float k24 = 5.9604644775390625e-8f, m2ln2 = -1.3862943611198906f;
                         const float u0 = ((float)(xr[0] >> 8) + 0.5f) * k24, u1 = ((float)(xr[1] >> 8) + 0.5f) * k24;

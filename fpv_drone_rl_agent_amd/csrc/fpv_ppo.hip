@@ -11,16 +11,13 @@
 //                          every workgroup reduces a slab of rows, slabs are summed in fixed order by
 //   U3 ppo_reduce_kernel   -> the 13 gradient tensors + {pg loss, value loss, approx KL, clip fraction}.
 // fp32 throughout (v_mfma_f32_32x32x2_f32); no atomics: the result is bitwise reproducible for a given launch shape.
-#include "fpv_internal.h"
+#include "fpv_mlp.h"
 
 #ifndef FPV_PPO_THREADS
 #define FPV_PPO_THREADS 256
 #endif
 
 namespace fpv {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -36,36 +33,6 @@ constexpr int kTImage = kTHead + kHeadFloats;
 constexpr int kPW1 = 0, kPB1 = 3072, kPW2 = 3200, kPB2 = 19584, kPWh = 19712, kPBh = 20224, kPartStride = 20232;
 constexpr int kFwdBwdThreads = FPV_PPO_THREADS;          // U1 workgroup: 256 = one wave per SIMD (512 measured slower: 175 vs 133 us)
 constexpr int kWaveStats = 8;                           // pg, vl, kl, clip fraction, d log_std[4]
-
-__host__ __device__ constexpr int tile_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-struct Hidden {
-    f32x16 t[4];
-};
-
-__device__ __forceinline__ float fast_tanh(float x) {
-    const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);
-    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
-}
-
-__device__ __forceinline__ void bias_init(Hidden& a, const float* __restrict__ lb, int h) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const f32x4* b = reinterpret_cast<const f32x4*>(lb + (m * 2 + h) * 16);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = b[q];
-            a.t[m][4 * q] = v.x; a.t[m][4 * q + 1] = v.y; a.t[m][4 * q + 2] = v.z; a.t[m][4 * q + 3] = v.w;
-        }
-    }
-}
-
-__device__ __forceinline__ void tanh_all(Hidden& a) {
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) a.t[m][r] = fast_tanh(a.t[m][r]);
-}
 
 // lane (col, h) holds rows tile_row(r, h) of each 32-row tile: four consecutive rows per register quad -> 16-byte stores
 __device__ __forceinline__ void store_rows(float* __restrict__ mat, int64_t n, const Hidden& t, int h) {
