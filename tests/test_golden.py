@@ -71,3 +71,33 @@ def test_hip_fp64_matches_golden_trajectory():
         assert np.allclose(r.cpu().numpy(), G["b_reward"][t], rtol=1e-9, atol=1e-9), t
     assert np.allclose(eng.get_state().cpu().numpy(), G["b_state_out"], rtol=1e-9, atol=1e-9)
     eng.close()
+
+
+def test_ppo_golden_vector_is_reproduced_by_the_cpu_definition():
+    """tests/golden/ppo_grad_v1.npz against policy.ActorCritic + the SB3 loss evaluated here on the CPU in float64:
+    the fixture pins the loss definition the HIP update kernels are tested against (tests/test_ppo_grad_gpu.py)."""
+    import os
+    import numpy as np
+    import torch
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ppo_grad_v1.npz"))
+    m = ActorCritic().double()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            p.copy_(torch.from_numpy(g["param/" + n]))
+    obs, act, old_lp, adv, ret = (torch.from_numpy(g[k]) for k in ("obs", "act", "old_lp", "adv", "ret"))
+    clip, vf, ent = float(g["clip"]), float(g["vf"]), float(g["ent"])
+    v, lp, en = m.evaluate(obs, act)
+    ratio = torch.exp(lp - old_lp)
+    pg = -torch.min(adv * ratio, adv * torch.clamp(ratio, 1 - clip, 1 + clip)).mean()
+    (pg + vf * torch.nn.functional.mse_loss(v, ret) - ent * en.mean()).backward()
+    for n, p in m.named_parameters():
+        assert np.allclose(p.grad.numpy(), g["grad/" + n], rtol=1e-10, atol=1e-14), n
+    # the hand-derived derivative the kernels implement: d loss / d log pi = -adv * ratio / rows where the unclipped
+    # branch is the minimum, d log pi / d mu = z / sigma
+    with torch.no_grad():
+        mean, _ = m.mean_value(obs)
+        z = (act - mean) * torch.exp(-m.log_std)
+        w = (adv * ratio <= adv * torch.clamp(ratio, 1 - clip, 1 + clip)).double()
+        dmu = (-adv * ratio * w / obs.shape[0]).unsqueeze(1) * z * torch.exp(-m.log_std)
+        assert np.allclose(dmu.sum(0).numpy(), g["grad/action_net.bias"], rtol=1e-9, atol=1e-14)

@@ -128,3 +128,28 @@ def test_fused_adam_matches_torch_adam_with_clip(max_norm):
     opt2 = FusedAdam(torch.nn.Parameter(b.data.clone()), lr=1.0)
     opt2.load_state_dict(sd)
     assert opt2.lr == 3e-4 and int(opt2.state[0]["step"]) == 25
+
+
+def test_ppo_grad_matches_the_committed_float64_golden_vector():
+    """tests/golden/ppo_grad_v1.npz: the same loss differentiated by torch autograd on the CPU in float64
+    (tests/golden/make_golden_ppo.py).  fp32 MFMA sums over 517 rows against float64: 1e-4 of each tensor's max-norm."""
+    import os
+    import numpy as np
+    from fpv_drone_rl_agent_amd.ops_policy import FusedPolicy
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ppo_grad_v1.npz"))
+    dev = torch.device("cuda:0")
+    m = ActorCritic().to(dev)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            p.copy_(torch.from_numpy(g["param/" + n]).float())
+    t = lambda k: torch.from_numpy(g[k]).float().to(dev).contiguous()
+    fp = FusedPolicy(m)
+    stats = fp.ppo_grad(t("obs"), t("act"), t("old_lp"), t("adv"), t("ret"), clip_range=float(g["clip"]),
+                        vf_coef=float(g["vf"]), ent_coef=float(g["ent"]))
+    torch.cuda.synchronize()
+    for n, p in m.named_parameters():
+        want = g["grad/" + n]
+        err = np.abs(p.grad.double().cpu().numpy() - want).max()
+        assert err <= 1e-4 * np.abs(want).max() + 1e-10, (n, err, np.abs(want).max())
+    assert np.allclose(stats.double().cpu().numpy(), g["stats"], rtol=1e-4, atol=1e-6)
