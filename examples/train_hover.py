@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--ent-coef", type=float, default=0.0)
     ap.add_argument("--gamma", type=float, default=0.99)
     ap.add_argument("--log-std-min", type=float, default=-3.5, help="floor under the policy log-std (sigma >= 0.03)")
+    ap.add_argument("--save", default=None, help="path stem: writes <stem>.zip (model) and <stem>.pkl (VecNormalize statistics), "
+                                                 "as train_hover.py:62-63 does")
     ap.add_argument("--autograd-update", action="store_true",
                     help="minibatch gradient through torch autograd instead of the fpv_ppo_grad kernels")
     args = ap.parse_args()
@@ -51,6 +53,11 @@ def main():
     model.learn(int(args.timesteps), log_every=args.log_every)
     if rank == 0:
         print({"wall_s": round(time.time() - t0, 1), "timesteps": model.num_timesteps, **model.logger})
+        if args.save:
+            from fpv_drone_rl_agent_amd.checkpoint import save_model, save_normalizer
+            save_model(args.save, model)
+            save_normalizer(args.save + ".pkl", col)
+            print("saved", args.save + ".zip", args.save + ".pkl")
 
 
 if __name__ == "__main__":
