@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--log-std-min", type=float, default=-3.5, help="floor under the policy log-std (sigma >= 0.03)")
     ap.add_argument("--save", default=None, help="path stem: writes <stem>.zip (model) and <stem>.pkl (VecNormalize statistics), "
                                                  "as train_hover.py:62-63 does")
+    ap.add_argument("--grad-storage", choices=["f32", "bf16"], default="f32",
+                    help="how the update kernels pass activations through memory: bf16 halves that traffic")
     ap.add_argument("--autograd-update", action="store_true",
                     help="minibatch gradient through torch autograd instead of the fpv_ppo_grad kernels")
     args = ap.parse_args()
@@ -48,7 +50,8 @@ def main():
                     domain_rand=args.task == "yaw", ledger_capacity=args.drones * max(2, args.n_steps // 8))
     col = RolloutCollector(eng, policy, n_steps=args.n_steps, policy_seed=args.seed, gamma=args.gamma)
     model = PPO(col, learning_rate=args.lr, n_epochs=args.epochs, n_minibatches=args.minibatches, ent_coef=args.ent_coef,
-                target_kl=args.target_kl, fused_update=not args.autograd_update, log_std_min=args.log_std_min)
+                target_kl=args.target_kl, fused_update=not args.autograd_update, log_std_min=args.log_std_min,
+                grad_storage=args.grad_storage)
     t0 = time.time()
     model.learn(int(args.timesteps), log_every=args.log_every)
     if rank == 0:

@@ -536,13 +536,14 @@ int fpv_ppo_grad(fpv_policy* p, const fpv_ppo_io* io, void* stream) {
     const uintptr_t act_rows = p->act_dim == 4 ? (uintptr_t)io->actions : 0;
     if (((uintptr_t)io->obs | act_rows | (uintptr_t)io->workspace) & 15)
         return fail(FPV_ERR_ARG, "fpv_ppo_grad: row buffers and workspace must be 16-byte aligned");
+    if (io->storage != 0 && io->storage != 1) return fail(FPV_ERR_ARG, "fpv_ppo_grad: storage must be 0 (fp32) or 1 (bf16)");
     const int64_t need = ppo_workspace_floats(io->rows, p->cus) * (int64_t)sizeof(float);
     if (io->workspace_bytes < need)
         return fail(FPV_ERR_ARG, "fpv_ppo_grad: workspace of %lld bytes, %lld needed (fpv_ppo_workspace_bytes)",
                     (long long)io->workspace_bytes, (long long)need);
     FPV_HIP(launch_ppo_grad(io->weights, io->grads, io->index, io->obs, io->actions, io->old_logp, io->advantages, io->returns,
                             io->rows, io->clip_range, io->vf_coef, io->ent_coef, io->stats, (float*)io->workspace, p->in_dim,
-                            p->act_dim, p->cus, (hipStream_t)stream));
+                            p->act_dim, p->cus, io->storage, (hipStream_t)stream));
     return FPV_OK;
 }
 

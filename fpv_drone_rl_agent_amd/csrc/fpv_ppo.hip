@@ -34,20 +34,36 @@ constexpr int kPW1 = 0, kPB1 = 3072, kPW2 = 3200, kPB2 = 19584, kPWh = 19712, kP
 constexpr int kFwdBwdThreads = FPV_PPO_THREADS;          // U1 workgroup: 256 = one wave per SIMD (512 measured slower: 175 vs 133 us)
 constexpr int kWaveStats = 8;                           // pg, vl, kl, clip fraction, d log_std[4]
 
-// lane (col, h) holds rows tile_row(r, h) of each 32-row tile: four consecutive rows per register quad -> 16-byte stores
-__device__ __forceinline__ void store_rows(float* __restrict__ mat, int64_t n, const Hidden& t, int h) {
-    f32x4* row = reinterpret_cast<f32x4*>(mat + n * kHid);
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            row[m * 8 + 2 * q + h] = f32x4{t.t[m][4 * q], t.t[m][4 * q + 1], t.t[m][4 * q + 2], t.t[m][4 * q + 3]};
+// Storage type of the activation / delta matrices that U1 hands to U2 through memory: float (default, exact) or bf16
+// (`fpv_ppo_io.storage = 1`).  The matrices are 4 KB per row in fp32 — U1 writes and U2 reads 268 MB per 65 536-row
+// minibatch, which costs both kernels about as much time as their matrix products — and half that in bf16; the products
+// stay fp32 MFMA on the rounded values (relative rounding 2^-9 per stored value, zero-mean over the rows of a sum).
+typedef unsigned short bf16_bits;
+__device__ __forceinline__ float from_store(float v) { return v; }
+__device__ __forceinline__ float from_store(bf16_bits v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ __forceinline__ bf16_bits to_bf16(float v) {     // round to nearest even
+    const uint32_t u = __float_as_uint(v);
+    return (bf16_bits)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
 
+// lane (col, h) holds rows tile_row(r, h) of each 32-row tile: four consecutive rows per register quad -> one 16-byte
+// (fp32) or 8-byte (bf16) store
 __device__ __forceinline__ void store_tile(float* __restrict__ mat, int64_t n, const f32x16& t, int m, int h) {
     f32x4* row = reinterpret_cast<f32x4*>(mat + n * kHid);
 #pragma unroll
     for (int q = 0; q < 4; ++q) row[m * 8 + 2 * q + h] = f32x4{t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
+}
+__device__ __forceinline__ void store_tile(bf16_bits* __restrict__ mat, int64_t n, const f32x16& t, int m, int h) {
+    uint2* row = reinterpret_cast<uint2*>(mat + n * kHid);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        row[m * 8 + 2 * q + h] = uint2{(uint32_t)to_bf16(t[4 * q]) | ((uint32_t)to_bf16(t[4 * q + 1]) << 16),
+                                       (uint32_t)to_bf16(t[4 * q + 2]) | ((uint32_t)to_bf16(t[4 * q + 3]) << 16)};
+}
+template <typename ST>
+__device__ __forceinline__ void store_rows(ST* __restrict__ mat, int64_t n, const Hidden& t, int h) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) store_tile(mat, n, t.t[m], m, h);
 }
 
 __device__ __forceinline__ void load_tile(const float* __restrict__ mat, int64_t n, f32x16& t, int m, int h) {
@@ -58,16 +74,14 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ mat, int64_t
         t[4 * q] = v.x; t[4 * q + 1] = v.y; t[4 * q + 2] = v.z; t[4 * q + 3] = v.w;
     }
 }
-
-__device__ __forceinline__ void load_rows(const float* __restrict__ mat, int64_t n, Hidden& t, int h) {
-    const f32x4* row = reinterpret_cast<const f32x4*>(mat + n * kHid);
+__device__ __forceinline__ void load_tile(const bf16_bits* __restrict__ mat, int64_t n, f32x16& t, int m, int h) {
+    const uint2* row = reinterpret_cast<const uint2*>(mat + n * kHid);
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = row[m * 8 + 2 * q + h];
-            t.t[m][4 * q] = v.x; t.t[m][4 * q + 1] = v.y; t.t[m][4 * q + 2] = v.z; t.t[m][4 * q + 3] = v.w;
-        }
+    for (int q = 0; q < 4; ++q) {
+        const uint2 v = row[m * 8 + 2 * q + h];
+        t[4 * q] = __uint_as_float(v.x << 16); t[4 * q + 1] = __uint_as_float(v.x & 0xFFFF0000u);
+        t[4 * q + 2] = __uint_as_float(v.y << 16); t[4 * q + 3] = __uint_as_float(v.y & 0xFFFF0000u);
+    }
 }
 
 }  // namespace
@@ -138,7 +152,7 @@ struct PpoArgs {
     const float* old_logp;    // [*]
     const float* adv;         // [*]
     const float* ret;         // [*]
-    float* mats;              // [2][4][rows][128]: H1, H2, D1, D2 per net
+    void* mats;               // [2][4][rows][128] of ST: H1, H2, D1, D2 per net
     float* xg;                // [rows][in_dim] gathered observations (U2's operand for dW1)
     float* dmu;               // [rows][4]
     float* dv;                // [rows]
@@ -148,7 +162,7 @@ struct PpoArgs {
     int32_t in_dim, act_dim;
 };
 
-template <int THREADS>
+template <int THREADS, typename ST>
 __global__ __launch_bounds__(THREADS) void ppo_fwd_bwd_kernel(PpoArgs p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* hb = lds + kTNet;
@@ -183,10 +197,11 @@ __global__ __launch_bounds__(THREADS) void ppo_fwd_bwd_kernel(PpoArgs p) {
                     reinterpret_cast<f32x4*>(hb)[g] = reinterpret_cast<const f32x4*>(p.image + kTHead)[g];
         }
         __syncthreads();
-        float* H1 = p.mats + (size_t)(net * 4 + 0) * p.rows * kHid;
-        float* H2 = p.mats + (size_t)(net * 4 + 1) * p.rows * kHid;
-        float* D1 = p.mats + (size_t)(net * 4 + 2) * p.rows * kHid;
-        float* D2 = p.mats + (size_t)(net * 4 + 3) * p.rows * kHid;
+        ST* const mats = static_cast<ST*>(p.mats);
+        ST* H1 = mats + (size_t)(net * 4 + 0) * p.rows * kHid;
+        ST* H2 = mats + (size_t)(net * 4 + 1) * p.rows * kHid;
+        ST* D1 = mats + (size_t)(net * 4 + 2) * p.rows * kHid;
+        ST* D2 = mats + (size_t)(net * 4 + 3) * p.rows * kHid;
 
 #pragma unroll 1
         for (int64_t base = (int64_t)blockIdx.x * kChunk; base < p.rows; base += (int64_t)gridDim.x * kChunk) {
@@ -401,7 +416,7 @@ __global__ __launch_bounds__(THREADS) void ppo_fwd_bwd_kernel(PpoArgs p) {
 
 // ---------------------------------------------------------------- U2: weight gradients, K = rows
 struct WgradArgs {
-    const float* mats;        // [2][4][rows][128]
+    const void* mats;         // [2][4][rows][128] of ST
     const float* xg;          // [rows][in_dim]
     const float* dmu;         // [rows][4]
     const float* dv;          // [rows]
@@ -411,8 +426,10 @@ struct WgradArgs {
 };
 
 namespace {
-struct Ops {
-    float a2, a1, ah, x, hh, b[4];
+template <typename ST>
+struct Ops {                  // one k-step's operands as they come from memory (converted only when they are multiplied)
+    ST a2, a1, hh, b[4];
+    float ah, x;
 };
 }  // namespace
 
@@ -422,6 +439,7 @@ struct Ops {
 // blockIdx.y = net, blockIdx.x = slab of rows.
 constexpr int kWgradXchFloats = 4 * 99 * 64;
 
+template <typename ST>
 __global__ __launch_bounds__(512) void ppo_wgrad_kernel(WgradArgs p) {
     extern __shared__ __attribute__((aligned(16))) float xch[];     // [4 waves][99][64 lanes]
     const int net = blockIdx.y, slab = blockIdx.x;
@@ -432,10 +450,11 @@ __global__ __launch_bounds__(512) void ppo_wgrad_kernel(WgradArgs p) {
     const int64_t n1 = n0 + p.rows_per_slab < p.rows ? n0 + p.rows_per_slab : p.rows;
     const int len = (int)(n1 - n0);
     // lane-fixed column offsets; rows are 32-bit offsets from the slab's first row
-    const float* H1 = p.mats + ((size_t)(net * 4 + 0) * p.rows + n0) * kHid + i;
-    const float* H2 = p.mats + ((size_t)(net * 4 + 1) * p.rows + n0) * kHid + 32 * w + i;
-    const float* D1 = p.mats + ((size_t)(net * 4 + 2) * p.rows + n0) * kHid + 32 * w + i;
-    const float* D2 = p.mats + ((size_t)(net * 4 + 3) * p.rows + n0) * kHid + 32 * w + i;
+    const ST* const mats = static_cast<const ST*>(p.mats);
+    const ST* H1 = mats + ((size_t)(net * 4 + 0) * p.rows + n0) * kHid + i;
+    const ST* H2 = mats + ((size_t)(net * 4 + 1) * p.rows + n0) * kHid + 32 * w + i;
+    const ST* D1 = mats + ((size_t)(net * 4 + 2) * p.rows + n0) * kHid + 32 * w + i;
+    const ST* D2 = mats + ((size_t)(net * 4 + 3) * p.rows + n0) * kHid + 32 * w + i;
     const float* XG = p.xg + n0 * p.in_dim + (i < p.in_dim ? i : p.in_dim - 1);
     const float* AH = net == 0 ? p.dmu + n0 * 4 + (i < 4 ? i : 3) : p.dv + n0;
     const int ah_stride = net == 0 ? 4 : 1;
@@ -450,7 +469,7 @@ __global__ __launch_bounds__(512) void ppo_wgrad_kernel(WgradArgs p) {
 
     // one k-step = rows row0 + kk (slab-relative).  load() only requests; masking waits until fma(), so that a whole
     // group of requests is in flight before anything depends on one of them
-    auto load = [&](Ops& o, int row0) {
+    auto load = [&](Ops<ST>& o, int row0) {
         const int row = row0 + kk;
         const int r = row < len ? row : 0;
         o.a2 = D2[r * kHid]; o.a1 = D1[r * kHid]; o.ah = AH[r * ah_stride];
@@ -459,18 +478,19 @@ __global__ __launch_bounds__(512) void ppo_wgrad_kernel(WgradArgs p) {
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) o.b[jt] = H1[r * kHid + 32 * jt];
     };
-    auto fma = [&](const Ops& o, int row0) {
+    auto fma = [&](const Ops<ST>& o, int row0) {
         const bool ok = row0 + kk < len;
-        const float a2 = ok ? o.a2 : 0.f, a1 = ok ? o.a1 : 0.f, ah = (ok && ah_on) ? o.ah : 0.f, x = x_on ? o.x : 0.f;
+        const float a2 = ok ? from_store(o.a2) : 0.f, a1 = ok ? from_store(o.a1) : 0.f, ah = (ok && ah_on) ? o.ah : 0.f,
+                    x = x_on ? o.x : 0.f;
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) w2[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, o.b[jt], w2[jt], 0, 0, 0);
+        for (int jt = 0; jt < 4; ++jt) w2[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, from_store(o.b[jt]), w2[jt], 0, 0, 0);
         w1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, x, w1, 0, 0, 0);
-        hd = __builtin_amdgcn_mfma_f32_32x32x2f32(ah, o.hh, hd, 0, 0, 0);
+        hd = __builtin_amdgcn_mfma_f32_32x32x2f32(ah, from_store(o.hh), hd, 0, 0, 0);
         sb2 += a2; sb1 += a1; sbh += ah;
     };
 
     constexpr int U = 4;                        // k-steps (pairs of rows) per register group = 8 rows
-    Ops A[U], B[U];
+    Ops<ST> A[U], B[U];
     int g0 = 8 * set;                           // this set's groups: rows g0, g0 + 16, ...
 #pragma unroll
     for (int u = 0; u < U; ++u) load(A[u], g0 + 2 * u);
@@ -702,17 +722,18 @@ int64_t ppo_workspace_floats(int64_t rows, int cus) {
            2 * (int64_t)slabs * kPartStride + 64;
 }
 
-hipError_t launch_ppo_grad(const float* const* w, float* const* grads, const int64_t* index, const float* obs,
-                           const float* actions, const float* old_logp, const float* adv, const float* ret, int64_t rows,
-                           float clip_range, float vf_coef, float ent_coef, float* stats, float* ws, int in_dim, int act_dim,
-                           int cus, hipStream_t s) {
+template <typename ST>
+static hipError_t launch_ppo_grad_t(const float* const* w, float* const* grads, const int64_t* index, const float* obs,
+                                    const float* actions, const float* old_logp, const float* adv, const float* ret,
+                                    int64_t rows, float clip_range, float vf_coef, float ent_coef, float* stats, float* ws,
+                                    int in_dim, int act_dim, int cus, hipStream_t s) {
     static bool attr_set = false;
     constexpr size_t lds_bytes = (size_t)(kTNet + kHeadFloats) * sizeof(float);
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)ppo_fwd_bwd_kernel<kFwdBwdThreads>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds_bytes);
+        hipError_t e = hipFuncSetAttribute((const void*)ppo_fwd_bwd_kernel<kFwdBwdThreads, ST>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)ppo_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+            e = hipFuncSetAttribute((const void*)ppo_wgrad_kernel<ST>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(kWgradXchFloats * sizeof(float)));
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -720,7 +741,7 @@ hipError_t launch_ppo_grad(const float* const* w, float* const* grads, const int
     int rps;
     const int slabs = ppo_slabs(rows, &rps);
     const int blocks = ppo_blocks(rows, cus);
-    // workspace carve-up (floats; every piece 16-byte aligned)
+    // workspace carve-up (floats; every piece 16-byte aligned); the matrices take 8 rows x 128 floats, or half of that
     float* image = ws;
     float* mats = image + kTImage;
     float* xg = mats + 8 * rows * kHid;
@@ -733,13 +754,24 @@ hipError_t launch_ppo_grad(const float* const* w, float* const* grads, const int
     hipLaunchKernelGGL(ppo_pack_kernel, dim3((kTImage + 255) / 256), dim3(256), 0, s, pp, image);
     PpoArgs a{image, index, obs, actions, old_logp, adv, ret, mats, xg, dmu, dv, wave_stats,
               rows, clip_range, vf_coef, 1.0f / (float)rows, in_dim, act_dim};
-    hipLaunchKernelGGL(ppo_fwd_bwd_kernel<kFwdBwdThreads>, dim3(blocks), dim3(kFwdBwdThreads), lds_bytes, s, a);
+    hipLaunchKernelGGL((ppo_fwd_bwd_kernel<kFwdBwdThreads, ST>), dim3(blocks), dim3(kFwdBwdThreads), lds_bytes, s, a);
     WgradArgs g{mats, xg, dmu, dv, part, rows, rps, slabs, in_dim, act_dim};
-    hipLaunchKernelGGL(ppo_wgrad_kernel, dim3(slabs, 2), dim3(512), kWgradXchFloats * sizeof(float), s, g);
+    hipLaunchKernelGGL(ppo_wgrad_kernel<ST>, dim3(slabs, 2), dim3(512), kWgradXchFloats * sizeof(float), s, g);
     ReduceArgs r{part, wave_stats, {}, stats, slabs, blocks * (kFwdBwdThreads / 64), in_dim, act_dim, 1.0f / (float)rows, ent_coef};
     for (int k = 0; k < 13; ++k) r.g[k] = grads[k];
     hipLaunchKernelGGL(ppo_reduce_kernel, dim3((2 * kPartStride + 31) / 32 + 1), dim3(256), 0, s, r);
     return hipGetLastError();
+}
+
+hipError_t launch_ppo_grad(const float* const* w, float* const* grads, const int64_t* index, const float* obs,
+                           const float* actions, const float* old_logp, const float* adv, const float* ret, int64_t rows,
+                           float clip_range, float vf_coef, float ent_coef, float* stats, float* ws, int in_dim, int act_dim,
+                           int cus, int storage, hipStream_t s) {
+    if (storage == 1)
+        return launch_ppo_grad_t<bf16_bits>(w, grads, index, obs, actions, old_logp, adv, ret, rows, clip_range, vf_coef,
+                                            ent_coef, stats, ws, in_dim, act_dim, cus, s);
+    return launch_ppo_grad_t<float>(w, grads, index, obs, actions, old_logp, adv, ret, rows, clip_range, vf_coef, ent_coef,
+                                    stats, ws, in_dim, act_dim, cus, s);
 }
 
 }  // namespace fpv

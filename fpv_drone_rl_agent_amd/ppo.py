@@ -25,7 +25,8 @@ class PPO:
     def __init__(self, collector: RolloutCollector, learning_rate: float = 3e-4, n_epochs: int = 4,
                  n_minibatches: int = 8, clip_range: float = 0.2, ent_coef: float = 0.0, vf_coef: float = 0.5,
                  max_grad_norm: float = 0.5, normalize_advantage: bool = True, target_kl: float | None = None,
-                 use_graph: bool = True, fused_update: bool | None = None, log_std_min: float | None = None):
+                 use_graph: bool = True, fused_update: bool | None = None, log_std_min: float | None = None,
+                 grad_storage: str = "f32"):
         self.col = collector
         self.policy = collector.policy
         # capturable Adam: its step counter lives on the device, so one minibatch update (forward, loss, backward,
@@ -40,6 +41,9 @@ class PPO:
         if fused_update and fp is None:
             raise ValueError("fused_update needs a collector with the fused policy kernel (fused_policy=True)")
         self.fused_update = bool(fused_update)
+        if grad_storage not in ("f32", "bf16"):
+            raise ValueError("grad_storage must be 'f32' or 'bf16'")
+        self.grad_storage = grad_storage        # how fpv_ppo_grad passes activations between its kernels (ops_policy.ppo_grad)
         self._fp = fp
         self._ws = self._adv_n = None
         self._stats = torch.zeros(4, dtype=torch.float32, device=collector.device) if self.fused_update else None
@@ -94,7 +98,8 @@ class PPO:
         """The same step with the gradient from fpv_ppo_grad; the rollout arrays are read through idx in the kernel."""
         b = self._fused_src
         self._fp.ppo_grad(b["obs"], b["act"], b["old_lp"], b["adv"], b["ret"], index=idx, clip_range=self.clip_range,
-                          vf_coef=self.vf_coef, ent_coef=self.ent_coef, stats=self._stats, workspace=self._ws)
+                          vf_coef=self.vf_coef, ent_coef=self.ent_coef, stats=self._stats, workspace=self._ws,
+                          storage=self.grad_storage)
         self._allreduce_grads()
         self.opt.step(self._flat_grad)
         if self.log_std_min is not None:

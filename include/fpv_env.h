@@ -294,6 +294,8 @@ typedef struct {
     float* stats;             /* [4] out: policy-gradient loss, value loss (MSE), approx KL, clip fraction */
     void* workspace;          /* device scratch, >= fpv_ppo_workspace_bytes(rows), 16-byte aligned */
     int64_t workspace_bytes;
+    int32_t storage;          /* 0: activations / deltas pass between the kernels in fp32 (exact, default); 1: in bf16 —  */
+    int32_t reserved1;        /* half the HBM traffic of the update, gradients within ~1e-3 of their max-norm          */
 } fpv_ppo_io;
 
 int fpv_ppo_workspace_bytes(fpv_policy* pol, int64_t rows, int64_t* bytes);

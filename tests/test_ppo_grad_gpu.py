@@ -21,7 +21,7 @@ def _torch_grads(m, obs, act, old_lp, adv, ret, clip, vf, ent):
     return {n: p.grad.clone() for n, p in m.named_parameters()}, stats
 
 
-def _case(rows, obs_dim, act_dim, total=None, seed=0, ent=0.01):
+def _case(rows, obs_dim, act_dim, total=None, seed=0, ent=0.01, storage="f32", tol=2e-4):
     from fpv_drone_rl_agent_amd.ops_policy import FusedPolicy
     from fpv_drone_rl_agent_amd.policy import ActorCritic
     torch.manual_seed(seed)
@@ -46,12 +46,12 @@ def _case(rows, obs_dim, act_dim, total=None, seed=0, ent=0.01):
     fp = FusedPolicy(m)
     for p in m.parameters():
         p.grad = torch.full_like(p, 7.0)        # the call overwrites, it does not accumulate
-    stats = fp.ppo_grad(obs, act, old_lp, adv, ret, index=idx, clip_range=0.2, vf_coef=0.5, ent_coef=ent)
+    stats = fp.ppo_grad(obs, act, old_lp, adv, ret, index=idx, clip_range=0.2, vf_coef=0.5, ent_coef=ent, storage=storage)
     torch.cuda.synchronize()
     for n, p in m.named_parameters():
         scale = want[n].abs().max().item()
         err = (p.grad - want[n]).abs().max().item()
-        assert err <= 2e-4 * scale + 1e-9, (n, err, scale)
+        assert err <= tol * scale + 1e-9, (n, err, scale)
     assert torch.allclose(stats, wstats, rtol=2e-4, atol=2e-6), (stats, wstats)
     return m, fp
 
@@ -153,3 +153,10 @@ def test_ppo_grad_matches_the_committed_float64_golden_vector():
         err = np.abs(p.grad.double().cpu().numpy() - want).max()
         assert err <= 1e-4 * np.abs(want).max() + 1e-10, (n, err, np.abs(want).max())
     assert np.allclose(stats.double().cpu().numpy(), g["stats"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("rows", [130, 16384])
+def test_ppo_grad_bf16_storage_stays_close(rows):
+    """storage="bf16": the activations / deltas cross memory rounded to bf16 (2^-9 relative), the products stay fp32:
+    every gradient tensor within 4e-3 of its max-norm (statistics and head inputs are not affected by the rounding)."""
+    _case(rows, 20, 4, seed=rows + 1, storage="bf16", tol=4e-3)

@@ -11,6 +11,7 @@ from fpv_drone_rl_agent_amd.policy import ActorCritic
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 total = int(sys.argv[2]) if len(sys.argv) > 2 else 8 * rows
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+storage = sys.argv[4] if len(sys.argv) > 4 else "f32"
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 m = ActorCritic(log_std_init=-1.0).to(dev)
@@ -22,7 +23,7 @@ lp = torch.randn(total, device=dev) - 2; adv = torch.randn(total, device=dev); r
 idx = torch.randperm(total, device=dev)[:rows].contiguous()
 ws = fp.ppo_workspace(rows); stats = torch.zeros(4, device=dev)
 def step():
-    fp.ppo_grad(obs, act, lp, adv, ret, index=idx, stats=stats, workspace=ws)
+    fp.ppo_grad(obs, act, lp, adv, ret, index=idx, stats=stats, workspace=ws, storage=storage)
     opt.step(fgrad)
 for _ in range(5): step()
 torch.cuda.synchronize()
@@ -32,5 +33,5 @@ for _ in range(iters): step()
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / iters
 flop = rows * 2 * (2 * (24 * 128 + 128 * 128) + 2 * 128 * 128 + 2 * (128 * 128 + 128 * 32 + 32 * 128))   # fwd, bwd-data, wgrad, per net pair
-print(json.dumps({"rows": rows, "us_per_minibatch": round(us, 1), "rows_per_s": round(rows / us * 1e6),
+print(json.dumps({"rows": rows, "storage": storage, "us_per_minibatch": round(us, 1), "rows_per_s": round(rows / us * 1e6),
                   "mfma_TFLOPs": round(flop / us / 1e6, 1)}))
