@@ -52,7 +52,7 @@ struct fpv_env {
 struct fpv_policy {
     int device;
     int cus;
-    int gemm;               // 0: exact fp32 MFMA, 1: 6-term bf16 split MFMA
+    int gemm;               // 0: exact fp32 MFMA, 1: 6-term bf16 split MFMA, 2: exact fp32 MFMA, layer-at-a-time kernel only
     int in_dim, act_dim;    // 20 / 4 (hover) unless fpv_policy_set_dims says otherwise
     float* image;
     unsigned char* split_image;
@@ -478,7 +478,8 @@ int fpv_policy_set_dims(fpv_policy* p, int32_t in_dim, int32_t act_dim) {
 
 int fpv_policy_set_gemm(fpv_policy* p, int32_t mode) {
     if (!p) return fail(FPV_ERR_ARG, "fpv_policy_set_gemm: null handle");
-    if (mode != 0 && mode != 1) return fail(FPV_ERR_ARG, "fpv_policy_set_gemm: mode must be 0 (fp32 MFMA) or 1 (bf16 6-term split)");
+    if (mode < 0 || mode > 2)
+        return fail(FPV_ERR_ARG, "fpv_policy_set_gemm: mode must be 0 (fp32 MFMA), 1 (bf16 6-term split) or 2 (fp32 MFMA, layer-at-a-time kernel)");
     p->gemm = mode;
     return FPV_OK;
 }
@@ -516,7 +517,7 @@ int fpv_policy_forward(fpv_policy* p, const fpv_policy_io* io, void* stream) {
     FPV_HIP(launch_policy_forward(p->image, io->obs, io->rms, io->eps_in, io->tick, io->obs_n, io->action, io->clipped,
                                   io->value, io->logp, io->eps_out, io->n, io->seed, io->id_offset, io->clip_obs,
                                   io->eps_norm, io->deterministic, p->cus, nets, io->narrow ? 1 : 0, p->in_dim, p->act_dim, mg,
-                                  io->n_dev, (hipStream_t)stream));
+                                  io->n_dev, p->gemm == 2 ? 1 : 0, (hipStream_t)stream));
     return FPV_OK;
 }
 

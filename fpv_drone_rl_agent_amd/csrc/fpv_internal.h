@@ -210,7 +210,7 @@ hipError_t launch_policy_forward(const float* image, const float* obs, const dou
                                  const uint64_t* tick, float* obs_n, float* action, float* clipped, float* value,
                                  float* logp, float* eps_out, int64_t n, uint64_t seed, uint64_t id_offset,
                                  float clip_obs, float eps_norm, int deterministic, int max_blocks, int nets, int narrow,
-                                 int in_dim, int act_dim, const MergeArgs& merge, const int32_t* n_dev, hipStream_t s);
+                                 int in_dim, int act_dim, const MergeArgs& merge, const int32_t* n_dev, int legacy, hipStream_t s);
 int policy_image_floats();
 // fpv_ppo.hip
 int64_t ppo_workspace_floats(int64_t rows, int cus);

@@ -4,6 +4,12 @@
 #include "fpv_dynamics.h"   // philox4x32_10
 #include "fpv_internal.h"
 
+// Phase stamps (s_memtime / s_memrealtime) exist only in the diagnostic build tools/src/policy_stamps.hip, which defines
+// FPV_STAMP before including the kernel source; in the product the markers compile to nothing.
+#ifndef FPV_STAMP
+#define FPV_STAMP(k) ((void)0)
+#endif
+
 namespace fpv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
