@@ -12,7 +12,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libfpv_env.so")
-SOURCES = ["fpv_step.hip", "fpv_yaw.hip", "fpv_rollout.hip", "fpv_policy.hip", "fpv_policy_split.hip", "fpv_ppo.hip", "fpv_capi.hip"]
+SOURCES = ["fpv_step.hip", "fpv_yaw.hip", "fpv_rollout.hip", "fpv_policy.hip", "fpv_policy_w16.hip", "fpv_policy_split.hip", "fpv_ppo.hip", "fpv_capi.hip"]
 HEADERS = ["fpv_dynamics.h", "fpv_internal.h", "fpv_mlp.h", os.path.join("..", "..", "include", "fpv_env.h")]
 
 

@@ -55,6 +55,7 @@ struct fpv_policy {
     int gemm;               // 0: exact fp32 MFMA, 1: 6-term bf16 split MFMA, 2: exact fp32 MFMA, layer-at-a-time kernel only
     int in_dim, act_dim;    // 20 / 4 (hover) unless fpv_policy_set_dims says otherwise
     float* image;
+    float* image16;         // fpv_policy_w16.hip
     unsigned char* split_image;
 };
 
@@ -440,8 +441,10 @@ int fpv_policy_create(int32_t device, fpv_policy** out) {
     p->in_dim = 20;
     p->act_dim = 4;
     p->split_image = nullptr;
+    p->image16 = nullptr;
     hipError_t e = hipMalloc((void**)&p->image, sizeof(float) * (size_t)policy_image_floats());
     if (e == hipSuccess) e = hipMalloc((void**)&p->split_image, (size_t)policy_split_image_bytes());
+    if (e == hipSuccess) e = hipMalloc((void**)&p->image16, sizeof(float) * (size_t)policy16_image_floats());
     if (e != hipSuccess) {
         delete p;
         return fail(FPV_ERR_HIP, "fpv_policy_create: %s", hipGetErrorString(e));
@@ -454,6 +457,7 @@ int fpv_policy_destroy(fpv_policy* p) {
     if (!p) return FPV_OK;
     if (p->image) (void)hipFree(p->image);
     if (p->split_image) (void)hipFree(p->split_image);
+    if (p->image16) (void)hipFree(p->image16);
     delete p;
     return FPV_OK;
 }
@@ -463,6 +467,7 @@ int fpv_policy_load(fpv_policy* p, const float* const* weights, void* stream) {
     for (int i = 0; i < 13; ++i)
         if (!weights[i]) return fail(FPV_ERR_ARG, "fpv_policy_load: weight pointer %d is null", i);
     FPV_HIP(launch_policy_pack(weights, p->image, p->in_dim, p->act_dim, (hipStream_t)stream));
+    if (p->in_dim <= 20) FPV_HIP(launch_policy16_pack(weights, p->image16, p->in_dim, p->act_dim, (hipStream_t)stream));
     if (p->in_dim == 20 && p->act_dim == 4) FPV_HIP(launch_policy_split_pack(weights, p->split_image, (hipStream_t)stream));
     return FPV_OK;
 }
@@ -514,10 +519,17 @@ int fpv_policy_forward(fpv_policy* p, const fpv_policy_io* io, void* stream) {
                                             io->clip_obs, io->eps_norm, io->deterministic, p->cus, mg, (hipStream_t)stream));
         return FPV_OK;
     }
+    if (p->gemm == 0 && nets == 3 && !io->narrow && !mg.rows && !io->eps_in && !io->deterministic && !io->n_dev && p->in_dim <= 20) {
+        // the rollout's launch shape (both nets, in-kernel sampling): 16-wave workgroups on 16x16x4 tiles
+        FPV_HIP(launch_policy16_forward(p->image16, io->obs, io->rms, io->tick, io->obs_n, io->action, io->clipped, io->value,
+                                        io->logp, io->eps_out, io->n, io->seed, io->id_offset, io->clip_obs, io->eps_norm,
+                                        p->cus, p->in_dim, p->act_dim, (hipStream_t)stream));
+        return FPV_OK;
+    }
     FPV_HIP(launch_policy_forward(p->image, io->obs, io->rms, io->eps_in, io->tick, io->obs_n, io->action, io->clipped,
                                   io->value, io->logp, io->eps_out, io->n, io->seed, io->id_offset, io->clip_obs,
                                   io->eps_norm, io->deterministic, p->cus, nets, io->narrow ? 1 : 0, p->in_dim, p->act_dim, mg,
-                                  io->n_dev, p->gemm == 2 ? 1 : 0, (hipStream_t)stream));
+                                  io->n_dev, (hipStream_t)stream));
     return FPV_OK;
 }
 

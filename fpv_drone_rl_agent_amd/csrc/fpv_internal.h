@@ -210,8 +210,15 @@ hipError_t launch_policy_forward(const float* image, const float* obs, const dou
                                  const uint64_t* tick, float* obs_n, float* action, float* clipped, float* value,
                                  float* logp, float* eps_out, int64_t n, uint64_t seed, uint64_t id_offset,
                                  float clip_obs, float eps_norm, int deterministic, int max_blocks, int nets, int narrow,
-                                 int in_dim, int act_dim, const MergeArgs& merge, const int32_t* n_dev, int legacy, hipStream_t s);
+                                 int in_dim, int act_dim, const MergeArgs& merge, const int32_t* n_dev, hipStream_t s);
 int policy_image_floats();
+// fpv_policy_w16.hip
+hipError_t launch_policy16_pack(const float* const* w, float* image, int in_dim, int act_dim, hipStream_t s);
+hipError_t launch_policy16_forward(const float* image, const float* obs, const double* rms, const uint64_t* tick, float* obs_n,
+                                   float* action, float* clipped, float* value, float* logp, float* eps_out, int64_t n,
+                                   uint64_t seed, uint64_t id_offset, float clip_obs, float eps_norm, int max_blocks, int in_dim,
+                                   int act_dim, hipStream_t s);
+int policy16_image_floats();
 // fpv_ppo.hip
 int64_t ppo_workspace_floats(int64_t rows, int cus);
 hipError_t launch_ppo_grad(const float* const* w, float* const* grads, const int64_t* index, const float* obs,

@@ -9,27 +9,26 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <vector>
 
 constexpr int kStampSlots = 16;
-__device__ unsigned long long g_stamps[1024 * 8 * kStampSlots * 2];
+__device__ unsigned long long g_stamps[1024 * 16 * kStampSlots * 2];
 
 #define FPV_STAMP(k)                                                                                         \
     do {                                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         const unsigned long long t_ = __builtin_amdgcn_s_memtime(), r_ = __builtin_amdgcn_s_memrealtime();   \
         if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) {                                                  \
-            unsigned long long* q_ = g_stamps + (((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * kStampSlots + (k)) * 2; \
+            unsigned long long* q_ = g_stamps + (((size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * kStampSlots + (k)) * 2; \
             q_[0] = t_;                                                                                      \
             q_[1] = r_;                                                                                      \
         }                                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
     } while (0)
 
-#ifndef FPV_STAMP_SOURCE
-#define FPV_STAMP_SOURCE "fpv_policy.hip"
-#endif
-#include FPV_STAMP_SOURCE
+#include "fpv_policy.hip"
+#include "fpv_policy_w16.hip"
 
 using namespace fpv;
 
@@ -37,8 +36,8 @@ static const char* kPhaseLayered[kStampSlots] = {"start", "stage issued + LDS wr
                                                  "pi L1 mfma", "pi tanh1", "pi L2 mfma", "pi tanh2", "pi heads",
                                                  "V L1 mfma", "V tanh1", "V L2 mfma", "V tanh2", "V head", "sample + stores", ""};
 static const char* kPhasePipelined[kStampSlots] = {"start", "obs + LDS-DMA issued", "wait(obs, pi.W1) + barrier", "normalise",
-                                                   "pi L1", "wait(pi.W2) + pi L2", "wait(V.W1) + V L1 (+ pi tile 3)", "wait(V.W2) + V L2 (+ sampling)",
-                                                   "stores + V tile 3 (exposed tail)", "", "", "", "", "", "", ""};
+                                                   "pi L1 + tanh", "wait(pi.W2) + pi L2", "pi tanh + action head", "wait(V.W1) + V L1 + tanh",
+                                                   "wait(V.W2) + V L2", "V tanh + head, sample, stores", "", "", "", "", "", ""};
 
 int main(int argc, char** argv) {
     const int64_t n = argc > 1 ? atoll(argv[1]) : 65536;
@@ -49,8 +48,15 @@ int main(int argc, char** argv) {
     srand(1);
     auto rnd = [] { return (float)rand() / RAND_MAX * 2.f - 1.f; };
     const int img_floats = policy_image_floats();
-    std::vector<float> h_img(img_floats), h_obs(n * 20);
-    for (auto& v : h_img) v = 0.15f * rnd();
+    std::vector<float> h_obs(n * 20), h_w[13];
+    const int wsz[13] = {128 * 20, 128, 128 * 128, 128, 4 * 128, 4, 4, 128 * 20, 128, 128 * 128, 128, 128, 1};
+    float* d_w[13];
+    for (int i = 0; i < 13; ++i) {
+        h_w[i].resize(wsz[i]);
+        for (auto& v : h_w[i]) v = (i == 6 ? -0.5f : 0.15f) * rnd();
+        hipMalloc(&d_w[i], wsz[i] * 4);
+        hipMemcpy(d_w[i], h_w[i].data(), wsz[i] * 4, hipMemcpyHostToDevice);
+    }
     for (auto& v : h_obs) v = 2.0f * rnd();
     std::vector<double> h_rms(41, 0.0), h_rows(1024 * 44), h_ret(3, 1.0);
     for (int i = 0; i < 20; ++i) h_rms[20 + i] = 1.0;
@@ -63,7 +69,10 @@ int main(int argc, char** argv) {
     hipMalloc(&clipped, n * 16); hipMalloc(&value, n * 4); hipMalloc(&logp, n * 4);
     hipMalloc(&rms, 41 * 8); hipMalloc(&rms_out, 41 * 8); hipMalloc(&rows, 1024 * 44 * 8); hipMalloc(&ret, 24);
     hipMalloc(&ret_out, 24); hipMalloc(&snap, 44 * 8); hipMalloc(&tick, 8);
-    hipMemcpy(image, h_img.data(), img_floats * 4, hipMemcpyHostToDevice);
+    float* image16;
+    hipMalloc(&image16, policy16_image_floats() * 4);
+    launch_policy_pack(d_w, image, 20, 4, 0);
+    launch_policy16_pack(d_w, image16, 20, 4, 0);
     hipMemcpy(obs, h_obs.data(), n * 80, hipMemcpyHostToDevice);
     hipMemcpy(rms, h_rms.data(), 41 * 8, hipMemcpyHostToDevice);
     hipMemcpy(rows, h_rows.data(), 1024 * 44 * 8, hipMemcpyHostToDevice);
@@ -76,12 +85,15 @@ int main(int argc, char** argv) {
     for (int variant = 0; variant < 3; ++variant) {   // 0: layer-at-a-time, 1: the same + merge prologue, 2: pipelined
         const bool with_merge = variant == 1, pipelined = variant == 2;
         const char* const* names = pipelined ? kPhasePipelined : kPhaseLayered;
-        const int last = pipelined ? 8 : 14;
+        const int last = pipelined ? 9 : 14;
         MergeArgs mg{};
         if (with_merge) mg = MergeArgs{rows, ret, rms_out, ret_out, snap, (double)n, nrows, 20};
         auto go = [&] {
+            if (pipelined)
+                return launch_policy16_forward(image16, obs, rms, tick, obs_n, action, clipped, value, logp, nullptr, n, 7, 0, 10.f,
+                                               1e-8f, cus, 20, 4, 0);
             return launch_policy_forward(image, obs, rms, nullptr, tick, obs_n, action, clipped, value, logp, nullptr, n, 7, 0,
-                                         10.f, 1e-8f, 0, cus, 3, 0, 20, 4, mg, nullptr, pipelined ? 0 : 1, 0);
+                                         10.f, 1e-8f, 0, cus, 3, 0, 20, 4, mg, nullptr, 0);
         };
         for (int i = 0; i < 20; ++i) go();
         hipDeviceSynchronize();
@@ -98,18 +110,19 @@ int main(int argc, char** argv) {
         hipMemcpy(h_action.data(), action, n * 16, hipMemcpyDeviceToHost);
         hipMemcpy(h_value.data(), value, n * 4, hipMemcpyDeviceToHost);
         hipMemcpy(h_logp.data(), logp, n * 4, hipMemcpyDeviceToHost);
-        long long mism = -1;
+        double mism = -1;     // max |difference| to the layer-at-a-time kernel's outputs (same fp32 arithmetic, other summation order)
         if (variant == 0) { ref_action = h_action; ref_value = h_value; ref_logp = h_logp; }
         else if (variant == 2) {
             mism = 0;
-            for (int64_t i = 0; i < n * 4; ++i) mism += memcmp(&h_action[i], &ref_action[i], 4) != 0;
-            for (int64_t i = 0; i < n; ++i) mism += (memcmp(&h_value[i], &ref_value[i], 4) != 0) + (memcmp(&h_logp[i], &ref_logp[i], 4) != 0);
+            for (int64_t i = 0; i < n * 4; ++i) mism = std::max(mism, (double)fabsf(h_action[i] - ref_action[i]));
+            for (int64_t i = 0; i < n; ++i) mism = std::max(mism, std::max((double)fabsf(h_value[i] - ref_value[i]), (double)fabsf(h_logp[i] - ref_logp[i])));
         }
-        const int blocks = (int)std::min<int64_t>((n + 255) / 256, cus), waves = blocks * 8;
-        std::vector<unsigned long long> st((size_t)1024 * 8 * kStampSlots * 2);
+        const int wpb = pipelined ? 16 : 8;
+        const int blocks = (int)std::min<int64_t>((n + 255) / 256, cus), waves = blocks * wpb;
+        std::vector<unsigned long long> st((size_t)1024 * 16 * kStampSlots * 2);
         hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), st.size() * 8);
-        printf("{\"n\": %lld, \"kernel\": \"%s\", \"merge_prologue\": %d, \"us_per_launch_hip_events\": %.2f, \"bit_mismatches_vs_layered\": %lld, \"phases\": [",
-               (long long)n, pipelined ? "pipelined (policy_forward_dual_kernel)" : "layer-at-a-time (policy_forward_kernel<512>)", (int)with_merge,
+        printf("{\"n\": %lld, \"kernel\": \"%s\", \"merge_prologue\": %d, \"us_per_launch_hip_events\": %.2f, \"max_abs_diff_vs_layered\": %.3g, \"phases\": [",
+               (long long)n, pipelined ? "policy_forward_w16_kernel (16 waves, 16x16x4)" : "policy_forward_kernel<512> (8 waves, 32x32x2)", (int)with_merge,
                ms * 1e3 / settle, mism);
         double tot_med = 0;
         for (int k = 1; k <= last; ++k) {
@@ -118,11 +131,11 @@ int main(int argc, char** argv) {
                 const unsigned long long* q = st.data() + (size_t)w * kStampSlots * 2;
                 const double v = (double)(q[2 * k] - q[2 * (k - 1)]);
                 dd[0].push_back(v);
-                dd[1 + ((w & 7) >= 4)].push_back(v);
+                dd[1 + ((w % wpb) >= wpb / 2)].push_back(v);
             }
             for (auto& d : dd) std::sort(d.begin(), d.end());
             tot_med += dd[0][dd[0].size() / 2];
-            printf("%s{\"phase\": \"%s\", \"cycles_median\": %.0f, \"p10\": %.0f, \"p90\": %.0f, \"median_waves_0_3\": %.0f, \"median_waves_4_7\": %.0f}",
+            printf("%s{\"phase\": \"%s\", \"cycles_median\": %.0f, \"p10\": %.0f, \"p90\": %.0f, \"median_older_half\": %.0f, \"median_younger_half\": %.0f}",
                    k > 1 ? ", " : "", names[k], dd[0][dd[0].size() / 2], dd[0][dd[0].size() / 10], dd[0][dd[0].size() * 9 / 10],
                    dd[1][dd[1].size() / 2], dd[2][dd[2].size() / 2]);
         }
@@ -132,12 +145,12 @@ int main(int argc, char** argv) {
             const unsigned long long* q = st.data() + (size_t)w * kStampSlots * 2;
             tot.push_back((double)(q[2 * last] - q[0]));
             clk.push_back((double)(q[2 * last] - q[0]) / (double)(q[2 * last + 1] - q[1]) * 0.1);
-            ((w & 7) >= 4 ? end_hi : end_lo).push_back((double)(q[2 * last] - q[0]));
+            ((w % wpb) >= wpb / 2 ? end_hi : end_lo).push_back((double)(q[2 * last] - q[0]));
             r_first = std::min(r_first, q[1]); r_last = std::max(r_last, q[2 * last + 1]);
         }
         std::sort(tot.begin(), tot.end()); std::sort(clk.begin(), clk.end());
         std::sort(end_lo.begin(), end_lo.end()); std::sort(end_hi.begin(), end_hi.end());
-        printf("], \"wave_cycles_total_median\": %.0f, \"wave_cycles_waves_0_3\": %.0f, \"wave_cycles_waves_4_7\": %.0f, \"sum_of_phase_medians\": %.0f, "
+        printf("], \"wave_cycles_total_median\": %.0f, \"wave_cycles_older_half\": %.0f, \"wave_cycles_younger_half\": %.0f, \"sum_of_phase_medians\": %.0f, "
                "\"clock_GHz_median\": %.3f, \"clock_GHz_p10\": %.3f, \"clock_GHz_p90\": %.3f, \"first_stamp_to_last_stamp_us\": %.2f}\n",
                tot[tot.size() / 2], end_lo[end_lo.size() / 2], end_hi[end_hi.size() / 2], tot_med, clk[clk.size() / 2], clk[clk.size() / 10],
                clk[clk.size() * 9 / 10], (double)(r_last - r_first) * 0.01);
