@@ -210,25 +210,70 @@ __global__ __launch_bounds__(1024) void policy_forward_w16_kernel(Policy16Args p
         FPV_STAMP(3);
 
         float head[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // 4 action means + value (partial sums over this lane's 32 hidden units)
+        f32x4 pend0 = {0.f, 0.f, 0.f, 0.f}, pend1 = {0.f, 0.f, 0.f, 0.f};   // the last layer-2 tile pair of the previous net
+        lfloat* wa = ldsc + kHead + g * 128;        // Wa_p[g][t][r][o]
+        lfloat* wv = ldsc + kHead + 512 + g * 32;   // Wv_p[g][t][r]
+        // head terms of element r of finished layer-2 tile t: the same instructions for both nets (no branch between
+        // the products) — s_pi / s_v are 1 / 0 for pi and 0 / 1 for V, so the other net's term adds an exact zero.
+        // Results pass through an asm so that hipcc keeps the arithmetic where it is written, under the products.
+        auto head_apply = [&](float v, f32x4 wh, float wvr, float s_pi, float s_v) {
+            const float th = fast_tanh(v), tp = th * s_pi, tv = th * s_v;
+            head[0] += wh.x * tp; head[1] += wh.y * tp; head[2] += wh.z * tp; head[3] += wh.w * tp;
+            head[4] += wvr * tv;
+        };
         // (the two nets as a real loop: one base register + immediate offsets address a whole net's image)
 #pragma unroll 1
         for (int net = 0; net < 2; ++net) {
             lfloat* nb = ldsc + net * kNet + lane;  // + lane: W1p is read one float per lane
             lfloat* nb4 = ldsc + net * kNet + lane * 4;
             lfloat* nbg = ldsc + net * kNet + g * 4;
-            // ---- layer 1: in (<= 20) -> 128: five k-steps on eight independent output tiles
+            const float s_pi = net == 0 ? 1.0f : 0.0f, s_v = 1.0f - s_pi;
+            // ---- layer 1: in (<= 20) -> 128, one pair of 16-row output tiles at a time: five k-steps alternate between
+            // the pair's accumulators (a product never waits for the one just issued); the vector work of the pair
+            // before — tanh, or for V's first pair the tanh + action-head terms of pi's last layer-2 pair — sits between
+            // the k-steps; the next pair's fragments are requested one pair ahead
             f32x4 a[8];
+            float wf0[5], wf1[5];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) a[t] = *(lf32x4*)(nbg + kB1 + t * 16);
+            for (int s = 0; s < 5; ++s) { wf0[s] = nb[kW1 + (s * 8 + 0) * 64]; wf1[s] = nb[kW1 + (s * 8 + 1) * 64]; }
 #pragma unroll
-            for (int s = 0; s < 5; ++s)
+            for (int P = 0; P < 4; ++P) {
+                a[2 * P] = *(lf32x4*)(nbg + kB1 + (2 * P) * 16);
+                a[2 * P + 1] = *(lf32x4*)(nbg + kB1 + (2 * P + 1) * 16);
+                float nf0[5], nf1[5];
 #pragma unroll
-                for (int t = 0; t < 8; ++t)
-                    a[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(nb[kW1 + (s * 8 + t) * 64], x[s], a[t], 0, 0, 0);
-            FPV_FENCE();
+                for (int s = 0; s < 5; ++s) {
+                    nf0[s] = P < 3 ? nb[kW1 + (s * 8 + 2 * P + 2) * 64] : 0.0f;
+                    nf1[s] = P < 3 ? nb[kW1 + (s * 8 + 2 * P + 3) * 64] : 0.0f;
+                }
+                // (P == 0) head weights of the pending pair's elements, requested one slice ahead: slices take elements
+                // {0,1} {2,3} {4,5} {6} {7} of the pair (tiles 6, 7)
+                f32x4 hw0 = {0.f, 0.f, 0.f, 0.f}, hw1 = {0.f, 0.f, 0.f, 0.f};
+                if (P == 0) { hw0 = *(lf32x4*)(wa + (6 * 4 + 0) * 4); hw1 = *(lf32x4*)(wa + (6 * 4 + 1) * 4); }
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                a[t].x = fast_tanh(a[t].x); a[t].y = fast_tanh(a[t].y); a[t].z = fast_tanh(a[t].z); a[t].w = fast_tanh(a[t].w);
+                for (int s = 0; s < 5; ++s) {
+                    const int e0 = s < 3 ? 2 * s : 3 + s, e1 = s < 3 ? 2 * s + 2 : 4 + s;        // this slice's elements
+                    const int f0 = s + 1 < 3 ? 2 * (s + 1) : 3 + (s + 1);                        // the next slice's first
+                    f32x4 nh0 = hw0, nh1 = hw1;
+                    if (P == 0 && s < 4) {
+                        nh0 = *(lf32x4*)(wa + ((6 + (f0 >> 2)) * 4 + (f0 & 3)) * 4);
+                        if (s + 1 < 3) nh1 = *(lf32x4*)(wa + ((6 + ((f0 + 1) >> 2)) * 4 + ((f0 + 1) & 3)) * 4);
+                    }
+                    a[2 * P] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf0[s], x[s], a[2 * P], 0, 0, 0);
+                    a[2 * P + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf1[s], x[s], a[2 * P + 1], 0, 0, 0);
+                    // vector slice s of 5: elements e0..e1 of the 8 pending ones
+#pragma unroll
+                    for (int e = e0; e < e1; ++e) {
+                        if (P == 0) head_apply(e < 4 ? pend0[e & 3] : pend1[e & 3], e == e0 ? hw0 : hw1, 0.0f, s_v, 0.0f);
+                        else a[2 * P - 2 + (e >> 2)][e & 3] = fast_tanh(a[2 * P - 2 + (e >> 2)][e & 3]);
+                    }
+                    if (P == 0) asm volatile("" : "+v"(head[0]), "+v"(head[1]), "+v"(head[2]), "+v"(head[3]) :: "memory");
+                    else asm volatile("" : "+v"(a[2 * P - 2]), "+v"(a[2 * P - 1]) :: "memory");
+                    hw0 = nh0; hw1 = nh1;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int s = 0; s < 5; ++s) { wf0[s] = nf0[s]; wf1[s] = nf1[s]; }
             }
             if (net == 0) FPV_STAMP(4); else FPV_STAMP(7);
             if (first) {
@@ -236,55 +281,65 @@ __global__ __launch_bounds__(1024) void policy_forward_w16_kernel(Policy16Args p
                 else FPV_WAIT_VM(0);                // G4 landed
                 __builtin_amdgcn_s_barrier();
             }
-            // ---- layer 2: 128 -> 128; the layer-1 tiles are the B operands as they stand.  Two output tiles alternate,
-            // so a product never waits for the one just issued (40-cycle dependent latency against a 32-cycle issue)
-            f32x4 c[8];
+            // ---- layer 2: 128 -> 128, one pair of output tiles at a time; the layer-1 tiles are the B operands as they
+            // stand.  Per k-tile u: the next fragments are requested, eight products alternate between the pair's
+            // accumulators, then one element of pending vector work: during the first pair the tanh of layer 1's last
+            // pair (read from u = 6 on), afterwards tanh + head terms of the pair before
+            f32x4 w0 = *(lf32x4*)(nb4 + kW2 + (0 * 8 + 0) * 256), w1 = *(lf32x4*)(nb4 + kW2 + (1 * 8 + 0) * 256);
+            f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = {0.f, 0.f, 0.f, 0.f};           // the pair before
+            f32x4 hw = {0.f, 0.f, 0.f, 0.f};                                       // head weights of the pending element,
+            float hv = 0.0f;                                                       // requested one k-tile ahead
 #pragma unroll
-            for (int t = 0; t < 8; ++t) c[t] = *(lf32x4*)(nbg + kB2 + t * 16);
+            for (int Q = 0; Q < 4; ++Q) {
+                f32x4 c0 = *(lf32x4*)(nbg + kB2 + (2 * Q) * 16), c1 = *(lf32x4*)(nbg + kB2 + (2 * Q + 1) * 16);
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-#pragma unroll
-                for (int tp = 0; tp < 4; ++tp) {
-                    const f32x4 w0 = *(lf32x4*)(nb4 + kW2 + ((2 * tp) * 8 + u) * 256);
-                    const f32x4 w1 = *(lf32x4*)(nb4 + kW2 + ((2 * tp + 1) * 8 + u) * 256);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        c[2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[r], a[u][r], c[2 * tp], 0, 0, 0);
-                        c[2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[r], a[u][r], c[2 * tp + 1], 0, 0, 0);
+                for (int u = 0; u < 8; ++u) {
+                    const int nq = u < 7 ? Q : Q + 1, nu = u < 7 ? u + 1 : 0;      // next (pair, k-tile)
+                    f32x4 n0 = w0, n1 = w1;
+                    if (nq < 4) {
+                        n0 = *(lf32x4*)(nb4 + kW2 + ((2 * nq) * 8 + nu) * 256);
+                        n1 = *(lf32x4*)(nb4 + kW2 + ((2 * nq + 1) * 8 + nu) * 256);
                     }
-                    FPV_FENCE();
-                }
-            if (net == 0) FPV_STAMP(5); else FPV_STAMP(8);
-            // ---- tanh + heads on the VALU: this lane holds 32 of its drone's 128 hidden values
-            if (net == 0) {
-                lfloat* wa = ldsc + kHead + g * 128;
-#pragma unroll
-                for (int t = 0; t < 8; ++t)
+                    f32x4 nhw = hw;
+                    float nhv = hv;
+                    if (nq >= 1 && nq < 4) {        // the element the next k-tile finishes: nu of pair nq - 1
+                        nhw = *(lf32x4*)(wa + ((2 * nq - 2 + (nu >> 2)) * 4 + (nu & 3)) * 4);
+                        nhv = wv[(2 * nq - 2 + (nu >> 2)) * 4 + (nu & 3)];
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const f32x4 wh = *(lf32x4*)(wa + (t * 4 + r) * 4);
-                        const float v = fast_tanh(c[t][r]);
-                        head[0] += wh.x * v; head[1] += wh.y * v; head[2] += wh.z * v; head[3] += wh.w * v;
-                        if (r == 3) {               // the sums pass through the fence: the arithmetic stays in its tile
-                            asm volatile("" : "+v"(head[0]), "+v"(head[1]), "+v"(head[2]), "+v"(head[3]) :: "memory");
-                            __builtin_amdgcn_sched_barrier(0);
+                        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[r], a[u][r], c0, 0, 0, 0);
+                        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[r], a[u][r], c1, 0, 0, 0);
+                    }
+                    if (Q == 0) {
+                        if (u < 4) {
+                            a[6 + (u >> 1)][2 * (u & 1)] = fast_tanh(a[6 + (u >> 1)][2 * (u & 1)]);
+                            a[6 + (u >> 1)][2 * (u & 1) + 1] = fast_tanh(a[6 + (u >> 1)][2 * (u & 1) + 1]);
+                            asm volatile("" : "+v"(a[6]), "+v"(a[7]) :: "memory");
                         }
+                    } else {
+                        head_apply(u < 4 ? q0[u & 3] : q1[u & 3], hw, hv, s_pi, s_v);
+                        asm volatile("" : "+v"(head[0]), "+v"(head[1]), "+v"(head[2]), "+v"(head[3]), "+v"(head[4]) :: "memory");
                     }
-                FPV_STAMP(6);
+                    w0 = n0; w1 = n1; hw = nhw; hv = nhv;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                q0 = c0; q1 = c1;
+            }
+            if (net == 0) {
+                pend0 = q0; pend1 = q1;             // finished under V's first layer-1 pair
+                FPV_STAMP(5);
                 if (first) {
                     FPV_WAIT_VM(4);                 // G3 landed
                     __builtin_amdgcn_s_barrier();
                 }
+                FPV_STAMP(6);
             } else {
-                lfloat* wv = ldsc + kHead + 512 + g * 32;
+                FPV_STAMP(8);
+                // ---- the exposed tail: tanh + value-head terms of V's last pair
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const f32x4 wh = *(lf32x4*)(wv + t * 4);
-                    head[4] += wh.x * fast_tanh(c[t].x); head[4] += wh.y * fast_tanh(c[t].y);
-                    head[4] += wh.z * fast_tanh(c[t].z); head[4] += wh.w * fast_tanh(c[t].w);
-                    asm volatile("" : "+v"(head[4]) :: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                for (int e = 0; e < 8; ++e)
+                    head_apply(e < 4 ? q0[e & 3] : q1[e & 3], f32x4{0.f, 0.f, 0.f, 0.f}, wv[((e < 4 ? 6 : 7)) * 4 + (e & 3)], 0.0f, 1.0f);
             }
         }
         first = false;

@@ -36,8 +36,8 @@ static const char* kPhaseLayered[kStampSlots] = {"start", "stage issued + LDS wr
                                                  "pi L1 mfma", "pi tanh1", "pi L2 mfma", "pi tanh2", "pi heads",
                                                  "V L1 mfma", "V tanh1", "V L2 mfma", "V tanh2", "V head", "sample + stores", ""};
 static const char* kPhasePipelined[kStampSlots] = {"start", "obs + LDS-DMA issued", "wait(obs, pi.W1) + barrier", "normalise",
-                                                   "pi L1 + tanh", "wait(pi.W2) + pi L2", "pi tanh + action head", "wait(V.W1) + V L1 + tanh",
-                                                   "wait(V.W2) + V L2", "V tanh + head, sample, stores", "", "", "", "", "", ""};
+                                                   "pi L1", "wait(pi.W2) + pi L2", "wait(V.W1) + barrier", "V L1 (+ pi's last pair)",
+                                                   "wait(V.W2) + V L2", "V's last pair, sample, stores", "", "", "", "", "", ""};
 
 int main(int argc, char** argv) {
     const int64_t n = argc > 1 ? atoll(argv[1]) : 65536;
