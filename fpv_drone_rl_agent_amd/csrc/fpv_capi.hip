@@ -52,7 +52,7 @@ struct fpv_env {
 struct fpv_policy {
     int device;
     int cus;
-    int gemm;               // 0: exact fp32 MFMA, 1: 6-term bf16 split MFMA, 2: exact fp32 MFMA, layer-at-a-time kernel only
+    int gemm;               // 0: exact fp32 MFMA, 1: 6-term bf16 split MFMA, 2: exact fp32 MFMA on 16x16x4 tiles, 16-wave workgroups (fpv_policy_w16.hip)
     int in_dim, act_dim;    // 20 / 4 (hover) unless fpv_policy_set_dims says otherwise
     float* image;
     float* image16;         // fpv_policy_w16.hip
@@ -484,7 +484,7 @@ int fpv_policy_set_dims(fpv_policy* p, int32_t in_dim, int32_t act_dim) {
 int fpv_policy_set_gemm(fpv_policy* p, int32_t mode) {
     if (!p) return fail(FPV_ERR_ARG, "fpv_policy_set_gemm: null handle");
     if (mode < 0 || mode > 2)
-        return fail(FPV_ERR_ARG, "fpv_policy_set_gemm: mode must be 0 (fp32 MFMA), 1 (bf16 6-term split) or 2 (fp32 MFMA, layer-at-a-time kernel)");
+        return fail(FPV_ERR_ARG, "fpv_policy_set_gemm: mode must be 0 (fp32 MFMA), 1 (bf16 6-term split) or 2 (fp32 MFMA, 16-wave kernel)");
     p->gemm = mode;
     return FPV_OK;
 }
@@ -519,7 +519,7 @@ int fpv_policy_forward(fpv_policy* p, const fpv_policy_io* io, void* stream) {
                                             io->clip_obs, io->eps_norm, io->deterministic, p->cus, mg, (hipStream_t)stream));
         return FPV_OK;
     }
-    if (p->gemm == 0 && nets == 3 && !io->narrow && !mg.rows && !io->eps_in && !io->deterministic && !io->n_dev && p->in_dim <= 20) {
+    if (p->gemm == 2 && nets == 3 && !io->narrow && !mg.rows && !io->eps_in && !io->deterministic && !io->n_dev && p->in_dim <= 20) {
         // the rollout's launch shape (both nets, in-kernel sampling): 16-wave workgroups on 16x16x4 tiles
         FPV_HIP(launch_policy16_forward(p->image16, io->obs, io->rms, io->tick, io->obs_n, io->action, io->clipped, io->value,
                                         io->logp, io->eps_out, io->n, io->seed, io->id_offset, io->clip_obs, io->eps_norm,

@@ -39,10 +39,10 @@ class FusedPolicy:
 
     def set_gemm(self, gemm: str) -> None:
         """'f32': exact fp32 MFMA (default).  'bf16x6': 6-term bf16 split on bf16 MFMA, fp32-level error.
-        'f32_layered': the fp32 arithmetic on the layer-at-a-time kernel for every launch shape (same bits as 'f32')."""
-        modes = {"f32": 0, "bf16x6": 1, "f32_layered": 2}
+        'f32_w16': the fp32 arithmetic on 16x16x4 tiles with 16-wave workgroups (rounding-level differences to 'f32')."""
+        modes = {"f32": 0, "bf16x6": 1, "f32_w16": 2}
         if gemm not in modes:
-            raise ValueError("gemm must be 'f32', 'bf16x6' or 'f32_layered'")
+            raise ValueError("gemm must be 'f32', 'bf16x6' or 'f32_w16'")
         L.check(self.lib.fpv_policy_set_gemm(self._h, modes[gemm]), "fpv_policy_set_gemm")
         self.gemm = gemm
 

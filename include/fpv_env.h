@@ -272,10 +272,10 @@ int fpv_policy_forward(fpv_policy* pol, const fpv_policy_io* io, void* stream);
 /* Hidden-layer GEMM arithmetic: 0 (default) = v_mfma_f32_32x32x2_f32, bit-exact fp32 fma chains; 1 = each fp32
  * operand cut into three bf16 pieces and the six piece products of order <= 4 summed on v_mfma_f32_32x32x16_bf16
  * in fp32 accumulators (error at the level of one fp32 rounding, 2.7x fewer matrix-pipe cycles); 2 = the arithmetic of
- * mode 0 on the two-waves-per-SIMD kernel (32x32x2 tiles) for every launch shape; mode 0 itself runs the rollout's launch
- * shape — both nets, in-kernel sampling, no merge prologue — on the four-waves-per-SIMD kernel (16x16x4 tiles,
- * fpv_policy_w16.hip): the same fp32 fma arithmetic with another summation order, so the two agree to rounding
- * (tests/test_policy_gpu.py), not bit for bit. */
+ * mode 0 on v_mfma_f32_16x16x4_f32 with four waves per SIMD (fpv_policy_w16.hip) for the rollout's launch shape (both
+ * nets, in-kernel sampling, no merge prologue): another summation order, so it agrees with mode 0 to rounding, not bit
+ * for bit.  Kept as the measured alternative: it is not faster — vector instructions do not co-execute
+ * with fp32-input MFMA on gfx950 (tools/mfma_mix), so the tanh work bounds both shapes alike. */
 int fpv_policy_set_gemm(fpv_policy* pol, int32_t mode);
 
 /* ---- PPO minibatch gradient (SB3 PPO.train: clipped surrogate + vf_coef * MSE value loss - ent_coef * entropy) ----

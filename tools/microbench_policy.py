@@ -6,7 +6,7 @@ from fpv_drone_rl_agent_amd.policy import ActorCritic
 from fpv_drone_rl_agent_amd.ops_policy import FusedPolicy
 torch.manual_seed(0)
 m = ActorCritic().cuda()
-for gemm, n in [(g, n) for g in ('f32', 'f32_layered', 'bf16x6') for n in (4096, 65536, 524288)]:
+for gemm, n in [(g, n) for g in ('f32', 'f32_w16', 'bf16x6') for n in (4096, 65536, 524288)]:
     fp = FusedPolicy(m, gemm=gemm)
     obs = torch.randn(n, 20, device="cuda")
     bufs = dict(obs_n=torch.empty(n, 20, device="cuda"), action=torch.empty(n, 4, device="cuda"), clipped=torch.empty(n, 4, device="cuda"),
