@@ -12,6 +12,7 @@ from .build import LIB_PATH, build_extension
 
 FPV_F32, FPV_F64 = 0, 1
 TASK_HOVER, TASK_YAW = 0, 1
+DETECTOR_ANALYTIC, DETECTOR_PIXEL = 0, 1
 STATE_WORDS, OBS_WORDS, ACT_WORDS = 36, 20, 4
 INFO_TERMINATED, INFO_TRUNCATED, INFO_OUT_OF_BOUNDS, INFO_ON_FLOOR = 1, 2, 4, 8
 
@@ -21,7 +22,7 @@ class FpvConfig(C.Structure):
         ("num_envs", C.c_int64), ("device", C.c_int32), ("precision", C.c_int32),
         ("floor_check", C.c_int32), ("task", C.c_int32), ("noise_ratio", C.c_double),
         ("seed", C.c_uint64), ("id_offset", C.c_uint64), ("ledger_capacity", C.c_int64),
-        ("domain_rand", C.c_int32), ("reserved1", C.c_int32),
+        ("domain_rand", C.c_int32), ("detector", C.c_int32),
     ]
 
 

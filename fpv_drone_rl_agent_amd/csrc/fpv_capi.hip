@@ -95,6 +95,7 @@ static int step_impl(fpv_env* e, const T* actions, T* obs, T* reward, uint8_t* t
     a.sigma = (T)e->cfg.noise_ratio;
     a.floor_check = e->cfg.floor_check;
     a.domain_rand = e->cfg.domain_rand;
+    a.detector = e->cfg.detector;
     a.done = ex ? ex->done : nullptr;
     a.ret = ex ? ex->ret : nullptr;
     a.partials = ex ? ex->partials : nullptr;
@@ -130,6 +131,8 @@ int fpv_create(const fpv_config* cfg, fpv_env** out) {
         return fail(FPV_ERR_ARG, "fpv_create: unknown precision %d", cfg->precision);
     if (cfg->noise_ratio < 0.0) return fail(FPV_ERR_ARG, "fpv_create: negative noise_ratio");
     if (cfg->task != FPV_TASK_HOVER && cfg->task != FPV_TASK_YAW) return fail(FPV_ERR_ARG, "fpv_create: unknown task %d", cfg->task);
+    if (cfg->detector != FPV_DETECTOR_ANALYTIC && cfg->detector != FPV_DETECTOR_PIXEL)
+        return fail(FPV_ERR_ARG, "fpv_create: unknown detector %d", cfg->detector);
     int ndev = 0;
     FPV_HIP(hipGetDeviceCount(&ndev));
     if (cfg->device < 0 || cfg->device >= ndev)
@@ -174,8 +177,8 @@ int fpv_create(const fpv_config* cfg, fpv_env** out) {
                       : launch_yaw_reset<float>(e->state, e->tick, nullptr, nullptr, cfg->num_envs, cfg->seed, cfg->id_offset,
                                                 cfg->domain_rand, 1, nullptr);
         else
-            err = cfg->precision == FPV_F64 ? launch_init<double>(e->state, e->tmpl, cfg->num_envs, nullptr)
-                                            : launch_init<float>(e->state, e->tmpl, cfg->num_envs, nullptr);
+            err = cfg->precision == FPV_F64 ? launch_init<double>(e->state, e->tmpl, cfg->num_envs, cfg->detector, nullptr)
+                                            : launch_init<float>(e->state, e->tmpl, cfg->num_envs, cfg->detector, nullptr);
     }
     if (err == hipSuccess) err = hipDeviceSynchronize();
     if (err != hipSuccess) {

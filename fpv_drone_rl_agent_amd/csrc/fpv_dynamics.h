@@ -71,6 +71,10 @@ __device__ __forceinline__ float rsqrt_(float x) { return __builtin_amdgcn_rsqf(
 __device__ __forceinline__ double rsqrt_(double x) { return 1.0 / sqrt(x); }
 __device__ __forceinline__ float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }  // v_sqrt_f32, 1 ulp
 __device__ __forceinline__ double sqrt_(double x) { return sqrt(x); }
+__device__ __forceinline__ float ceil_(float x) { return ceilf(x); }
+__device__ __forceinline__ double ceil_(double x) { return ceil(x); }
+__device__ __forceinline__ float floor_(float x) { return floorf(x); }
+__device__ __forceinline__ double floor_(double x) { return floor(x); }
 __device__ __forceinline__ float abs_(float x) { return fabsf(x); }
 __device__ __forceinline__ double abs_(double x) { return fabs(x); }
 __device__ __forceinline__ float min_(float a, float b) { return fminf(a, b); }
@@ -429,10 +433,145 @@ __device__ __forceinline__ bool camera_features(const Drone<T>& d, T& cx, T& cy,
     return ok;
 }
 
+// ---------------------------------------------------------------- pixel detector (SPEC §6b)
+// hover.py:157-222 on a 128 x 128 rendering of the panel, without a renderer: a pixel is red when its centre
+// (i + 0.5, j + 0.5) lies in the projected front face.  One pass over the blob's rows gives cv2.boundingRect's integer
+// w / h (:209-213), cv2.contourArea and arcLength of the outer contour (the polygon through the boundary pixels, :206) and
+// the border rule (:180-185); the four approxPolyDP vertices (:189-203) are the covered pixels nearest to the projected
+// corners, accepted when the two off the longer diagonal lie farther than 0.04 arcLength from it.  OpenCV's rules are
+// restated from their documentation (cv2 is not on disk): parity unpinned; pinned by hover.py:50-51's own constants
+// (reset pose: 20 / 13 = 1.538, 207 / 16384 = 0.0126) and compared with a full Douglas-Peucker restatement in
+// tests/test_detector_cpu.py.  The arithmetic and its order are those of SPEC §6b (the CPU checker follows the same text).
+template <typename T>
+__device__ __forceinline__ bool row_span(const T (&u)[4], const T (&v)[4], const T (&slope)[4], int j, int& a, int& b) {
+    const T y = T(j) + T(0.5);
+    T xl = T(0), xr = T(0);
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int m = (k + 1) & 3;
+        if ((v[k] <= y) != (v[m] <= y)) {
+            const T x = u[k] + (y - v[k]) * slope[k];
+            if (n == 0) { xl = x; xr = x; }
+            else { xl = min_(xl, x); xr = max_(xr, x); }
+            ++n;
+        }
+    }
+    if (n < 2) return false;
+    const T fa = max_(ceil_(xl - T(0.5)), T(0)), fb = min_(floor_(xr - T(0.5)), T(127));
+    if (fa > fb) return false;
+    a = (int)fa; b = (int)fb;
+    return true;
+}
+
+template <typename T>
+__device__ __forceinline__ bool camera_features_pixel(const Drone<T>& d, T& cx, T& cy, T& area, T& ratio) {
+    const T xx = d.qx * d.qx, yy = d.qy * d.qy, zz = d.qz * d.qz;
+    const T xy = d.qx * d.qy, xz = d.qx * d.qz, yz = d.qy * d.qz;
+    const T wx_ = d.qw * d.qx, wy_ = d.qw * d.qy, wz_ = d.qw * d.qz;
+    const T r00 = T(1) - T(2) * (yy + zz), r01 = T(2) * (xy - wz_), r02 = T(2) * (xz + wy_);
+    const T r10 = T(2) * (xy + wz_), r11 = T(1) - T(2) * (xx + zz), r12 = T(2) * (yz - wx_);
+    const T r20 = T(2) * (xz - wy_), r21 = T(2) * (yz + wx_), r22 = T(1) - T(2) * (xx + yy);
+    const T dx = C<T>::panel_x - d.px, dy = -d.py, dz = C<T>::panel_zc - d.pz;
+    const T bx = r00 * dx + r10 * dy + r20 * dz;
+    const T by = r01 * dx + r11 * dy + r21 * dz;
+    const T bz = r02 * dx + r12 * dy + r22 * dz;
+    const T c = C<T>::cam_c, s = C<T>::cam_s;
+    const T dep_c = c * bx + s * bz, up_c = c * bz - s * bx, rt_c = -by;
+    const T dep_y = c * r10 + s * r12, up_y = c * r12 - s * r10, rt_y = -r11;
+    const T dep_z = c * r20 + s * r22, up_z = c * r22 - s * r20, rt_z = -r21;
+    T u[4], v[4];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const T sy = (j == 0 || j == 3) ? T(1) : T(-1);
+        const T sz = (j >= 2) ? T(1) : T(-1);
+        T dep = dep_c + sy * dep_y + sz * dep_z;
+        const T up = up_c + sy * up_y + sz * up_z;
+        const T rt = rt_c + sy * rt_y + sz * rt_z;
+        if (!(dep > T(0.1))) { ok = false; dep = T(1); }
+        const T k = T(64) / dep;
+        u[j] = T(64) + k * rt;
+        v[j] = T(64) - k * up;
+    }
+    cx = T(0); cy = T(0); area = T(0); ratio = T(0);
+    T slope[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = (j + 1) & 3;
+        slope[j] = v[m] != v[j] ? (u[m] - u[j]) / (v[m] - v[j]) : T(0);
+    }
+    const T vmin = min_(min_(v[0], v[1]), min_(v[2], v[3])), vmax = max_(max_(v[0], v[1]), max_(v[2], v[3]));
+    const T flo = max_(ceil_(vmin - T(0.5)), T(0)), fhi = min_(floor_(vmax - T(0.5)), T(127));
+    if (!ok || !(flo <= fhi)) return false;
+    const int jlo = (int)flo, jhi = (int)fhi;
+    int j0 = -1, jn = -1, amin = 128, bmax = -1, pa = 0, pb = 0;
+    bool border = false, broken = false;
+    T apx = T(0), len = T(0);
+    for (int j = jlo; j <= jhi; ++j) {
+        int a, b;
+        if (!row_span(u, v, slope, j, a, b)) continue;                  // (a sliver between two pixel centres)
+        if (j0 >= 0 && jn != j - 1) broken = true;                      // an empty row inside the blob
+        if (j0 < 0) { j0 = j; len += T(b - a); }
+        else {
+            if (a > pb + 1 || b < pa - 1) broken = true;                // not 8-connected to the row above
+            const T ml = T(a > pa ? a : pa) - (a != pa ? T(0.5) : T(0));
+            const T mr = T(b < pb ? b : pb) + (b != pb ? T(0.5) : T(0));
+            if (mr > ml) apx += mr - ml;
+            const int da = a > pa ? a - pa : pa - a, db = b > pb ? b - pb : pb - b;
+            len += (da == 0 ? T(1) : T(1.4142135623730951) + T(da - 1)) + (db == 0 ? T(1) : T(1.4142135623730951) + T(db - 1));
+        }
+        if (a == 0 || b == 127 || j == 0 || j == 127) border = true;    // hover.py:180-185
+        amin = a < amin ? a : amin;
+        bmax = b > bmax ? b : bmax;
+        jn = j; pa = a; pb = b;
+    }
+    if (j0 < 0 || broken || border) return false;
+    len += T(pb - pa);
+    int vx[4], vy[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const T fr = floor_(v[k]);
+        const int jc = (int)(fr < T(j0) ? T(j0) : (fr > T(jn) ? T(jn) : fr));
+        T best = T(1e30);
+        vx[k] = 0; vy[k] = 0;
+#pragma unroll
+        for (int dj = -1; dj <= 1; ++dj) {
+            const int j = jc + dj;
+            int a = 0, b = 0;
+            if (j < j0 || j > jn) continue;
+            row_span(u, v, slope, j, a, b);
+            const T fx = floor_(u[k]);
+            const int x = (int)(fx < T(a) ? T(a) : (fx > T(b) ? T(b) : fx));
+            const T ex = T(x) + T(0.5) - u[k], ey = T(j) + T(0.5) - v[k], d2 = ex * ex + ey * ey;
+            if (d2 < best) { best = d2; vx[k] = x; vy[k] = j; }
+        }
+    }
+    const T eps = T(0.04) * len;
+    {
+        const T d02 = T((vx[2] - vx[0]) * (vx[2] - vx[0]) + (vy[2] - vy[0]) * (vy[2] - vy[0]));
+        const T d13 = T((vx[3] - vx[1]) * (vx[3] - vx[1]) + (vy[3] - vy[1]) * (vy[3] - vy[1]));
+        const int p = d02 >= d13 ? 0 : 1, q = p + 2;
+        const T ex = T(vx[q] - vx[p]), ey = T(vy[q] - vy[p]), el = sqrt_(ex * ex + ey * ey);
+        if (!(el > T(0))) return false;
+#pragma unroll
+        for (int k = 1; k < 4; k += 2) {
+            const int m = (p + k) & 3;
+            const T dist = abs_(ex * T(vy[m] - vy[p]) - ey * T(vx[m] - vx[p])) / el;
+            if (!(dist > eps)) return false;
+        }
+    }
+    cx = T(0.25) * T(vx[0] + vx[1] + vx[2] + vx[3]) / T(64) - T(1);     // hover.py:197-203
+    cy = T(0.25) * T(vy[0] + vy[1] + vy[2] + vy[3]) / T(64) - T(1);
+    area = apx / T(16384);                                              // :206
+    ratio = T(bmax - amin + 1) / T(jn - j0 + 1);                        // :209-213
+    return true;
+}
+
 // Observation of hover.py:237-272 into o[20]; updates the feature memory.  Returns visible.
 template <typename T>
 __device__ __forceinline__ bool observe(Drone<T>& d, T roll, T pitch, T yaw, T a0, T a1, T a2, T a3,
-                                        T (&o)[kObsWords]) {
+                                        T (&o)[kObsWords], int detector = 0) {
     o[0] = wrap_angle(roll - d.er) * C<T>::inv_agent_dt;   // hover.py:228-230
     o[1] = wrap_angle(pitch - d.ep) * C<T>::inv_agent_dt;
     o[2] = wrap_angle(yaw - d.eyaw) * C<T>::inv_agent_dt;
@@ -445,7 +584,7 @@ __device__ __forceinline__ bool observe(Drone<T>& d, T roll, T pitch, T yaw, T a
     o[5] = cr * cp * sy - sr * sp * cy;
     o[6] = cr * cp * cy + sr * sp * sy;
     T cx, cyy, area, ratio;
-    const bool vis = camera_features(d, cx, cyy, area, ratio);
+    const bool vis = detector ? camera_features_pixel(d, cx, cyy, area, ratio) : camera_features(d, cx, cyy, area, ratio);
     o[7] = cx; o[8] = cyy;                                 // hover.py:253-267
     o[9] = d.prev_cx; o[10] = d.prev_cy;
     o[11] = area; o[12] = d.prev_area;

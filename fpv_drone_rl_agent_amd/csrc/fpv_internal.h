@@ -34,6 +34,7 @@ struct StepArgs {
     T sigma;
     int32_t floor_check;
     int32_t domain_rand;  // yaw task: resample the airframe at every reset
+    int32_t detector;     // hover task: 0 analytic projection (SPEC §6), 1 pixel rules of hover.py:157-222 (SPEC §6b)
     // fused VecNormalize bookkeeping (all optional, fp32 handles only; see fpv_step_fused)
     uint8_t* done;       // [n] terminated | truncated
     float* ret;          // [n] discounted-return accumulator, updated in place
@@ -48,7 +49,7 @@ hipError_t launch_step(const StepArgs<T>& a, bool noise, hipStream_t s);
 template <typename T>
 hipError_t launch_reset(void* state, const void* tmpl, const uint8_t* mask, void* obs, int64_t n, hipStream_t s);
 template <typename T>
-hipError_t launch_init(void* state, void* tmpl, int64_t n, hipStream_t s);
+hipError_t launch_init(void* state, void* tmpl, int64_t n, int detector, hipStream_t s);
 template <typename T>
 hipError_t launch_convert(void* state, void* canon, int64_t n, bool to_canon, hipStream_t s);
 

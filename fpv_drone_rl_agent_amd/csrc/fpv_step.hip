@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kTile * TPB) void step_kernel(StepArgs<T> p) {
     T roll, pitch, yaw;
     euler_from_quat(d.qx, d.qy, d.qz, d.qw, roll, pitch, yaw);
     T o[kObsWords];
-    const bool vis = observe(d, roll, pitch, yaw, act.x, act.y, act.z, act.w, o);
+    const bool vis = observe(d, roll, pitch, yaw, act.x, act.y, act.z, act.w, o, p.detector);
     uint32_t bits;
     const T reward = reward_and_flags(d, roll, pitch, vis, o, act.x, act.y, act.z, act.w, p.floor_check != 0, bits);
     d.er = roll; d.ep = pitch; d.eyaw = yaw;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(2 * kTile) void step_kernel_pair(StepArgs<float> p)
     T roll, pitch, yaw;
     euler_from_quat(d.qx, d.qy, d.qz, d.qw, roll, pitch, yaw);
     T o[kObsWords];
-    const bool vis = observe(d, roll, pitch, yaw, act.x, act.y, act.z, act.w, o);
+    const bool vis = observe(d, roll, pitch, yaw, act.x, act.y, act.z, act.w, o, p.detector);
     uint32_t bits;
     const T reward = reward_and_flags(d, roll, pitch, vis, o, act.x, act.y, act.z, act.w, p.floor_check != 0, bits);
     d.er = roll; d.ep = pitch; d.eyaw = yaw;
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kTile) void reset_kernel(Vec4<T>* state, const T* t
 // reset template = spawn state + noise-free motor warm-up + first observation (SPEC §8);
 // evaluated once at fpv_create with the same device functions the step uses.
 template <typename T>
-__global__ void template_kernel(T* tmpl) {
+__global__ void template_kernel(T* tmpl, int detector) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Drone<T> d = {};
     d.pz = C<T>::z_rest;
@@ -359,7 +359,7 @@ __global__ void template_kernel(T* tmpl) {
     for (int k = 0; k < 20; ++k) thr += C<T>::alpha * (C<T>::pwm_idle - thr);  // hover.py:109-110
     d.t0 = d.t1 = d.t2 = d.t3 = thr;
     T o[kObsWords];
-    observe(d, T(0), T(0), T(0), T(0), T(0), T(0), T(0), o);                   // hover.py:112-113
+    observe(d, T(0), T(0), T(0), T(0), T(0), T(0), T(0), o, detector);         // hover.py:112-113
     const T s[kStateWords] = {d.px, d.py, d.pz, d.steps, d.qx, d.qy, d.qz, d.qw, d.vx, d.vy, d.vz, d.ep_ret,
                               d.wx, d.wy, d.wz, d.prev_area, d.t0, d.t1, d.t2, d.t3, d.ix, d.iy, d.iz,
                               d.prev_ratio, d.ex, d.ey, d.ez, d.prev_cx, d.er, d.ep, d.eyaw, d.prev_cy,
@@ -447,16 +447,16 @@ template hipError_t launch_reset<float>(void*, const void*, const uint8_t*, void
 template hipError_t launch_reset<double>(void*, const void*, const uint8_t*, void*, int64_t, hipStream_t);
 
 template <typename T>
-hipError_t launch_init(void* state, void* tmpl, int64_t n, hipStream_t s) {
+hipError_t launch_init(void* state, void* tmpl, int64_t n, int detector, hipStream_t s) {
     const int64_t tiles = (n + kTile - 1) / kTile;
-    hipLaunchKernelGGL(template_kernel<T>, dim3(1), dim3(64), 0, s, (T*)tmpl);
+    hipLaunchKernelGGL(template_kernel<T>, dim3(1), dim3(64), 0, s, (T*)tmpl, detector);
     const int64_t g = tiles * kGranules * kTile;
     hipLaunchKernelGGL(fill_kernel<T>, dim3((unsigned)((g + 255) / 256)), dim3(256), 0, s, (Vec4<T>*)state,
                        (const T*)tmpl, tiles);
     return hipGetLastError();
 }
-template hipError_t launch_init<float>(void*, void*, int64_t, hipStream_t);
-template hipError_t launch_init<double>(void*, void*, int64_t, hipStream_t);
+template hipError_t launch_init<float>(void*, void*, int64_t, int, hipStream_t);
+template hipError_t launch_init<double>(void*, void*, int64_t, int, hipStream_t);
 
 template <typename T>
 hipError_t launch_convert(void* state, void* canon, int64_t n, bool to_canon, hipStream_t s) {

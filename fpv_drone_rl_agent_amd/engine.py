@@ -26,7 +26,7 @@ class FpvEngine:
 
     def __init__(self, num_envs: int, device: int | str | torch.device = 0, *, render: bool = False,
                  noise_ratio: float = 0.02, seed: int = 0, id_offset: int = 0, precision: str = "f32",
-                 ledger_capacity: int = 0, task: str = "hover", domain_rand: bool = False):
+                 ledger_capacity: int = 0, task: str = "hover", domain_rand: bool = False, detector: str = "analytic"):
         if not torch.cuda.is_available():
             raise RuntimeError("FpvEngine needs a HIP device: the MI355X extension has no CPU fallback")
         self.lib = L.load()
@@ -41,9 +41,13 @@ class FpvEngine:
         if task not in ("hover", "yaw"):
             raise ValueError("task must be 'hover' (simulation/hover.py) or 'yaw' (simulation/yaw.py)")
         self.task = task
+        if detector not in ("analytic", "pixel"):
+            raise ValueError("detector must be 'analytic' (docs/SPEC.md §6) or 'pixel' (the 128 x 128 rules of hover.py:157-222, §6b)")
+        self.detector = detector
         cfg = L.FpvConfig(self.num_envs, dev.index or 0, L.FPV_F64 if self._f64 else L.FPV_F32,
                           0 if render else 1, L.TASK_YAW if task == "yaw" else L.TASK_HOVER, float(noise_ratio),
-                          int(seed), int(id_offset), int(ledger_capacity), 1 if domain_rand else 0, 0)
+                          int(seed), int(id_offset), int(ledger_capacity), 1 if domain_rand else 0,
+                          L.DETECTOR_PIXEL if detector == "pixel" else L.DETECTOR_ANALYTIC)
         h = C.c_void_p()
         L.check(self.lib.fpv_create(C.byref(cfg), C.byref(h)), "fpv_create")
         self._h = h

@@ -68,8 +68,17 @@ typedef struct {
     uint64_t id_offset;      /* global id of drone 0: rank * num_envs */
     int64_t ledger_capacity; /* done-ledger rows (rounded up to a multiple of the tile count); 0 = 2 * num_envs */
     int32_t domain_rand;     /* FPV_TASK_YAW: per-drone mass / drag resampled at every reset (BASELINE cfg 5) */
-    int32_t reserved1;
+    int32_t detector;        /* fpv_detector: how obs[7..15] of the hover task come out of the camera pose (hover.py:157-222) */
 } fpv_config;
+
+/* The reference renders a 128 x 128 image and runs OpenCV's contour calls on it (hover.py:157-222).  Neither a renderer
+ * nor OpenCV is part of this path: FPV_DETECTOR_ANALYTIC projects the panel's corners and takes centre / area /
+ * bounding-box ratio of the continuous quadrilateral (docs/SPEC.md §6); FPV_DETECTOR_PIXEL applies the reference's rules
+ * on the pixel grid — coverage by pixel centres, border rule, integer boundingRect, contourArea of the pixel contour,
+ * the four approxPolyDP vertices (SPEC §6b; from the reset pose it reproduces hover.py:50-51's target_area = 0.013 and
+ * target_ratio = 1.53).  The yaw task's target_center stays analytic (its sphere detector is missing from the
+ * reference). */
+typedef enum { FPV_DETECTOR_ANALYTIC = 0, FPV_DETECTOR_PIXEL = 1 } fpv_detector;
 
 /* Device-side view of the done ledger (SB3 VecEnv `infos[i]["terminal_observation"]`,
  * `["TimeLimit.truncated"]`, Monitor `["episode"] = {r, l}` — SURVEY.md §8a A11).

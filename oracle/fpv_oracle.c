@@ -178,6 +178,150 @@ int fpv_oracle_camera(const double pos[3], const double quat[4], double center[2
     return 1;
 }
 
+/* ------------------------------------------------------------------ pixel detector (SPEC §6b)
+ * hover.py:157-222 on a 128 x 128 rendering of the panel, restated without a renderer and without OpenCV (neither is
+ * on disk: PARITY UNPINNED for cv2's contour rules).  Coverage: a pixel is red when its centre (i + 0.5, j + 0.5) lies in
+ * the projected front face.  From the row spans [a_j, b_j]: the border rule (:180-185), cv2.boundingRect's integer w / h
+ * (:209-213), cv2.contourArea of the 8-connected outer contour = the polygon through the boundary pixels (:206), its
+ * arcLength, and a stand-in for approxPolyDP's four vertices (:189-203): the covered pixel nearest to each projected
+ * corner, accepted when every vertex lies farther than epsilon = 0.04 * arcLength from the diagonal of the other two.
+ * The reference's own constants pin the convention: from the reset pose this gives w / h = 20 / 13 = 1.538 and
+ * area = 207 / 16384 = 0.01263, i.e. hover.py:50-51's target_ratio = 1.53 and target_area = 0.013. */
+static int row_span(const double u[4], const double v[4], const double slope[4], int j, int* a, int* b) {
+    double y = j + 0.5, xl = 0.0, xr = 0.0;
+    int n = 0;
+    for (int k = 0; k < 4; ++k) {
+        int m = (k + 1) & 3;
+        if ((v[k] <= y) != (v[m] <= y)) {                 /* the edge crosses this row of pixel centres */
+            double x = u[k] + (y - v[k]) * slope[k];
+            if (n == 0) { xl = xr = x; }
+            else { if (x < xl) xl = x; if (x > xr) xr = x; }
+            ++n;
+        }
+    }
+    if (n < 2) return 0;
+    double fa = ceil(xl - 0.5), fb = floor(xr - 0.5);
+    if (fa < 0.0) fa = 0.0;
+    if (fb > 127.0) fb = 127.0;
+    if (fa > fb) return 0;
+    *a = (int)fa; *b = (int)fb;
+    return 1;
+}
+
+/* dbg (may be NULL): spans[128][2] (a, b; -1 for empty rows), then 8 vertex coordinates, arcLength, contour area */
+static int camera_pixel(const double pos[3], const double quat[4], double center[2], double* area, double* ratio,
+                        double* dbg) {
+    static const double CY[4] = {1.0, -1.0, -1.0, 1.0};
+    static const double CZ[4] = {-1.0, -1.0, 1.0, 1.0};
+    double R[3][3];
+    rotmat(quat, R);
+    double c = cos(CAM_TILT_DEG * M_PI / 180.0), s = sin(CAM_TILT_DEG * M_PI / 180.0);
+    double u[4], v[4];
+    int ok = 1;
+    center[0] = center[1] = 0.0; *area = 0.0; *ratio = 0.0;
+    for (int j = 0; j < 4; ++j) {
+        double dw[3] = {PANEL_X - pos[0], CY[j] - pos[1], PANEL_ZC + CZ[j] - pos[2]};
+        double db[3];
+        for (int i = 0; i < 3; ++i) db[i] = R[0][i] * dw[0] + R[1][i] * dw[1] + R[2][i] * dw[2];
+        double depth = c * db[0] + s * db[2];
+        double up = -s * db[0] + c * db[2];
+        double right = -db[1];
+        if (!(depth > 0.1)) { ok = 0; depth = 1.0; }
+        double k = 64.0 / depth;
+        u[j] = 64.0 + k * right;
+        v[j] = 64.0 - k * up;
+    }
+    if (!ok) return 0;
+    double slope[4];                                      /* du / dv of the four edges (unused when an edge is level) */
+    for (int j = 0; j < 4; ++j) {
+        int m = (j + 1) & 3;
+        slope[j] = v[m] != v[j] ? (u[m] - u[j]) / (v[m] - v[j]) : 0.0;
+    }
+    double vmin = v[0], vmax = v[0];
+    for (int j = 1; j < 4; ++j) { if (v[j] < vmin) vmin = v[j]; if (v[j] > vmax) vmax = v[j]; }
+    double flo = ceil(vmin - 0.5), fhi = floor(vmax - 0.5);
+    if (flo < 0.0) flo = 0.0;
+    if (fhi > 127.0) fhi = 127.0;
+    if (!(flo <= fhi)) return 0;
+    int jlo = (int)flo, jhi = (int)fhi;
+    if (dbg) for (int i = 0; i < 256; ++i) dbg[i] = -1.0;
+    /* pass over the rows: bounding box, contour area and length, border rule, 8-connectivity */
+    int j0 = -1, jn = -1, amin = 128, bmax = -1, pa = 0, pb = 0, border = 0, broken = 0;
+    double apx = 0.0, len = 0.0;
+    for (int j = jlo; j <= jhi; ++j) {
+        int a, b;
+        if (!row_span(u, v, slope, j, &a, &b)) continue;               /* (a sliver between two pixel centres) */
+        if (dbg) { dbg[2 * j] = a; dbg[2 * j + 1] = b; }
+        if (j0 >= 0 && jn != j - 1) broken = 1;                 /* an empty row inside the blob */
+        if (j0 < 0) { j0 = j; len += (double)(b - a); }
+        else {
+            if (a > pb + 1 || b < pa - 1) broken = 1;           /* not 8-connected to the row above */
+            double ml = (a > pa ? a : pa) - (a != pa ? 0.5 : 0.0);
+            double mr = (b < pb ? b : pb) + (b != pb ? 0.5 : 0.0);
+            if (mr > ml) apx += mr - ml;
+            int da = a > pa ? a - pa : pa - a, db = b > pb ? b - pb : pb - b;
+            len += (da == 0 ? 1.0 : 1.4142135623730951 + (double)(da - 1)) + (db == 0 ? 1.0 : 1.4142135623730951 + (double)(db - 1));
+        }
+        if (a == 0 || b == 127 || j == 0 || j == 127) border = 1;      /* hover.py:180-185 */
+        if (a < amin) amin = a;
+        if (b > bmax) bmax = b;
+        jn = j; pa = a; pb = b;
+    }
+    if (j0 < 0 || broken || border) return 0;
+    len += (double)(pb - pa);                                           /* the bottom row's run */
+    /* the four vertices: covered pixel nearest to each projected corner (rows within one of the corner's own) */
+    int vx[4], vy[4];
+    for (int k = 0; k < 4; ++k) {
+        double fr = floor(v[k]);                                        /* row whose centre is nearest to v: round(v - 0.5) */
+        int jc = (int)(fr < (double)j0 ? j0 : (fr > (double)jn ? jn : fr));
+        double best = 1e300;
+        for (int dj = -1; dj <= 1; ++dj) {
+            int j = jc + dj, a, b;
+            if (j < j0 || j > jn) continue;
+            row_span(u, v, slope, j, &a, &b);
+            double fx = floor(u[k]);
+            int x = (int)(fx < (double)a ? a : (fx > (double)b ? b : fx));
+            double dx = x + 0.5 - u[k], dy = j + 0.5 - v[k], d2 = dx * dx + dy * dy;
+            if (d2 < best) { best = d2; vx[k] = x; vy[k] = j; }
+        }
+    }
+    if (dbg) {
+        for (int k = 0; k < 4; ++k) { dbg[256 + 2 * k] = vx[k]; dbg[257 + 2 * k] = vy[k]; }
+        dbg[264] = len; dbg[265] = apx;
+    }
+    /* approxPolyDP's 4-vertex gate: Douglas-Peucker starts from the two farthest points of the contour (the longer
+     * diagonal) and adds a vertex on either side only if it lies farther than eps from that chord */
+    double eps = 0.04 * len;
+    {
+        double d02 = (double)((vx[2] - vx[0]) * (vx[2] - vx[0]) + (vy[2] - vy[0]) * (vy[2] - vy[0]));
+        double d13 = (double)((vx[3] - vx[1]) * (vx[3] - vx[1]) + (vy[3] - vy[1]) * (vy[3] - vy[1]));
+        int p = d02 >= d13 ? 0 : 1, q = p + 2;                           /* the longer diagonal's ends */
+        double ex = vx[q] - vx[p], ey = vy[q] - vy[p], el = sqrt(ex * ex + ey * ey);
+        if (!(el > 0.0)) return 0;
+        for (int k = p + 1; k < p + 4; k += 2) {
+            int m = k & 3;
+            double dist = fabs(ex * (vy[m] - vy[p]) - ey * (vx[m] - vx[p])) / el;
+            if (!(dist > eps)) return 0;
+        }
+    }
+    center[0] = 0.25 * (double)(vx[0] + vx[1] + vx[2] + vx[3]) / 64.0 - 1.0;      /* hover.py:197-203 */
+    center[1] = 0.25 * (double)(vy[0] + vy[1] + vy[2] + vy[3]) / 64.0 - 1.0;
+    *area = apx / 16384.0;                                                           /* :206 */
+    *ratio = (double)(bmax - amin + 1) / (double)(jn - j0 + 1);                      /* :209-213 */
+    return 1;
+}
+
+int fpv_oracle_camera_pixel(const double pos[3], const double quat[4], double center[2], double* area,
+                            double* ratio) {
+    return camera_pixel(pos, quat, center, area, ratio, NULL);
+}
+
+/* test hook: the same, also returning the row spans, the four vertices, arcLength and the contour area in pixels */
+int fpv_oracle_camera_pixel_debug(const double pos[3], const double quat[4], double center[2], double* area,
+                                  double* ratio, double dbg[266]) {
+    return camera_pixel(pos, quat, center, area, ratio, dbg);
+}
+
 /* ------------------------------------------------------------------ reward (SPEC §7) */
 double fpv_oracle_reward(const double pos[3], const double euler[3], double omega_z,
                          const double center[2], double area, double ratio, int visible,
@@ -308,10 +452,11 @@ static void substep_p(const fpv_oracle_cfg* cfg, fpv_oracle_state* s, const doub
 /* ------------------------------------------------------------------ observation (SPEC §6) */
 static void observe(fpv_oracle_state* s, const double euler[3], const double action[4],
                     double obs[FPV_ORACLE_OBS_WORDS], double center[2], double* area, double* ratio,
-                    int* visible) {
+                    int* visible, int detector) {
     for (int i = 0; i < 3; ++i) obs[i] = fpv_oracle_wrap(euler[i] - s->prev_euler[i]) / AGENT_DT; /* :228-230 */
     fpv_oracle_quat_from_euler(euler, obs + 3);                                                 /* :233 */
-    *visible = fpv_oracle_camera(s->pos, s->quat, center, area, ratio);
+    *visible = detector ? fpv_oracle_camera_pixel(s->pos, s->quat, center, area, ratio)
+                        : fpv_oracle_camera(s->pos, s->quat, center, area, ratio);
     obs[7] = center[0]; obs[8] = center[1];           /* hover.py:253-267 */
     obs[9] = s->prev_center[0]; obs[10] = s->prev_center[1];
     obs[11] = *area; obs[12] = s->prev_area;
@@ -323,7 +468,7 @@ static void observe(fpv_oracle_state* s, const double euler[3], const double act
     s->prev_ratio = *ratio;
 }
 
-void fpv_oracle_reset_state(fpv_oracle_state* s, double obs[FPV_ORACLE_OBS_WORDS]) {
+void fpv_oracle_reset_state_d(fpv_oracle_state* s, double obs[FPV_ORACLE_OBS_WORDS], int detector) {
     /* hover.py:72-114, SPEC §8; prev_action is preserved (hover.py:101 vs :357) */
     double keep[4];
     memcpy(keep, s->prev_action, sizeof keep);
@@ -337,8 +482,10 @@ void fpv_oracle_reset_state(fpv_oracle_state* s, double obs[FPV_ORACLE_OBS_WORDS
     double euler[3] = {0, 0, 0}, zero[4] = {0, 0, 0, 0}, c[2], a, r;
     int vis;
     double tmp[FPV_ORACLE_OBS_WORDS];
-    observe(s, euler, zero, obs ? obs : tmp, c, &a, &r, &vis);      /* hover.py:112-113 */
+    observe(s, euler, zero, obs ? obs : tmp, c, &a, &r, &vis, detector); /* hover.py:112-113 */
 }
+
+void fpv_oracle_reset_state(fpv_oracle_state* s, double obs[FPV_ORACLE_OBS_WORDS]) { fpv_oracle_reset_state_d(s, obs, 0); }
 
 uint32_t fpv_oracle_step_one(const fpv_oracle_cfg* cfg, fpv_oracle_state* s, const double action[4],
                              uint64_t drone_id, uint64_t agent_tick, double obs[FPV_ORACLE_OBS_WORDS],
@@ -350,7 +497,7 @@ uint32_t fpv_oracle_step_one(const fpv_oracle_cfg* cfg, fpv_oracle_state* s, con
     double euler[3], center[2], area, ratio;
     int visible;
     fpv_oracle_euler_from_quat(s->quat, euler);
-    observe(s, euler, action, obs, center, &area, &ratio, &visible); /* hover.py:351 */
+    observe(s, euler, action, obs, center, &area, &ratio, &visible, cfg->detector); /* hover.py:351 */
     uint32_t info;
     *reward = fpv_oracle_reward(s->pos, euler, s->omega[2], center, area, ratio, visible, action,
                                 s->prev_action, s->step_count, cfg->floor_check, &info); /* :352 */
@@ -362,12 +509,16 @@ uint32_t fpv_oracle_step_one(const fpv_oracle_cfg* cfg, fpv_oracle_state* s, con
 }
 
 /* ------------------------------------------------------------------ batch */
-void fpv_oracle_reset_batch(int64_t n, double* state, double* obs, const uint8_t* mask) {
+void fpv_oracle_reset_batch_d(int64_t n, double* state, double* obs, const uint8_t* mask, int detector) {
     fpv_oracle_state* st = (fpv_oracle_state*)state;
     for (int64_t i = 0; i < n; ++i) {
         if (mask && !mask[i]) continue;
-        fpv_oracle_reset_state(&st[i], obs ? obs + i * FPV_ORACLE_OBS_WORDS : NULL);
+        fpv_oracle_reset_state_d(&st[i], obs ? obs + i * FPV_ORACLE_OBS_WORDS : NULL, detector);
     }
+}
+
+void fpv_oracle_reset_batch(int64_t n, double* state, double* obs, const uint8_t* mask) {
+    fpv_oracle_reset_batch_d(n, state, obs, mask, 0);
 }
 
 void fpv_oracle_step_batch(const fpv_oracle_cfg* cfg, int64_t n, double* state, const double* actions,
@@ -392,7 +543,7 @@ void fpv_oracle_step_batch(const fpv_oracle_cfg* cfg, int64_t n, double* state, 
             memcpy(tobs + i * FPV_ORACLE_OBS_WORDS, o, FPV_ORACLE_OBS_WORDS * sizeof(double));
             tret[i] = st[i].ep_return;
             bits[i] |= ((uint32_t)st[i].step_count) << 8;
-            fpv_oracle_reset_state(&st[i], o);                        /* SPEC §8 auto-reset */
+            fpv_oracle_reset_state_d(&st[i], o, cfg->detector);       /* SPEC §8 auto-reset */
         }
     }
     if (led_count) {

@@ -54,6 +54,8 @@ typedef struct {
     double noise_ratio;    /* cf2x.yaml:5 (0.02) or 0 for noise-free KATs */
     uint64_t seed;         /* Philox key */
     uint64_t id_offset;    /* global id of drone 0 (rank offset) */
+    int32_t detector;      /* 0: analytic projection (SPEC §6), 1: 128 x 128 pixel rules of hover.py:157-222 (SPEC §6b) */
+    int32_t reserved;
 } fpv_oracle_cfg;
 
 /* info bits written to the done ledger and by fpv_oracle_reward */
@@ -72,6 +74,12 @@ void fpv_oracle_scale_action(const double a[4], double sp[4]);      /* hover.py:
 /* SPEC §6: returns visible (0/1); center[2], area, ratio */
 int fpv_oracle_camera(const double pos[3], const double quat[4], double center[2], double* area,
                       double* ratio);
+/* SPEC §6b: the same through the 128 x 128 pixel rules of hover.py:157-222 (cv2's rules restated: parity unpinned) */
+int fpv_oracle_camera_pixel(const double pos[3], const double quat[4], double center[2], double* area,
+                            double* ratio);
+/* test hook: dbg = row spans [128][2] (-1 = empty), 4 vertices (x, y), arcLength, contour area [px^2] */
+int fpv_oracle_camera_pixel_debug(const double pos[3], const double quat[4], double center[2], double* area,
+                                  double* ratio, double dbg[266]);
 /* SPEC §7 / hover.py:274-332.  Returns reward, writes info bits. */
 double fpv_oracle_reward(const double pos[3], const double euler[3], double omega_z,
                          const double center[2], double area, double ratio, int visible,
@@ -79,7 +87,8 @@ double fpv_oracle_reward(const double pos[3], const double euler[3], double omeg
                          int floor_check, uint32_t* info);
 
 /* ---- one drone ---- */
-void fpv_oracle_reset_state(fpv_oracle_state* s, double obs[FPV_ORACLE_OBS_WORDS]);
+void fpv_oracle_reset_state(fpv_oracle_state* s, double obs[FPV_ORACLE_OBS_WORDS]);     /* detector 0 */
+void fpv_oracle_reset_state_d(fpv_oracle_state* s, double obs[FPV_ORACLE_OBS_WORDS], int detector);
 /* one physics sub-step k (SPEC §4); pwm[4] is carried between the even and odd sub-step */
 void fpv_oracle_substep(const fpv_oracle_cfg* cfg, fpv_oracle_state* s, const double sp[4],
                         double pwm[4], int k, uint64_t drone_id, uint64_t tick);
@@ -93,7 +102,8 @@ uint32_t fpv_oracle_step_one(const fpv_oracle_cfg* cfg, fpv_oracle_state* s, con
  * Done ledger (ascending drone index): led_idx[], led_info[] (bits | ep_len << 8),
  * led_ret[], led_obs[][20]; *led_count is read as the current fill and advanced.
  * nthreads > 1 uses OpenMP over drones. */
-void fpv_oracle_reset_batch(int64_t n, double* state, double* obs, const uint8_t* mask_or_null);
+void fpv_oracle_reset_batch(int64_t n, double* state, double* obs, const uint8_t* mask_or_null);   /* detector 0 */
+void fpv_oracle_reset_batch_d(int64_t n, double* state, double* obs, const uint8_t* mask_or_null, int detector);
 void fpv_oracle_step_batch(const fpv_oracle_cfg* cfg, int64_t n, double* state, const double* actions,
                            uint64_t agent_tick, double* obs, double* reward, uint8_t* terminated,
                            uint8_t* truncated, int64_t* led_count, int32_t* led_idx,

@@ -37,7 +37,7 @@ def build(force: bool = False) -> str:
 
 class _Cfg(C.Structure):
     _fields_ = [("floor_check", C.c_int32), ("domain_rand", C.c_int32), ("noise_ratio", C.c_double),
-                ("seed", C.c_uint64), ("id_offset", C.c_uint64)]
+                ("seed", C.c_uint64), ("id_offset", C.c_uint64), ("detector", C.c_int32), ("reserved", C.c_int32)]
 
 
 _lib = None
@@ -56,6 +56,7 @@ def lib():
         _lib.fpv_oracle_reward.argtypes = [dp, dp, C.c_double, dp, C.c_double, C.c_double, C.c_int,
                                            dp, dp, C.c_double, C.c_int, C.POINTER(C.c_uint32)]
         _lib.fpv_oracle_camera.restype = C.c_int
+        _lib.fpv_oracle_camera_pixel.restype = C.c_int
         _lib.fpv_oracle_step_one.restype = C.c_uint32
         _lib.fpv_oracle_version.restype = C.c_int
     return _lib
@@ -69,8 +70,13 @@ def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
-def make_cfg(floor_check=True, noise_ratio=0.02, seed=0, id_offset=0, domain_rand=False):
-    return _Cfg(int(bool(floor_check)), int(bool(domain_rand)), float(noise_ratio), int(seed), int(id_offset))
+DETECTORS = {"analytic": 0, "pixel": 1}
+
+
+def make_cfg(floor_check=True, noise_ratio=0.02, seed=0, id_offset=0, domain_rand=False, detector="analytic"):
+    """detector: "analytic" (SPEC §6) or "pixel" (the 128 x 128 rules of hover.py:157-222, SPEC §6b)."""
+    return _Cfg(int(bool(floor_check)), int(bool(domain_rand)), float(noise_ratio), int(seed), int(id_offset),
+                DETECTORS[detector] if isinstance(detector, str) else int(detector), 0)
 
 
 # ---------------------------------------------------------------- small pieces
@@ -113,12 +119,25 @@ def scale_action(a):
     return sp
 
 
-def camera(pos, quat):
+def camera(pos, quat, detector="analytic"):
     pos, quat = _f64(pos), _f64(quat)
     c = np.zeros(2)
     area, ratio = C.c_double(), C.c_double()
-    vis = lib().fpv_oracle_camera(_dp(pos), _dp(quat), _dp(c), C.byref(area), C.byref(ratio))
+    fn = lib().fpv_oracle_camera_pixel if DETECTORS.get(detector, detector) else lib().fpv_oracle_camera
+    vis = fn(_dp(pos), _dp(quat), _dp(c), C.byref(area), C.byref(ratio))
     return int(vis), c, area.value, ratio.value
+
+
+def camera_pixel_debug(pos, quat):
+    """(visible, center, area, ratio, spans {row: (a, b)}, vertices [4][2], arcLength, contour area in pixels)."""
+    pos, quat = _f64(pos), _f64(quat)
+    c = np.zeros(2)
+    dbg = np.full(266, -1.0)
+    area, ratio = C.c_double(), C.c_double()
+    lib().fpv_oracle_camera_pixel_debug.restype = C.c_int
+    vis = lib().fpv_oracle_camera_pixel_debug(_dp(pos), _dp(quat), _dp(c), C.byref(area), C.byref(ratio), _dp(dbg))
+    spans = {j: (int(dbg[2 * j]), int(dbg[2 * j + 1])) for j in range(128) if dbg[2 * j] >= 0}
+    return int(vis), c, area.value, ratio.value, spans, dbg[256:264].reshape(4, 2).astype(int), dbg[264], dbg[265]
 
 
 def reward(pos, euler, omega_z, center, area, ratio, visible, action, prev_action, step_count,
@@ -132,18 +151,18 @@ def reward(pos, euler, omega_z, center, area, ratio, visible, action, prev_actio
 
 
 # ---------------------------------------------------------------- state / batch
-def reset_states(n):
+def reset_states(n, detector="analytic"):
     """n freshly reset drones.  Returns (state [n,36], obs [n,20])."""
     st = np.zeros((n, STATE_WORDS))
     obs = np.zeros((n, OBS_WORDS))
-    lib().fpv_oracle_reset_batch(C.c_int64(n), _dp(st), _dp(obs), None)
+    lib().fpv_oracle_reset_batch_d(C.c_int64(n), _dp(st), _dp(obs), None, C.c_int(DETECTORS.get(detector, detector)))
     return st, obs
 
 
-def reset_masked(state, obs, mask):
+def reset_masked(state, obs, mask, detector="analytic"):
     m = np.ascontiguousarray(mask, dtype=np.uint8)
-    lib().fpv_oracle_reset_batch(C.c_int64(state.shape[0]), _dp(state), _dp(obs),
-                                 m.ctypes.data_as(C.POINTER(C.c_uint8)))
+    lib().fpv_oracle_reset_batch_d(C.c_int64(state.shape[0]), _dp(state), _dp(obs),
+                                   m.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int(DETECTORS.get(detector, detector)))
 
 
 def step_one(cfg, state_row, action, drone_id, agent_tick):
