@@ -59,7 +59,7 @@ def main():
         if args.save:
             from fpv_drone_rl_agent_amd.checkpoint import save_model, save_normalizer
             save_model(args.save, model)
-            save_normalizer(args.save + ".pkl", col)
+            save_normalizer(args.save + ".pkl", col, format="npz")   # the reference's file name (train_hover.py:63), this build's npz archive
             print("saved", args.save + ".zip", args.save + ".pkl")
 
 

@@ -35,7 +35,7 @@ class FpvLedger(C.Structure):
 
 class FpvStepExtras(C.Structure):
     _fields_ = [("done", C.c_void_p), ("ret", C.c_void_p), ("partials", C.c_void_p), ("gamma", C.c_float),
-                ("reserved", C.c_int32)]
+                ("reserved", C.c_int32), ("obs_rms", C.c_void_p), ("ret_rms", C.c_void_p), ("snapshot", C.c_void_p)]
 
 
 PARTIAL_WORDS = 44

@@ -60,8 +60,34 @@ def load_policy_state(path: str, map_location="cpu") -> tuple[dict, dict]:
     return state, data
 
 
-def save_normalizer(path: str, collector) -> None:
+_PKL_HELP = ("SB3's VecNormalize.save writes a Python pickle of the wrapper object at this path; this build stores the "
+             "statistics as an npz archive (no SB3 in the image, and pickles execute code on load).  ")
+
+
+def check_stats_save_path(path: str, fmt) -> None:
+    """A `.pkl` path gets the npz archive only on request: a reference user who opens it with SB3 would otherwise meet an
+    opaque unpickling error (train_hover.py:27,63 / test_hover.py:8 exchange real pickles)."""
+    if fmt not in (None, "npz"):
+        raise ValueError("format must be None or 'npz'")
+    if path.endswith(".pkl") and fmt != "npz":
+        raise ValueError(_PKL_HELP + "Pass format='npz' to write that archive under the reference's .pkl file name "
+                         "(what CheckpointCallback does), or save to a .npz path.")
+
+
+def open_stats_archive(path: str):
+    """np.load of a statistics archive, with a clear error for a real pickle (SB3's own file)."""
+    with open(path, "rb") as f:
+        head = f.read(4)
+    if head[:2] != b"PK":                                   # npz = zip container
+        what = "a Python pickle" if head[:1] == b"\x80" else "not an npz archive"
+        raise ValueError(f"{path} is {what}.  " + _PKL_HELP + "Re-export the statistics with VecNormalize.save(path, format='npz') "
+                         "from this build; a file written by stable-baselines3 cannot be read here.")
+    return np.load(path, allow_pickle=False)
+
+
+def save_normalizer(path: str, collector, format=None) -> None:
     """model.env.save(path) — the rollout collector's VecNormalize statistics, vec_env.VecNormalize.load-compatible."""
+    check_stats_save_path(path, format)
     rms, rr = collector.obs_norm.rms.cpu().numpy(), collector.rew_norm.rms.cpu().numpy()
     d = collector.obs_norm.dim
     with open(path, "wb") as f:
@@ -72,7 +98,7 @@ def save_normalizer(path: str, collector) -> None:
 
 
 def load_normalizer(path: str, collector) -> None:
-    z = np.load(path, allow_pickle=False)
+    z = open_stats_archive(path)
     rms = np.concatenate([z["obs_mean"], z["obs_var"], [z["obs_count"]]])
     collector.obs_norm.rms.copy_(torch.from_numpy(rms))
     collector.rew_norm.rms.copy_(torch.tensor([float(z["ret_mean"]), float(z["ret_var"]), float(z["ret_count"])],
@@ -95,7 +121,7 @@ class CheckpointCallback:
             name = checkpoint_name(self.name_prefix, model.num_timesteps, model.logger)
             path = os.path.join(self.save_path, name)
             save_model(path, model)                                     # :26
-            save_normalizer(path.replace(".zip", ".pkl"), model.col)    # :27
+            save_normalizer(path.replace(".zip", ".pkl"), model.col, format="npz")    # :27 (the reference's file name)
             self._last_checkpoint_step = model.num_timesteps
             self.saved.append(path)
             if self.verbose > 0:

@@ -38,6 +38,7 @@ struct fpv_env {
     void* state;         // [tiles][9][64] granules
     void* tmpl;          // 56 reals
     uint64_t* tick;      // device [tiles]
+    uint32_t* merge_ticket;   // device counter of the in-launch statistics merge (zero between launches)
     uint32_t* led_count;
     int32_t* led_idx;
     uint32_t* led_info;
@@ -100,8 +101,25 @@ static int step_impl(fpv_env* e, const T* actions, T* obs, T* reward, uint8_t* t
     a.ret = ex ? ex->ret : nullptr;
     a.partials = ex ? ex->partials : nullptr;
     a.gamma = ex ? ex->gamma : 0.0f;
-    if (e->cfg.task == FPV_TASK_YAW) FPV_HIP(launch_yaw_step<T>(a, e->cfg.noise_ratio != 0.0, (hipStream_t)stream));
-    else FPV_HIP(launch_step<T>(a, e->cfg.noise_ratio != 0.0, (hipStream_t)stream));
+    const bool want_merge = ex && (ex->obs_rms || ex->ret_rms);
+    if (want_merge && !ex->partials) return fail(FPV_ERR_ARG, "fpv_step_fused: obs_rms / ret_rms need partials");
+    a.mg_ticket = want_merge ? e->merge_ticket : nullptr;
+    a.mg_obs_rms = want_merge ? ex->obs_rms : nullptr;
+    a.mg_ret_rms = want_merge ? ex->ret_rms : nullptr;
+    a.mg_snapshot = want_merge ? ex->snapshot : nullptr;
+    a.mg_count = (double)e->cfg.num_envs;
+    bool merged = false;
+    if (e->cfg.task == FPV_TASK_YAW) FPV_HIP(launch_yaw_step<T>(a, e->cfg.noise_ratio != 0.0, (hipStream_t)stream, &merged));
+    else FPV_HIP(launch_step<T>(a, e->cfg.noise_ratio != 0.0, (hipStream_t)stream, &merged));
+    if (want_merge && !merged) {
+        // launch shapes without the in-kernel reducer (one tile per workgroup, the wave-pair kernel): the merge kernel
+        int64_t rows = e->cfg.task == FPV_TASK_YAW ? yaw_partial_rows(e->cfg.num_envs)
+                                                   : step_partial_rows(e->cfg.num_envs, e->cfg.noise_ratio != 0.0);
+        double* scratch = nullptr;
+        if (int rc = scratch_for_current_device(&scratch)) return rc;
+        FPV_HIP(launch_moments_merge_tiles(rows, ex->partials, (double)e->cfg.num_envs, nullptr, nullptr, ex->obs_rms, ex->ret_rms,
+                                           ex->snapshot, scratch, e->obs_words, (hipStream_t)stream));
+    }
     return FPV_OK;
 }
 
@@ -161,6 +179,7 @@ int fpv_create(const fpv_config* cfg, fpv_env** out) {
     alloc(&e->state, (size_t)e->tiles * e->granules * kTile * 4 * e->word);
     alloc(&e->tmpl, (size_t)(kStateWords + kObsWords) * e->word);
     alloc((void**)&e->tick, (size_t)e->tiles * sizeof(uint64_t));
+    alloc((void**)&e->merge_ticket, 64);
     alloc((void**)&e->led_count, (size_t)e->tiles * sizeof(uint32_t));
     alloc((void**)&e->led_idx, (size_t)e->led_cap * sizeof(int32_t));
     alloc((void**)&e->led_info, (size_t)e->led_cap * sizeof(uint32_t));
@@ -168,6 +187,7 @@ int fpv_create(const fpv_config* cfg, fpv_env** out) {
     alloc(&e->led_ret, (size_t)e->led_cap * e->word);
     alloc(&e->led_obs, (size_t)e->led_cap * kObsWords * e->word);
     if (err == hipSuccess) err = hipMemset(e->tick, 0, (size_t)e->tiles * sizeof(uint64_t));
+    if (err == hipSuccess) err = hipMemset(e->merge_ticket, 0, 64);
     if (err == hipSuccess) err = hipMemset(e->led_count, 0, (size_t)e->tiles * sizeof(uint32_t));
     if (err == hipSuccess) {
         if (yaw)
@@ -191,7 +211,7 @@ int fpv_create(const fpv_config* cfg, fpv_env** out) {
 
 int fpv_destroy(fpv_env* e) {
     if (!e) return FPV_OK;
-    void* own[] = {e->state, e->tmpl, e->tick};
+    void* own[] = {e->state, e->tmpl, e->tick, e->merge_ticket};
     for (void* p : own)
         if (p) (void)hipFree(p);
     if (e->led_owned) {

@@ -444,24 +444,21 @@ __device__ __forceinline__ bool camera_features(const Drone<T>& d, T& cx, T& cy,
 // tests/test_detector_cpu.py.  The arithmetic and its order are those of SPEC §6b (the CPU checker follows the same text).
 template <typename T>
 __device__ __forceinline__ bool row_span(const T (&u)[4], const T (&v)[4], const T (&slope)[4], int j, int& a, int& b) {
+    // branch-free: the four edge tests run for every lane of the wave alike (crossings come in pairs on a closed polygon,
+    // so "at least two" = "any")
     const T y = T(j) + T(0.5);
-    T xl = T(0), xr = T(0);
-    int n = 0;
+    T xl = T(1e30), xr = T(-1e30);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int m = (k + 1) & 3;
-        if ((v[k] <= y) != (v[m] <= y)) {
-            const T x = u[k] + (y - v[k]) * slope[k];
-            if (n == 0) { xl = x; xr = x; }
-            else { xl = min_(xl, x); xr = max_(xr, x); }
-            ++n;
-        }
+        const bool cross = (v[k] <= y) != (v[m] <= y);
+        const T x = u[k] + (y - v[k]) * slope[k];
+        xl = cross ? min_(xl, x) : xl;
+        xr = cross ? max_(xr, x) : xr;
     }
-    if (n < 2) return false;
     const T fa = max_(ceil_(xl - T(0.5)), T(0)), fb = min_(floor_(xr - T(0.5)), T(127));
-    if (fa > fb) return false;
     a = (int)fa; b = (int)fb;
-    return true;
+    return xl <= xr && fa <= fb;
 }
 
 template <typename T>
@@ -508,7 +505,9 @@ __device__ __forceinline__ bool camera_features_pixel(const Drone<T>& d, T& cx, 
     int j0 = -1, jn = -1, amin = 128, bmax = -1, pa = 0, pb = 0;
     bool border = false, broken = false;
     T apx = T(0), len = T(0);
-    for (int j = jlo; j <= jhi; ++j) {
+    // rows are counted from each lane's own first row, so a wave iterates max(blob height), not the union of row ranges
+    for (int t = 0; t <= jhi - jlo; ++t) {
+        const int j = jlo + t;
         int a, b;
         if (!row_span(u, v, slope, j, a, b)) continue;                  // (a sliver between two pixel centres)
         if (j0 >= 0 && jn != j - 1) broken = true;                      // an empty row inside the blob

@@ -40,12 +40,109 @@ struct StepArgs {
     float* ret;          // [n] discounted-return accumulator, updated in place
     double* partials;    // [tiles][kPartialWords] per-tile sums
     float gamma;
+    // optional: the workgroup that finishes LAST folds this launch's partial rows into the running statistics
+    // (step_merge_tail below; four-tiles-per-workgroup variants only — launch_step / launch_yaw_step say whether they did)
+    uint32_t* mg_ticket;  // device counter, zero between launches; null = no merge in this launch
+    double* mg_obs_rms;   // [2 O + 1] {mean, var, count}, updated in place; may be null
+    double* mg_ret_rms;   // [3], updated in place; may be null
+    double* mg_snapshot;  // [kPartialWords] {obs statistics from word 0, ret statistics at 41..43} after the merge; may be null
+    double mg_count;      // batch count of this step (= n)
 };
 
 constexpr int kPartialWords = 44;  // sum obs[20], sum obs^2[20], sum ret, sum ret^2, 2 pad
 
+// ---- VecNormalize statistics merge by the last workgroup of the env-step launch ----
+// The rollout step is policy -> env step -> RunningMeanStd.update with the step's moment sums, and the next policy
+// launch needs the result.  Folding the rows in every policy workgroup's prologue (merge_prologue below) cost that
+// launch 6.5 k cycles back to back and more inside the rollout graph, where the table was just written by other XCDs.
+// Here the env-step workgroups publish their row write-through (sc1 stores, drained), take a ticket, and the workgroup
+// whose ticket is the last one folds the whole table — fixed order, so the result does not depend on which workgroup
+// it is — and updates the statistics in place; the policy launch then reads 41 doubles.  Hand-off per
+// cdna_hip_programming.md Guideline 16 (R1 with the ticket form): every byte of the rows stored sc1 and drained before
+// the storing workgroup's ticket add; every load of them in the reducer an sc1 load, after its own ticket add returned
+// and a workgroup barrier.  The rows are rewritten by every launch; the ticket is reset by the reducer.
+__device__ __forceinline__ void row_store_sc1(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double row_load_sc1(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// Called by EVERY thread of the workgroup at the end of the kernel, after the workgroup's row has been stored with
+// row_store_sc1 and each storing wave has executed s_waitcnt vmcnt(0).  xch: >= 4 P doubles of LDS.
+// nrows = gridDim.x (one row per workgroup), O = observation words, P = 2 O + 4.
+template <typename Args>
+__device__ __forceinline__ void step_merge_tail(const Args& p, const double* rows, int O, double* xch) {
+    const int P = 2 * O + 4, tid = threadIdx.x, nrows = gridDim.x;
+    int* flag = reinterpret_cast<int*>(xch);
+    __syncthreads();                                   // the storing wave's drain precedes the ticket (and xch is free)
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(p.mg_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = t == (unsigned)nrows - 1u;
+    }
+    __syncthreads();
+    const bool last = *flag != 0;
+    __syncthreads();                                   // everyone has read the flag before xch is reused
+    if (!last) return;
+    int ways = (int)blockDim.x / P;
+    if (ways > 4) ways = 4;                            // xch holds four rows
+    const int j = tid / P, c = tid - j * P;
+    if (j < ways) {
+        double acc = 0.0;
+        for (int b0 = j; b0 < nrows; b0 += 8 * ways) {  // eight rows in flight per thread, added in row order
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int b = b0 + q * ways;
+                v[q] = b < nrows ? row_load_sc1(rows + (int64_t)b * P + c) : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += v[q];
+        }
+        xch[j * P + c] = acc;
+    }
+    __syncthreads();
+    if (tid < P) {
+        double t = 0.0;
+        for (int w = 0; w < ways; ++w) t += xch[w * P + tid];
+        xch[tid] = t;                                  // way 0's slots <- column sums (each thread its own column)
+    }
+    __syncthreads();
+    // RunningMeanStd.update (SB3): every thread works out its new values from the old statistics first, a barrier, then
+    // the stores (the count word is read by all O threads)
+    const double bc = p.mg_count;
+    const bool do_obs = tid < O && p.mg_obs_rms != nullptr, do_ret = tid == 2 * O && p.mg_ret_rms != nullptr;
+    double nm = 0.0, nv = 0.0, tot = 0.0;
+    if (do_obs || do_ret) {
+        const double cnt = do_obs ? p.mg_obs_rms[2 * O] : p.mg_ret_rms[2];
+        const double mean = do_obs ? p.mg_obs_rms[tid] : p.mg_ret_rms[0];
+        const double var = do_obs ? p.mg_obs_rms[O + tid] : p.mg_ret_rms[1];
+        const double bm = (do_obs ? xch[tid] : xch[2 * O]) / bc;
+        double bv = (do_obs ? xch[O + tid] : xch[2 * O + 1]) / bc - bm * bm;
+        if (bv < 0.0) bv = 0.0;
+        const double delta = bm - mean;
+        tot = cnt + bc;
+        nm = mean + delta * bc / tot;
+        nv = (var * cnt + bv * bc + delta * delta * cnt * bc / tot) / tot;
+    }
+    __syncthreads();
+    if (do_obs) {
+        p.mg_obs_rms[tid] = nm; p.mg_obs_rms[O + tid] = nv;
+        if (p.mg_snapshot) { p.mg_snapshot[tid] = nm; p.mg_snapshot[O + tid] = nv; }
+        if (tid == 0) { p.mg_obs_rms[2 * O] = tot; if (p.mg_snapshot) p.mg_snapshot[2 * O] = tot; }
+    }
+    if (do_ret) {
+        p.mg_ret_rms[0] = nm; p.mg_ret_rms[1] = nv; p.mg_ret_rms[2] = tot;
+        if (p.mg_snapshot) { p.mg_snapshot[41] = nm; p.mg_snapshot[42] = nv; p.mg_snapshot[43] = tot; }
+    }
+    if (tid == 0) __hip_atomic_store(p.mg_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+}
+
+// *merged (may be null) is set to true when the launch folded the statistics itself (a.mg_ticket given and honoured)
 template <typename T>
-hipError_t launch_step(const StepArgs<T>& a, bool noise, hipStream_t s);
+hipError_t launch_step(const StepArgs<T>& a, bool noise, hipStream_t s, bool* merged = nullptr);
 template <typename T>
 hipError_t launch_reset(void* state, const void* tmpl, const uint8_t* mask, void* obs, int64_t n, hipStream_t s);
 template <typename T>
@@ -55,7 +152,7 @@ hipError_t launch_convert(void* state, void* canon, int64_t n, bool to_canon, hi
 
 // fpv_yaw.hip
 template <typename T>
-hipError_t launch_yaw_step(const StepArgs<T>& a, bool noise, hipStream_t s);
+hipError_t launch_yaw_step(const StepArgs<T>& a, bool noise, hipStream_t s, bool* merged = nullptr);
 template <typename T>
 hipError_t launch_yaw_reset(void* state, const uint64_t* tick, const uint8_t* mask, void* obs, int64_t n, uint64_t seed,
                             uint64_t id_offset, int domain_rand, int all_lanes, hipStream_t s);

@@ -172,9 +172,16 @@ __global__ __launch_bounds__(kTile * TPB) void step_kernel(StepArgs<T> p) {
                                  rows, lane, TPB > 1 ? bsum + wv * kPartialWords : p.partials + tile * kPartialWords);
                 if constexpr (TPB == 4) {
                     __syncthreads();
-                    if (wv == 0 && lane < kPartialWords)
-                        p.partials[(int64_t)blockIdx.x * kPartialWords + lane] =
-                            (bsum[lane] + bsum[kPartialWords + lane]) + (bsum[2 * kPartialWords + lane] + bsum[3 * kPartialWords + lane]);
+                    if (wv == 0 && lane < kPartialWords) {
+                        const double v = (bsum[lane] + bsum[kPartialWords + lane]) + (bsum[2 * kPartialWords + lane] + bsum[3 * kPartialWords + lane]);
+                        double* row = p.partials + (int64_t)blockIdx.x * kPartialWords + lane;
+                        if (p.mg_ticket) row_store_sc1(row, v);      // write-through: read by the last workgroup of this launch
+                        else *row = v;
+                    }
+                    if (p.mg_ticket) {                                  // uniform
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        step_merge_tail(p, p.partials, kObsWords, bsum);
+                    }
                 }
             }
         }
@@ -401,9 +408,16 @@ int64_t g_pair_max_tiles = 512;   // step_kernel_pair up to 32 768 drones: P and
                                   // (measured: -14 % at 4 096, -5 % at 32 768, tie at 65 536, +30 % at 131 072)
 
 template <typename T>
-hipError_t launch_step(const StepArgs<T>& a, bool noise, hipStream_t s) {
+hipError_t launch_step(const StepArgs<T>& a_in, bool noise, hipStream_t s, bool* merged) {
+    StepArgs<T> a = a_in;
     const int64_t tiles = (a.n + kTile - 1) / kTile;
     const bool fused = a.done || a.ret || a.partials;
+    // the in-launch statistics merge exists in the four-tiles-per-workgroup variant; the reducer holds <= 1 024 rows' worth
+    // of sums per thread-way comfortably (tiles / 4 <= 4 096)
+    const bool pair = sizeof(T) == 4 && noise && g_pair_max_tiles > 0 && tiles <= g_pair_max_tiles;
+    const bool can_merge = sizeof(T) == 4 && fused && a.partials && a.mg_ticket && !pair && tiles % 4 == 0 && tiles / 4 <= 4096;
+    if (!can_merge) a.mg_ticket = nullptr;
+    if (merged) *merged = can_merge;
     if constexpr (sizeof(T) == 4) {
         // few enough tiles that the chip would sit at one wave per SIMD: physics wave + helper wave per tile
         if (noise && g_pair_max_tiles > 0 && tiles <= g_pair_max_tiles) {
@@ -433,8 +447,8 @@ int64_t step_partial_rows(int64_t n, bool noise) {
     return tiles % 4 == 0 ? tiles / 4 : tiles;
 }
 
-template hipError_t launch_step<float>(const StepArgs<float>&, bool, hipStream_t);
-template hipError_t launch_step<double>(const StepArgs<double>&, bool, hipStream_t);
+template hipError_t launch_step<float>(const StepArgs<float>&, bool, hipStream_t, bool*);
+template hipError_t launch_step<double>(const StepArgs<double>&, bool, hipStream_t, bool*);
 
 template <typename T>
 hipError_t launch_reset(void* state, const void* tmpl, const uint8_t* mask, void* obs, int64_t n, hipStream_t s) {

@@ -169,9 +169,16 @@ __global__ __launch_bounds__(kTile * TPB) void yaw_step_kernel(StepArgs<T> p) {
                                                TPB > 1 ? bsum + wv * kRow : p.partials + tile * kRow);
                 if constexpr (TPB == 4) {
                     __syncthreads();
-                    if (wv == 0 && lane < kRow)
-                        p.partials[(int64_t)blockIdx.x * kRow + lane] =
-                            (bsum[lane] + bsum[kRow + lane]) + (bsum[2 * kRow + lane] + bsum[3 * kRow + lane]);
+                    if (wv == 0 && lane < kRow) {
+                        const double v = (bsum[lane] + bsum[kRow + lane]) + (bsum[2 * kRow + lane] + bsum[3 * kRow + lane]);
+                        double* row = p.partials + (int64_t)blockIdx.x * kRow + lane;
+                        if (p.mg_ticket) row_store_sc1(row, v);      // write-through: read by the last workgroup of this launch
+                        else *row = v;
+                    }
+                    if (p.mg_ticket) {                                  // uniform
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        step_merge_tail(p, p.partials, kYawObsWords, bsum);
+                    }
                 }
             }
         }
@@ -219,9 +226,13 @@ __global__ void yaw_convert_kernel(Vec4<T>* state, T* canon, int64_t n) {
 
 // ---------------------------------------------------------------- launchers
 template <typename T>
-hipError_t launch_yaw_step(const StepArgs<T>& a, bool noise, hipStream_t s) {
+hipError_t launch_yaw_step(const StepArgs<T>& a_in, bool noise, hipStream_t s, bool* merged) {
+    StepArgs<T> a = a_in;
     const int64_t tiles = (a.n + kTile - 1) / kTile;
     const bool fused = a.done || a.ret || a.partials;
+    const bool can_merge = sizeof(T) == 4 && fused && a.partials && a.mg_ticket && tiles % 4 == 0 && tiles / 4 <= 4096;
+    if (!can_merge) a.mg_ticket = nullptr;             // (the in-launch merge lives in the four-tiles-per-workgroup variant)
+    if (merged) *merged = can_merge;
     if constexpr (sizeof(T) == 4) {
         if (fused) {
             if (tiles % 4 == 0) {               // four tiles per workgroup, one partial row per workgroup (yaw_partial_rows)
@@ -243,8 +254,8 @@ int64_t yaw_partial_rows(int64_t n) {
     const int64_t tiles = (n + kTile - 1) / kTile;
     return tiles % 4 == 0 ? tiles / 4 : tiles;
 }
-template hipError_t launch_yaw_step<float>(const StepArgs<float>&, bool, hipStream_t);
-template hipError_t launch_yaw_step<double>(const StepArgs<double>&, bool, hipStream_t);
+template hipError_t launch_yaw_step<float>(const StepArgs<float>&, bool, hipStream_t, bool*);
+template hipError_t launch_yaw_step<double>(const StepArgs<double>&, bool, hipStream_t, bool*);
 
 template <typename T>
 hipError_t launch_yaw_reset(void* state, const uint64_t* tick, const uint8_t* mask, void* obs, int64_t n, uint64_t seed,

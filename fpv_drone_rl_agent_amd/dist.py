@@ -8,6 +8,7 @@ never a ring of our own.
 """
 from __future__ import annotations
 
+import datetime
 import os
 
 import torch
@@ -24,11 +25,12 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        timeout = datetime.timedelta(seconds=int(os.environ.get("FPV_DIST_TIMEOUT_S", "300")))
         if backend == "nccl":
             torch.cuda.set_device(local)
-            td.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            td.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=timeout)
         else:
-            td.init_process_group(backend, rank=rank, world_size=world)
+            td.init_process_group(backend, rank=rank, world_size=world, timeout=timeout)
     return rank, world, local
 
 

@@ -124,10 +124,13 @@ class FpvEngine:
         L.check(self.lib.fpv_partial_rows(self._h, C.byref(r)), "fpv_partial_rows")
         return int(r.value)
 
-    def step_fused(self, actions, *, done=None, ret=None, partials=None, gamma: float = 0.99, obs=None, reward=None):
+    def step_fused(self, actions, *, done=None, ret=None, partials=None, gamma: float = 0.99, obs=None, reward=None,
+                   obs_rms=None, ret_rms=None, snapshot=None):
         """fpv_step_fused: the env step plus VecNormalize's per-step bookkeeping (done mask, discounted-return
         accumulator, moment sums in the first `partial_rows` rows of partials [tiles, 2 * obs_words + 4]) in the same
-        kernel.  fp32 engines only."""
+        kernel.  obs_rms / ret_rms (float64 {mean, var, count}) are updated in place with this step's sums inside the
+        same call — by the launch's last workgroup where the launch shape allows, else by the merge kernel — and
+        snapshot receives the statistics as they stand afterwards.  fp32 engines only."""
         if self._f64:
             raise ValueError("step_fused runs on fp32 engines")
         if partials is not None and (partials.dtype != torch.float64 or not partials.is_contiguous()
@@ -139,8 +142,16 @@ class FpvEngine:
             raise ValueError(f"actions must be a contiguous [num_envs, {self.act_words}] device tensor of the engine's dtype")
         obs = self.obs if obs is None else obs
         reward = self.reward if reward is None else reward
+        for name, t, words in (("obs_rms", obs_rms, 2 * self.obs_words + 1), ("ret_rms", ret_rms, 3), ("snapshot", snapshot, 44)):
+            if t is not None and (t.dtype != torch.float64 or t.device != self.device or not t.is_contiguous() or t.numel() < words):
+                raise ValueError(f"{name} must be a contiguous float64 device tensor of at least {words} words")
+        if (obs_rms is not None or ret_rms is not None) and partials is None:
+            raise ValueError("obs_rms / ret_rms (the in-call statistics update) need partials")
         ex = L.FpvStepExtras(done.data_ptr() if done is not None else None, ret.data_ptr() if ret is not None else None,
-                             partials.data_ptr() if partials is not None else None, float(gamma), 0)
+                             partials.data_ptr() if partials is not None else None, float(gamma), 0,
+                             obs_rms.data_ptr() if obs_rms is not None else None,
+                             ret_rms.data_ptr() if ret_rms is not None else None,
+                             snapshot.data_ptr() if snapshot is not None else None)
         L.check(self.lib.fpv_step_fused(self._h, _ptr(actions), _ptr(obs), _ptr(reward), _ptr(self.terminated),
                                         _ptr(self.truncated), C.byref(ex), _stream(self.device)), "fpv_step_fused")
         return obs, reward, self.terminated, self.truncated

@@ -3,7 +3,8 @@ N = 1 view of the batched MI355X engine.
 
 Same constructor keywords, spaces, return arity / types / info keys.  Differences that follow from
 the engine (docs/SPEC.md): physics is the build's written spec (PyFlyt parity unpinned), camera
-features are analytic, and `reset()` is a constant-state overwrite instead of rebuilding a
+features come from the projected panel (`detector="analytic"`) or from the reference's pixel rules
+restated without a renderer (`detector="pixel"`), and `reset()` is a constant-state overwrite instead of rebuilding a
 simulator (the reference spends ~0.5 s there).
 """
 from __future__ import annotations
@@ -25,7 +26,7 @@ class QuadXHoverEnv(_EnvBase):
     metadata = {"render_modes": []}
 
     def __init__(self, flight_mode: int = 0, agent_hz: int = 40, render: bool = False, *, device=0,
-                 noise_ratio: float = 0.02, seed: int = 0):
+                 noise_ratio: float = 0.02, seed: int = 0, detector: str = "analytic"):
         if _EnvBase is not object:
             super().__init__()
         if flight_mode != 0:
@@ -41,7 +42,8 @@ class QuadXHoverEnv(_EnvBase):
         self.target_area, self.target_ratio = 0.013, 1.53                        # hover.py:49-51
         self.action_space = spaces.hover_action_space()
         self.observation_space = spaces.hover_observation_space()
-        self._engine = FpvEngine(1, device, render=render, noise_ratio=noise_ratio, seed=seed, ledger_capacity=4)
+        self._engine = FpvEngine(1, device, render=render, noise_ratio=noise_ratio, seed=seed, ledger_capacity=4,
+                                 detector=detector)      # "pixel": the 128 x 128 rules of hover.py:157-222 (SPEC §6b)
         self._act = torch.zeros((1, 4), dtype=torch.float32, device=self._engine.device)
         self.info = {"out_of_bounds": False, "collision": False, "env_complete": False, "on_floor": False}
         self.termination = self.truncation = False

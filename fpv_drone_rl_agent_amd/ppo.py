@@ -13,6 +13,9 @@ minibatch (156 KB - latency-bound on xGMI, so no bucketing and no ring of our ow
 """
 from __future__ import annotations
 
+import os
+import sys
+
 import torch
 import torch.distributed as td
 
@@ -121,8 +124,19 @@ class PPO:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._g_out = step(*self._g_in)
+        try:
+            with torch.cuda.graph(g):
+                self._g_out = step(*self._g_in)
+        except Exception as exc:                # e.g. a collective library that refuses stream capture
+            if D.world_size() == 1:
+                raise
+            # the minibatch holds the gradient all-reduce: fall back to eager launches for the rest of the run (every
+            # rank issues the same collectives either way, so ranks that captured and ranks that did not stay matched)
+            self._graph_failed = True
+            g = None
+            if D.rank() == 0:
+                print(f"fpv PPO: capturing the minibatch (with its all-reduce) into a HIP graph failed ({exc!r}); "
+                      "running it eagerly.  FPV_GRAPH_COLLECTIVES=0 selects this path up front.", file=sys.stderr, flush=True)
         self.policy.load_state_dict(saved[0])
         if saved[1]["state"]:
             self.opt.load_state_dict(saved[1])
@@ -146,7 +160,10 @@ class PPO:
         total = T * N
         mb = total // self.n_minibatches
         dev = obs.device
-        graph = self.use_graph and not (D.world_size() > 1 and td.get_backend() == "gloo")
+        # HIP-graph replay of the minibatch: off under the gloo rehearsal backend, off when the collective must stay outside
+        # any captured graph (FPV_GRAPH_COLLECTIVES=0: the first-RCCL-run escape hatch), off after a failed capture
+        graph = self.use_graph and not getattr(self, "_graph_failed", False) and not (
+            D.world_size() > 1 and (td.get_backend() == "gloo" or os.environ.get("FPV_GRAPH_COLLECTIVES", "1") == "0"))
         if self.fused_update:
             if self._adv_n is None or self._adv_n.numel() != total:
                 self._adv_n = torch.empty(total, dtype=torch.float32, device=dev)
@@ -165,6 +182,7 @@ class PPO:
                               [torch.zeros((mb, obs.shape[1]), dtype=f32, device=dev), torch.zeros((mb, act.shape[1]), dtype=f32, device=dev),
                                torch.zeros((mb,), dtype=f32, device=dev), torch.zeros((mb,), dtype=f32, device=dev),
                                torch.zeros((mb,), dtype=f32, device=dev)], dev)
+        graph = graph and not getattr(self, "_graph_failed", False)
         stats = []
         for epoch in range(self.n_epochs):
             perm = torch.randperm(total, device=dev, generator=self._gen)

@@ -14,11 +14,11 @@ Every per-step operation is asynchronous device work on one stream; the T-step l
 captured once into a HIP graph and replayed, so the host issues one launch per rollout.
 
 Two step implementations:
-  * fused (default): THREE kernels per step — fpv_policy_forward (normalise -> pi, V on fp32 MFMA ->
-    sample -> log-prob -> clip, writing straight into the rollout buffer), fpv_step_fused (env step +
-    done mask + discounted return + per-tile moment sums), fpv_moments_merge (both running statistics
-    + a snapshot).  Reward scaling is applied once per rollout (fpv_reward_finalize) with each step's
-    own statistics snapshot, which is arithmetically what VecNormalize does step by step.
+  * fused (default): TWO kernels per step — fpv_policy_forward (RunningMeanStd.update of both statistics
+    with the previous step's moment sums in its prologue -> normalise -> pi, V on fp32 MFMA -> sample ->
+    log-prob -> clip, writing straight into the rollout buffer) and fpv_step_fused (env step + done mask +
+    discounted return + moment sums).  Reward scaling is applied once per rollout (fpv_reward_finalize)
+    with each step's own statistics snapshot, which is arithmetically what VecNormalize does step by step.
   * unfused (`fused=False`): the same semantics through torch ops + the stand-alone normaliser
     kernels; kept as the readable reference of the fused path (tests compare both to the oracle).
 """
@@ -52,7 +52,7 @@ class RolloutCollector:
                  lam: float = 0.95, norm_obs: bool = True, norm_reward: bool = True, use_graph: bool = True,
                  clip_obs: float = 10.0, clip_reward: float = 10.0, fused: bool = True, policy_seed: int = 0,
                  policy_gemm: str = "f32", overlap_critic: bool = False, merge_in_policy: bool = True,
-                 fused_step: bool = True):
+                 fused_step: bool = True, merge_in_step: bool = False):
         if engine.dtype != torch.float32:
             raise ValueError("the rollout collector runs on an fp32 engine")
         self.engine, self.policy = engine, policy
@@ -103,7 +103,15 @@ class RolloutCollector:
             self.overlap_critic = bool(overlap_critic) and policy_gemm == "f32"
             self._vstream = torch.cuda.Stream(dev) if self.overlap_critic else None
             # VecNormalize's statistics update inside the next policy launch (fpv_policy_io.merge_*): up to 1 024 tiles
-            self._merge_in_policy = (bool(merge_in_policy) and engine.tiles <= 1024 and (self.norm_obs or self.norm_reward)
+            # Where VecNormalize's statistics update runs.  Default: in the next policy launch's prologue (every policy
+            # workgroup folds the step's <= 1 024 rows in the same order).  merge_in_step=True: inside fpv_step_fused (its
+            # last workgroup folds the rows — write-through rows + ticket — or the merge kernel behind it for launch
+            # shapes without that reducer); measured at 65 536 drones the policy launch then drops 58.0 -> 55.9 us but the
+            # env step grows 16.1 -> 23.0 us (the reducer's ticket + eight dependent sc1 round trips sit on the step's
+            # tail), 72.5 -> 77.1 us per rollout step, so it is not the default.  Both off: the stand-alone merge kernel.
+            self._merge_in_step = bool(merge_in_step) and (self.norm_obs or self.norm_reward)
+            self._merge_in_policy = (not self._merge_in_step and bool(merge_in_policy) and engine.tiles <= 1024
+                                     and (self.norm_obs or self.norm_reward)
                                      and not self.overlap_critic)   # (the table is <= 1 024 rows by construction)
             self._obs_rms_alt = torch.zeros_like(self.obs_norm.rms)
             self._ret_rms_alt = torch.zeros_like(self.rew_norm.rms)
@@ -194,6 +202,11 @@ class RolloutCollector:
             self.fp.forward(eng.obs, rms=rms, tick=eng.tick_ptr, obs_n=self.buf_obs[t], action=self.buf_act[t],
                             clipped=self.clipped, value=self.buf_val[t], logp=self.buf_logp[t],
                             clip_obs=self.obs_norm.clip, eps_norm=self.obs_norm.eps)
+        if self._merge_in_step:
+            eng.step_fused(self.clipped, done=self._starts[t + 1], ret=self.rew_norm.ret, partials=self.partials,
+                           gamma=self.gamma, reward=self.raw_rew[t], obs_rms=self.obs_norm.rms if self.norm_obs else None,
+                           ret_rms=self.rew_norm.rms if self.norm_reward else None, snapshot=self.snap[t])
+            return
         eng.step_fused(self.clipped, done=self._starts[t + 1], ret=self.rew_norm.ret, partials=self.partials,
                        gamma=self.gamma, reward=self.raw_rew[t])
         if not self._merge_in_policy:

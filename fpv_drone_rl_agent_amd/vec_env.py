@@ -216,9 +216,12 @@ class VecNormalize:
         self.venv.close()
 
     # -- persistence (train_hover.py:27,63; test_hover.py:8) --------------------------------
-    def save(self, path: str) -> None:
-        """Statistics + switches as a .npz-format file at exactly `path` (SB3 pickles the wrapper
-        object; without SB3 in the image that format is not reproducible — INTEGRATION.md)."""
+    def save(self, path: str, format=None) -> None:
+        """Statistics + switches as an npz archive at exactly `path`.  SB3 pickles the wrapper object; without SB3 in the
+        image that format is not reproducible, so a `.pkl` path is refused unless format="npz" says the
+        archive is wanted under that name."""
+        from .checkpoint import check_stats_save_path
+        check_stats_save_path(path, format)
         d = self.obs_rms.dim
         rms, rr = self.obs_rms.rms.cpu().numpy(), self.ret_rms.rms.cpu().numpy()
         with open(path, "wb") as f:
@@ -228,7 +231,8 @@ class VecNormalize:
 
     @staticmethod
     def load(load_path: str, venv: FpvVecEnv) -> "VecNormalize":
-        z = np.load(load_path, allow_pickle=False)
+        from .checkpoint import open_stats_archive
+        z = open_stats_archive(load_path)       # raises a clear error for a real pickle (a file written by SB3)
         vn = VecNormalize(venv, norm_obs=bool(z["norm_obs"]), norm_reward=bool(z["norm_reward"]),
                           clip_obs=float(z["clip_obs"]), clip_reward=float(z["clip_reward"]), gamma=float(z["gamma"]),
                           epsilon=float(z["epsilon"]))

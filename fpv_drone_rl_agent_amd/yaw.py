@@ -14,10 +14,20 @@ import torch
 from .engine import FpvEngine
 from .spaces import Box
 
+try:  # pragma: no cover - gymnasium is not in the build image; the reference's class is a gymnasium.Env (yaw.py:25 via hover)
+    import gymnasium as _gym  # type: ignore
+    _EnvBase = _gym.Env
+except Exception:
+    _EnvBase = object
 
-class DroneEnv:
+
+class DroneEnv(_EnvBase):
+    metadata = {"render_modes": []}
+
     def __init__(self, render: bool = False, *, device=0, noise_ratio: float = 0.02, seed: int = 0,
                  domain_rand: bool = False):
+        if _EnvBase is not object:
+            super().__init__()
         self.render = render
         self.action_space = Box(low=-1.0, high=1.0, shape=(1,), dtype=np.float32)                    # yaw.py:37
         self.observation_space = Box(low=-np.ones(12, np.float32), high=np.ones(12, np.float32), shape=(12,),
@@ -30,6 +40,8 @@ class DroneEnv:
         self.step_count, self.termination, self.truncation, self.info = 0, False, False, {}
 
     def reset(self, seed=None, options=None):
+        if _EnvBase is not object:
+            super().reset(seed=seed)                # yaw.py:77: seeds gymnasium's RNG only
         obs = self._engine.reset()
         self._engine.ledger_clear()
         self.step_count, self.termination, self.truncation, self.info = 0, False, False, {}

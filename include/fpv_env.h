@@ -104,13 +104,24 @@ int fpv_destroy(fpv_env* env);
 
 /* QuadXHoverEnv.reset() — hover.py:72-114; VecEnv.reset().  mask (uint8[num_envs]) selects
  * drones, NULL = all.  obs [num_envs][20] receives the reset observation of the selected
- * drones (others untouched); obs may be NULL.  prev_action is preserved (hover.py:101). */
+ * drones (others untouched); obs may be NULL.  prev_action is preserved (hover.py:101).
+ * Deviation from SURVEY.md §8(b)'s sketch, on purpose: there is NO per-call seed argument.  The reference's reset(seed)
+ * seeds gymnasium's RNG only and never reaches the simulator (hover.py:73); here the reset state is a
+ * constant (noise-free warm-up, docs/SPEC.md §8) and every random draw of the path (motor noise, the yaw task's
+ * heading / airframe) is a counter-based Philox stream keyed by fpv_config.seed, the global drone id and the agent
+ * tick — reproducible across calls, ranks and shardings without a mutable RNG state to reseed. */
 int fpv_reset(fpv_env* env, const uint8_t* mask, void* obs, void* stream);
 
 /* QuadXHoverEnv.step() — hover.py:334-358 for every drone, with VecEnv auto-reset.
  * actions [num_envs][4] raw (unscaled, unclipped); obs [num_envs][20]; reward [num_envs];
  * terminated / truncated uint8 [num_envs] (FPV_TASK_YAW: actions [num_envs][1], obs [num_envs][12] —
- * simulation/yaw.py:102-149).  Float handles only. */
+ * simulation/yaw.py:102-149).  Float handles only.
+ * Deviation from SURVEY.md §8(b)'s sketch, on purpose: there is NO dense terminal_obs [num_envs][20] output.  SB3's
+ * infos[i]["terminal_observation"] exists only for the few drones whose episode ended in this step; a dense array would
+ * add 80 B per drone and step to a 382 B path for values that are almost always unused.  They go to the done ledger
+ * instead (fpv_ledger above): one compacted row per episode end — drone index, FPV_INFO_* bits, episode length,
+ * Monitor's episode return and the terminal observation — appended by the step's own wave with a ballot and no atomic;
+ * fpv_ledger_scan / fpv_ledger_scatter consume it on the device (timeout bootstrap), FpvVecEnv.step_wait on the host. */
 int fpv_step(fpv_env* env, const float* actions, float* obs, float* reward, uint8_t* terminated,
              uint8_t* truncated, void* stream);
 /* Same for an FPV_F64 handle (trajectory-level parity runs). */
@@ -133,6 +144,16 @@ typedef struct {
     double* partials;
     float gamma;
     int32_t reserved;
+    /* Optional: RunningMeanStd.update inside this call.  obs_rms = double[2 O + 1] {mean, var, count}, ret_rms = double[3],
+     * updated IN PLACE with this step's sums (batch count = num_envs); snapshot (double[FPV_PARTIAL_WORDS], may be NULL)
+     * receives {obs statistics from word 0, ret statistics at 41..43} as they stand after the update.  Needs partials.
+     * With four tiles per workgroup (num_envs % 256 == 0 and above the wave-pair threshold) the workgroup that finishes
+     * last folds the rows inside the same launch (write-through rows + a ticket; fixed summation order); other launch
+     * shapes run the merge kernel behind the step.  Either way the statistics are final when the call's work is done
+     * on the stream, which is what the next fpv_policy_forward reads. */
+    double* obs_rms;
+    double* ret_rms;
+    double* snapshot;
 } fpv_step_extras;
 int fpv_step_fused(fpv_env* env, const float* actions, float* obs, float* reward, uint8_t* terminated,
                    uint8_t* truncated, const fpv_step_extras* extras, void* stream);

@@ -71,3 +71,33 @@ def test_single_process_passthrough():
     assert g.shape == (1, 3)
     mean, std = D.merge_advantage_stats(g)
     assert float(mean) == 0.5 and abs(float(std) - (3.0 - 0.25) ** 0.5) < 1e-12
+
+
+def test_bench_launch_contract_under_torchrun_gloo():
+    """bench.py exactly as the driver launches it for N > 1 — `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` — in its GPU-free plumbing mode:
+    rendezvous from the environment, WORLD_SIZE == --gpus, the rollout length that makes exactly K steps, barrier-bracketed
+    timing with MAX over ranks, the one all-gather, ONE JSON line from rank 0 carrying the contract's keys."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "4",
+           "--plumbing-only"]
+    out = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    rec = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config"):
+        assert key in rec
+    assert rec["n_gpus"] == 2 and rec["steps"] == 20 and rec["scaling"] == "weak"
+    assert rec["config"]["n_steps"] == 20 and rec["config"]["total_drones"] == 2 * 65536
+    assert rec["plumbing"]["gathered_rows"] == 2 and rec["plumbing"]["max_elapsed_s"] >= 0.001   # rank 1's time won the MAX
+    # a world size that contradicts --gpus must fail loudly on every rank
+    bad = subprocess.run(cmd[:-7] + ["--gpus", "4", "--steps", "20", "--warmup", "4", "--plumbing-only"], cwd=root,
+                         capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stderr + bad.stdout)

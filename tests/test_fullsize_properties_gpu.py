@@ -85,6 +85,69 @@ def test_fullsize_shard_independence_and_oracle_sample(oracle):
     eng.close(); one.close()
 
 
+def test_benchmarked_kernel_matches_oracle_sample_including_auto_reset(oracle):
+    """The kernel bench.py times — fpv_step_fused at 65 536 drones with motor noise: step_kernel<float, true, true, 4>, four
+    tiles per workgroup, VecNormalize bookkeeping in the same pass — against the scalar oracle on a seeded sample of 256
+    drones from the same states, auto-reset rows INCLUDED (returned observation = reset observation, state = reset
+    state with prev_action kept, terminal observation and episode statistics in the ledger).  The finite-difference
+    rates obs[0:3] are compared as angle differences (x agent_dt, hover.py:230) at the 1e-5 bar."""
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.synthetic import synthetic_states
+    n, seed, gamma = 65536, 13, 0.99
+    st0 = synthetic_states(n, seed=2).astype(np.float32)
+    rng = np.random.default_rng(3)
+    pick = rng.choice(n, 256, replace=False)
+    # make a third of the sample end its episode in this step: past max_steps, outside the dome, on the floor line
+    k = len(pick) // 9
+    st0[pick[:k], 34] = 401                                        # hover.py:275 truncation
+    st0[pick[k:2 * k], 0:3] = np.array([2.2, 2.2, 1.2], np.float32)          # |pos| > 3 (hover.py:278-281)
+    st0[pick[2 * k:3 * k], 2] = 0.05; st0[pick[2 * k:3 * k], 34] = 100       # z < 0.1 after call 31 (hover.py:283-290)
+    act = (torch.rand(n, 4, device="cuda", generator=torch.Generator(device="cuda").manual_seed(4)) * 2 - 1)
+    ret_in = torch.rand(n, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    eng = FpvEngine(n, 0, seed=seed, noise_ratio=0.02, ledger_capacity=2 * n)
+    assert eng.partial_rows == n // 256                            # the four-tiles-per-workgroup variant is the one launched
+    eng.set_state(torch.from_numpy(st0))
+    eng.set_tick(9)
+    done = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    ret = ret_in.clone()
+    partials = torch.zeros((eng.partial_rows, 44), dtype=torch.float64, device="cuda")
+    raw = torch.zeros(n, device="cuda")
+    eng.step_fused(act, done=done, ret=ret, partials=partials, gamma=gamma, reward=raw)
+    torch.cuda.synchronize()
+    got_st, got_obs = eng.get_state().cpu().numpy(), eng.obs.cpu().numpy()
+    got_rew, got_done, got_ret = raw.cpu().numpy(), done.cpu().numpy(), ret.cpu().numpy()
+    led = eng.ledger_read()
+    led_row = {int(i): r for r, i in enumerate(led["idx"])}
+    cfg = oracle.make_cfg(noise_ratio=0.02, seed=seed)
+    a_np, r_in = act.cpu().numpy().astype(np.float64), ret_in.cpu().numpy().astype(np.float64)
+    tol = lambda a, b, t=1e-5: (np.abs(a - b) <= t * np.maximum(1.0, np.abs(b))).all()
+    ended = 0
+    for i in pick:
+        row = st0[i].astype(np.float64).copy()
+        obs_r, rew_r, bits = oracle.step_one(cfg, row, a_np[i], int(i), 9)
+        assert tol(got_rew[i], rew_r, 2e-5), i
+        assert got_done[i] == (1 if bits & 3 else 0)
+        r_acc = r_in[i] * gamma + rew_r
+        if bits & 3:
+            ended += 1
+            j = led_row[int(i)]
+            assert led["info"][j] & 0xFF == bits and led["info"][j] >> 8 == int(row[34])
+            t_obs = led["obs"][j].astype(np.float64)
+            assert tol(t_obs[3:], obs_r[3:]) and tol(t_obs[0:3] * 0.025, obs_r[0:3] * 0.025), i      # terminal observation
+            assert tol(led["ep_return"][j], row[35], 2e-5)
+            keep = row[30:34].copy()                               # prev_action survives reset (hover.py:101 vs :357)
+            rs, ro = oracle.reset_states(1)
+            rs[0, 30:34] = keep
+            assert tol(got_st[i], rs[0]) and tol(got_obs[i], ro[0]), i
+            assert got_ret[i] == 0.0
+        else:
+            assert tol(got_st[i], row), i
+            assert tol(got_obs[i, 3:], obs_r[3:]) and tol(got_obs[i, 0:3] * 0.025, obs_r[0:3] * 0.025), i
+            assert tol(got_ret[i], r_acc, 2e-5)
+    assert ended >= 3 * k - 2
+    eng.close()
+
+
 def test_reset_is_idempotent_and_total():
     from fpv_drone_rl_agent_amd.engine import FpvEngine
     eng = FpvEngine(65536, 0)

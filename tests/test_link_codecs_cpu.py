@@ -1,6 +1,10 @@
-"""CRSF / PPM codecs against restatements of controller/receive_telemetry.py and
-controller/send_controll_commands_through_jack.py written here in the test (the reference files import pyserial /
-sounddevice at module top and cannot be imported)."""
+"""CRSF / PPM codecs (controller/receive_telemetry.py, controller/send_controll_commands_through_jack.py)
+against committed input / output vectors (tests/golden/link_codecs_v1.json, made by tests/golden/make_link_codecs.py from
+the formats' definitions: CRC-8/DVB-S2 by polynomial division, channel packing as one 176-bit little-endian integer, the
+PPM frame as run lengths).  The reference files import pyserial / sounddevice at module top and cannot be imported."""
+import json
+import os
+
 import numpy as np
 import pytest
 from hypothesis import given, settings, strategies as st
@@ -8,44 +12,27 @@ from hypothesis import given, settings, strategies as st
 from fpv_drone_rl_agent_amd import deploy as D
 
 
-def ref_crc8(data):                      # receive_telemetry.py:24-37
-    crc = 0
-    for a in data:
-        crc ^= a
-        for _ in range(8):
-            crc = ((crc << 1) ^ 0xD5) if crc & 0x80 else (crc << 1)
-        crc &= 0xFF
-    return crc
+GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "link_codecs_v1.json")))
 
 
-def ref_pack(channels):                  # receive_telemetry.py:45-71
-    result, dest_shift, new_val = bytearray(), 0, 0
-    for ch in channels:
-        new_val |= (ch << dest_shift) & 0xFF
-        result.append(new_val)
-        src_bits_left = 11 - 8 + dest_shift
-        new_val = ch >> (11 - src_bits_left)
-        if src_bits_left >= 8:
-            result.append(new_val & 0xFF)
-            new_val >>= 8
-            src_bits_left -= 8
-        dest_shift = src_bits_left
-    return bytes(result)
-
-
-def test_crc8_dvb_s2_check_value_and_reference():
+def test_crc8_dvb_s2_check_value_and_vectors():
     assert D.crc8(b"123456789") == 0xBC                       # catalogue check value of CRC-8/DVB-S2
-    rng = np.random.default_rng(0)
-    for n in (0, 1, 5, 24, 64):
-        b = bytes(rng.integers(0, 256, n, dtype=np.uint8))
-        assert D.crc8(b) == ref_crc8(b)
+    for v in GOLD["crc8_dvb_s2"]:
+        assert D.crc8(bytes.fromhex(v["hex"])) == v["crc"]
+
+
+def test_channel_packing_matches_vectors():
+    for v in GOLD["rc_channels_packed"]:
+        packed = D.pack_channels(v["channels"])
+        assert len(packed) == 22 and packed.hex() == v["hex"]
+        assert D.unpack_channels(packed) == v["channels"]
 
 
 @settings(max_examples=200, deadline=None)
 @given(st.lists(st.integers(0, 0x7FF), min_size=16, max_size=16))
-def test_channel_packing_matches_reference_and_roundtrips(ch):
+def test_channel_packing_is_the_176_bit_little_endian_integer_and_roundtrips(ch):
     packed = D.pack_channels(ch)
-    assert len(packed) == 22 and packed == ref_pack(ch)
+    assert packed == sum(c << (11 * i) for i, c in enumerate(ch)).to_bytes(22, "little")
     assert D.unpack_channels(packed) == ch
 
 
@@ -60,14 +47,14 @@ def test_channel_bit_layout():
 def test_channels_frame_and_validation():
     f = D.channels_frame([992] * 16)                          # 1500 us in CRSF units
     assert len(f) == 26 and f[0] == 0xC8 and f[1] == 24 and f[2] == 0x16     # :74
-    assert f[-1] == ref_crc8(f[2:-1]) and D.validate(f)                      # :39-40, :76
+    assert f[-1] == D.crc8(f[2:-1]) and D.validate(f)                        # :39-40, :76 (crc8 itself: vectors above)
     bad = bytearray(f); bad[10] ^= 1
     assert not D.validate(bytes(bad))
 
 
 def _frame(ptype, payload):
     body = bytes([ptype]) + bytes(payload)
-    return bytes([0xC8, len(body) + 1]) + body + bytes([ref_crc8(body)])
+    return bytes([0xC8, len(body) + 1]) + body + bytes([D.crc8(body)])
 
 
 def test_stream_parser_resyncs_like_the_reference():
@@ -89,28 +76,11 @@ def test_stream_parser_resyncs_like_the_reference():
         D.decode_attitude(bat)
 
 
-def ref_ppm(values, invert=False):       # send_controll_commands_through_jack.py:19-66
-    us = lambda u: int(u * 48000 / 1_000_000)
-    hi, lo = (-0.8, 0.8) if invert else (0.8, -0.8)
-    parts, total = [], 0
-    for v in values:
-        v = int(np.clip(v, 700, 2300))
-        parts += [np.full(us(300), hi, np.float32), np.full(us(v - 300), lo, np.float32)]
-        total += v
-    parts.append(np.full(us(300), hi, np.float32))
-    total += 300
-    gap = 22.5 * 1000 - total
-    if gap < 3000:
-        gap = 4000
-    parts.append(np.full(us(gap), lo, np.float32))
-    return np.concatenate(parts)
-
-
-@pytest.mark.parametrize("values,invert", [([1500] * 8, False), ([1000, 2000, 1500, 700, 2300, 1234, 1777, 600], True),
-                                           ([2300] * 8, False)])
-def test_ppm_frame_matches_reference(values, invert):
-    w = D.ppm_frame(values, invert)
-    r = ref_ppm(values, invert)
-    assert w.shape == r.shape and np.array_equal(w, r)
-    if values == [1500] * 8:
+@pytest.mark.parametrize("case", range(len(GOLD["ppm_48k"])))
+def test_ppm_frame_matches_vectors(case):
+    v = GOLD["ppm_48k"][case]
+    w = D.ppm_frame(v["values"], v["invert"])
+    expect = np.concatenate([np.full(n, level, np.float32) for level, n in v["runs"]])
+    assert w.shape == expect.shape and np.array_equal(w, expect)
+    if v["values"] == [1500] * 8:
         assert abs(len(w) / 48000 - 0.0225) < 2e-4            # a 22.5 ms frame

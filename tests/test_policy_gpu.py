@@ -152,3 +152,32 @@ def test_single_net_launches_match_the_joint_launch(narrow):
     for k in ref:
         assert torch.equal(out[k], ref[k]), k
     assert torch.equal(lp, lp_ref) and torch.equal(v, v_ref)
+
+
+@pytest.mark.parametrize("n", [1, 17, 256, 5000, 65536, 200000])
+def test_w16_kernel_matches_the_two_wave_kernel_on_the_rollout_launch(n):
+    """gemm = "f32_w16" (fpv_policy_w16.hip: 16 drones per wave on 16x16x4 tiles, four waves per SIMD, LDS-DMA staging) against
+    the default kernel on the rollout's launch shape (both nets, in-kernel Philox sampling, normaliser on): the same draws
+    bit for bit, outputs to fp32 rounding (another summation order), every row, over repeated launches."""
+    m, ref = _setup(9, "f32")
+    _, w16 = _setup(9, "f32_w16")
+    g = torch.Generator(device="cuda").manual_seed(n)
+    rms = torch.cat([torch.randn(20, generator=g, device="cuda").double(),
+                     torch.rand(20, generator=g, device="cuda").double() * 4 + 0.1, torch.tensor([9.0], device="cuda").double()])
+    tick = torch.zeros(4, dtype=torch.int64, device="cuda")
+    for trial in range(6 if n >= 65536 else 2):
+        obs = torch.randn(n, 20, device="cuda", generator=g) * 3 + 1
+        tick += 1
+        outs = []
+        for k in (ref, w16):
+            o = {name: torch.zeros(n, d, device="cuda") for name, d in (("obs_n", 20), ("action", 4), ("clipped", 4), ("eps_out", 4))}
+            v, lp = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+            k.forward(obs, rms=rms, tick=tick, value=v, logp=lp, **o)
+            outs.append((o, v, lp))
+        (a, va, la), (b, vb, lb) = outs
+        assert torch.equal(a["eps_out"], b["eps_out"]) and torch.equal(a["obs_n"], b["obs_n"])
+        scale = max(1.0, float(a["action"].abs().max()))
+        assert float((a["action"] - b["action"]).abs().max()) <= 4e-6 * scale, trial
+        assert float((va - vb).abs().max()) <= 4e-6 * max(1.0, float(va.abs().max())), trial
+        assert torch.allclose(la, lb, atol=1e-5, rtol=1e-6)
+        assert torch.equal(b["clipped"], b["action"].clamp(-1, 1))

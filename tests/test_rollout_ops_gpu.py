@@ -117,3 +117,40 @@ def test_step_fused_bookkeeping_matches_unfused(oracle, n):
     out = ops.reward_finalize(raw, snap)
     assert torch.allclose(out, torch.stack(rew_a), atol=1e-5, rtol=1e-5)
     a_eng.close(); b_eng.close()
+
+
+@pytest.mark.parametrize("task,n", [("hover", 65536), ("hover", 262144), ("hover", 4096), ("hover", 1000), ("yaw", 65536), ("yaw", 1000)])
+def test_statistics_update_inside_step_fused_matches_the_merge_kernel(task, n):
+    """fpv_step_extras.obs_rms / ret_rms / snapshot: RunningMeanStd.update inside the env-step call — by the launch's last
+    workgroup (write-through rows + ticket) at 65 536 / 262 144 drones, by the merge kernel behind the step at the
+    other shapes — against fpv_step_fused + fpv_moments_merge as two calls.  Many consecutive launches, every one
+    compared: a stale row or a lost ticket would show as a wrong or missing update."""
+    from fpv_drone_rl_agent_amd import ops
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    yaw = task == "yaw"
+    O, A = (12, 1) if yaw else (20, 4)
+    engs = [FpvEngine(n, 0, seed=3, task=task, domain_rand=yaw, ledger_capacity=8 * n) for _ in range(2)]
+    g = torch.Generator(device="cuda").manual_seed(1)
+    stats = []
+    for e in engs:
+        stats.append({"done": torch.zeros(n, dtype=torch.uint8, device="cuda"), "ret": torch.zeros(n, device="cuda"),
+                      "part": torch.zeros((e.partial_rows, 2 * O + 4), dtype=torch.float64, device="cuda"),
+                      "raw": torch.zeros(n, device="cuda"),
+                      "obs_rms": torch.cat([torch.zeros(O), torch.ones(O), torch.tensor([1e-4])]).double().cuda(),
+                      "ret_rms": torch.tensor([0.0, 1.0, 1e-4], dtype=torch.float64, device="cuda"),
+                      "snap": torch.zeros(44, dtype=torch.float64, device="cuda")})
+    for it in range(40):
+        act = torch.rand(n, A, device="cuda", generator=g) * 2 - 1
+        a, b = stats
+        engs[0].step_fused(act, done=a["done"], ret=a["ret"], partials=a["part"], gamma=0.99, reward=a["raw"],
+                           obs_rms=a["obs_rms"], ret_rms=a["ret_rms"], snapshot=a["snap"])
+        engs[1].step_fused(act, done=b["done"], ret=b["ret"], partials=b["part"], gamma=0.99, reward=b["raw"])
+        ops.moments_merge(b["part"], n, obs_rms=b["obs_rms"], ret_rms=b["ret_rms"], snapshot=b["snap"])
+        for k, tol in (("obs_rms", 1e-11), ("ret_rms", 1e-11)):
+            assert torch.allclose(a[k], b[k], rtol=tol, atol=1e-13), (it, k, (a[k] - b[k]).abs().max())
+        assert torch.allclose(a["snap"][:2 * O + 1], b["snap"][:2 * O + 1], rtol=1e-11, atol=1e-13)
+        assert torch.allclose(a["snap"][41:44], b["snap"][41:44], rtol=1e-11, atol=1e-13)
+        assert torch.equal(a["part"], b["part"]) and torch.equal(engs[0].obs, engs[1].obs)
+    assert float(stats[0]["obs_rms"][2 * O]) == pytest.approx(1e-4 + 40 * n)
+    for e in engs:
+        e.close()

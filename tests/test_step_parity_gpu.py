@@ -2,8 +2,8 @@
 
 Bar (north_star): done masks bit-exact, float state within 1e-5 for a fixed seed.  The fp32
 kernel is compared single-step from identical states with |a-b| <= 1e-5 * max(1, |b|); the
-three finite-difference rate channels obs[0:3] amplify a 1-ulp Euler-angle error by
-1/agent_dt = 40 (hover.py:230) and get 40x that tolerance.  The fp64 kernel variant is held
+three finite-difference rate channels obs[0:3] = wrap(d euler) / agent_dt (hover.py:230) are
+compared as the angle difference (x agent_dt) at the same bar.  The fp64 kernel variant is held
 to 1e-10 and carries the trajectory-level checks.  PyFlyt parity itself is unpinned
 (docs/SPEC.md): the oracle is the build's own CPU restatement.
 """
@@ -74,9 +74,10 @@ def test_fp32_single_step_matches_oracle(oracle, noise):
     # float state within 1e-5
     ok = _close(st, st_ref, 1e-5)
     assert ok.all(), f"state mismatch at words {np.unique(np.where(~ok)[1])}, max {np.abs(st - st_ref).max()}"
+    # obs[0:3] = wrap(d euler) / agent_dt (hover.py:230): compared as the angle difference itself, at the same 1e-5 bar
     tol = np.full(20, 1e-5)
-    tol[0:3] = 4e-4
-    assert _close(obs, obs_r, tol).all(), np.abs(obs - obs_r).max(axis=0)
+    scale = np.ones(20); scale[0:3] = 0.025
+    assert _close(obs * scale, obs_r * scale, tol).all(), np.abs(obs * scale - obs_r * scale).max(axis=0)
     assert _close(rew, rew_r, 2e-5).all()
     # done ledger: same rows (order free), terminal observation and Monitor episode stats
     got = eng.ledger_read()
@@ -85,7 +86,7 @@ def test_fp32_single_step_matches_oracle(oracle, noise):
     assert (got["idx"] == idx_r).all() and (got["info"] == info_r).all()
     assert (got["tag"] == tick).all()
     assert _close(got["ep_return"], ret_r, 2e-5).all()
-    assert _close(got["obs"], tobs_r, tol).all()
+    assert _close(got["obs"] * scale, tobs_r * scale, tol).all()
     eng.close()
 
 
