@@ -107,6 +107,17 @@ __global__ __launch_bounds__(THREADS) void policy_forward_kernel(PolicyArgs p, i
     // ---- stage the weight image (L2-resident after the first workgroups) and the normaliser: every granule of a
     // thread is requested before the first one is written to LDS, so the block pays one L2 round trip
     FPV_STAMP(0);
+    // the first chunk's observation rows are requested ahead of the weight image: their latency (the rows were just written
+    // by the env step, on other XCDs) then hides under the 160 KB of staging instead of following it (4.9 k cycles of the
+    // launch in profiles/r02_policy_phase_stamps.md)
+    f32x4 xpre[3];
+    {
+        const int64_t d0 = (int64_t)blockIdx.x * (THREADS / 2) + (threadIdx.x >> 6) * 32 + (threadIdx.x & 31);
+        const int hh = (threadIdx.x >> 5) & 1;
+        const f32x4* row = reinterpret_cast<const f32x4*>(p.obs + (d0 < p.n ? d0 : 0) * p.in_dim);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) xpre[q] = row[4 * (3 * hh + q) < p.in_dim ? 3 * hh + q : 0];
+    }
     MergeRegs mr;
     if (p.mg.rows) merge_request(p.mg, mr);     // the tile sums travel together with the weight image
     {
@@ -158,11 +169,15 @@ __global__ __launch_bounds__(THREADS) void policy_forward_kernel(PolicyArgs p, i
         float x[12];
         {
             const f32x4* row = reinterpret_cast<const f32x4*>(p.obs + (live ? d : 0) * p.in_dim);
+            const bool first_chunk = base == (int64_t)blockIdx.x * kChunk;     // its rows were requested before the staging
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const bool have = live && 4 * (3 * h + q) < p.in_dim;
-                const f32x4 v = have ? row[3 * h + q] : f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 v = xpre[q];
+                if (!first_chunk) v = row[have ? 3 * h + q : 0];
+                if (!have) v = f32x4{0.f, 0.f, 0.f, 0.f};
                 x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+                xpre[q] = f32x4{0.f, 0.f, 0.f, 0.f};      // dead from here on
             }
 #pragma unroll
             for (int j = 0; j < 12; ++j) {
