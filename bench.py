@@ -148,6 +148,8 @@ def main() -> None:
     ap.add_argument("--repeats", type=int, default=5, help="the K-step timed region is run this many times; the median is reported")
     ap.add_argument("--detector", choices=["analytic", "pixel"], default="analytic",
                     help="hover task camera features: continuous projection (SPEC §6) or the reference's 128x128 pixel rules (§6b)")
+    ap.add_argument("--two-launch", action="store_true",
+                    help="policy forward and env step as two kernels per rollout step (the default is fpv_rollout_step: one)")
     args = ap.parse_args()
 
     import torch
@@ -186,7 +188,7 @@ def main() -> None:
     policy = (ActorCritic(obs_dim=12, act_dim=1) if yaw else ActorCritic()).to(dev)
     eng = FpvEngine(n, dev, noise_ratio=0.02, seed=0, id_offset=rank * n, task=args.task, domain_rand=yaw,
                     ledger_capacity=n * max(2, T // 8), detector="analytic" if yaw else args.detector)
-    col = RolloutCollector(eng, policy, n_steps=T, use_graph=not args.no_graph)
+    col = RolloutCollector(eng, policy, n_steps=T, use_graph=not args.no_graph, one_launch=False if args.two_launch else None)
     col.start()
     if not yaw:
         eng.set_state(torch.from_numpy(synthetic_states(n, seed=rank)))  # staggered step counts => staggered dones

@@ -97,6 +97,7 @@ SIGNATURES = {
     "fpv_policy_set_dims": (C.c_int, [_vp, _i32, _i32]),
     "fpv_policy_set_gemm": (C.c_int, [_vp, _i32]),
     "fpv_policy_forward": (C.c_int, [_vp, C.POINTER(FpvPolicyIo), _vp]),
+    "fpv_rollout_step": (C.c_int, [_vp, _vp, C.POINTER(FpvPolicyIo), _vp, _vp, _vp, C.POINTER(FpvStepExtras), _vp]),
     "fpv_ppo_workspace_bytes": (C.c_int, [_vp, _i64, C.POINTER(_i64)]),
     "fpv_ppo_grad": (C.c_int, [_vp, C.POINTER(FpvPpoIo), _vp]),
     "fpv_adam_clip_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp]),

@@ -556,6 +556,58 @@ int fpv_policy_forward(fpv_policy* p, const fpv_policy_io* io, void* stream) {
     return FPV_OK;
 }
 
+int fpv_rollout_step(fpv_env* e, fpv_policy* p, const fpv_policy_io* io, float* reward, uint8_t* terminated, uint8_t* truncated,
+                     const fpv_step_extras* ex, void* stream) {
+    if (!e || !p || !io) return fail(FPV_ERR_ARG, "fpv_rollout_step: null argument");
+    if (!io->obs || !io->value || !reward || !terminated || !truncated) return fail(FPV_ERR_ARG, "fpv_rollout_step: null buffer");
+    if (e->cfg.precision != FPV_F32 || e->cfg.task != FPV_TASK_HOVER || e->cfg.noise_ratio == 0.0)
+        return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: fp32 hover handles with motor noise only");
+    if (e->cfg.num_envs % 256 != 0) return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: num_envs must be a multiple of 256");
+    if (io->n != e->cfg.num_envs) return fail(FPV_ERR_ARG, "fpv_rollout_step: io->n must equal num_envs");
+    if (p->in_dim != 20 || p->act_dim != 4 || p->gemm != 0)
+        return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: policy widths 20 / 4 in gemm mode 0 only");
+    if (io->eps_in || io->eps_out || io->deterministic || io->narrow || io->n_dev || (io->nets != 0 && io->nets != 3))
+        return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: eps_in / eps_out / deterministic / narrow / n_dev / single nets are not served");
+    if (ex && (ex->obs_rms || ex->ret_rms || ex->snapshot))
+        return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: the statistics update rides in the next call's io->merge_* fields");
+    if (((uintptr_t)io->obs | (uintptr_t)io->obs_n | (uintptr_t)io->action | (uintptr_t)io->clipped) & 15)
+        return fail(FPV_ERR_ARG, "fpv_rollout_step: row buffers must be 16-byte aligned");
+    MergeArgs mg{};
+    if (io->merge_partials) {
+        if (io->merge_rows <= 0 || io->merge_rows > 1024)
+            return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: in-launch merge takes 1..1024 partial rows");
+        if (!(io->merge_count > 0.0)) return fail(FPV_ERR_ARG, "fpv_rollout_step: merge_count must be positive");
+        if ((io->rms && (!io->rms_out || io->rms_out == io->rms)) || (io->ret_rms && (!io->ret_rms_out || io->ret_rms_out == io->ret_rms)))
+            return fail(FPV_ERR_ARG, "fpv_rollout_step: merged statistics go to a second buffer (other workgroups still read the first)");
+        if (ex && ex->partials == io->merge_partials)
+            return fail(FPV_ERR_ARG, "fpv_rollout_step: extras->partials must not be the table this call merges (alternate two tables)");
+        mg = MergeArgs{io->merge_partials, io->ret_rms, io->rms ? io->rms_out : nullptr, io->ret_rms ? io->ret_rms_out : nullptr,
+                       io->merge_snapshot, io->merge_count, (int32_t)io->merge_rows, p->in_dim};
+    }
+    StepArgs<float> a{};
+    a.state = (Vec4<float>*)e->state;
+    a.actions = nullptr; a.obs = const_cast<float*>(io->obs); a.reward = reward; a.terminated = terminated; a.truncated = truncated;
+    a.tick = e->tick;
+    a.tmpl = (const float*)e->tmpl;
+    a.led_count = e->led_count; a.led_idx = e->led_idx; a.led_info = e->led_info; a.led_tag = e->led_tag;
+    a.led_ret = (float*)e->led_ret; a.led_obs = (float*)e->led_obs; a.led_rows = e->led_rows;
+    a.n = e->cfg.num_envs;
+    a.seed = e->cfg.seed;
+    a.id_offset = e->cfg.id_offset;
+    a.sigma = (float)e->cfg.noise_ratio;
+    a.floor_check = e->cfg.floor_check;
+    a.domain_rand = e->cfg.domain_rand;
+    a.detector = e->cfg.detector;
+    a.done = ex ? ex->done : nullptr;
+    a.ret = ex ? ex->ret : nullptr;
+    a.partials = ex ? ex->partials : nullptr;
+    a.gamma = ex ? ex->gamma : 0.0f;
+    a.mg_count = (double)e->cfg.num_envs;
+    FPV_HIP(launch_rollout_step(p->image, io->rms, io->obs_n, io->action, io->clipped, io->value, io->logp, io->seed, io->id_offset,
+                                io->clip_obs, io->eps_norm, mg, a, (hipStream_t)stream));
+    return FPV_OK;
+}
+
 int fpv_ppo_workspace_bytes(fpv_policy* p, int64_t rows, int64_t* bytes) {
     if (!p || !bytes || rows <= 0) return fail(FPV_ERR_ARG, "fpv_ppo_workspace_bytes: null argument or rows <= 0");
     *bytes = ppo_workspace_floats(rows, p->cus) * (int64_t)sizeof(float);

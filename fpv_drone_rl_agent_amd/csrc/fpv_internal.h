@@ -317,6 +317,10 @@ hipError_t launch_policy16_forward(const float* image, const float* obs, const d
                                    uint64_t seed, uint64_t id_offset, float clip_obs, float eps_norm, int max_blocks, int in_dim,
                                    int act_dim, hipStream_t s);
 int policy16_image_floats();
+// fpv_rollstep.hip
+hipError_t launch_rollout_step(const float* image, const double* rms, float* obs_n, float* action, float* clipped, float* value,
+                               float* logp, uint64_t pol_seed, uint64_t pol_id_offset, float clip_obs, float eps_norm,
+                               const MergeArgs& merge, const StepArgs<float>& st, hipStream_t s);
 // fpv_ppo.hip
 int64_t ppo_workspace_floats(int64_t rows, int cus);
 hipError_t launch_ppo_grad(const float* const* w, float* const* grads, const int64_t* index, const float* obs,

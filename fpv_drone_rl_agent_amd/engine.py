@@ -44,6 +44,7 @@ class FpvEngine:
         if detector not in ("analytic", "pixel"):
             raise ValueError("detector must be 'analytic' (docs/SPEC.md §6) or 'pixel' (the 128 x 128 rules of hover.py:157-222, §6b)")
         self.detector = detector
+        self.noise_ratio = float(noise_ratio)
         cfg = L.FpvConfig(self.num_envs, dev.index or 0, L.FPV_F64 if self._f64 else L.FPV_F32,
                           0 if render else 1, L.TASK_YAW if task == "yaw" else L.TASK_HOVER, float(noise_ratio),
                           int(seed), int(id_offset), int(ledger_capacity), 1 if domain_rand else 0,

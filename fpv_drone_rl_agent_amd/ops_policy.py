@@ -91,6 +91,34 @@ class FusedPolicy:
                 "fpv_policy_forward")
         return {"obs_n": obs_n, "action": action, "clipped": clipped, "value": value, "logp": logp, "eps": eps_out}
 
+    def rollout_step(self, engine, *, rms=None, obs_n=None, action=None, clipped=None, value=None, logp=None,
+                     clip_obs: float = 10.0, eps_norm: float = 1e-8, merge: dict | None = None, done=None, ret=None,
+                     partials=None, gamma: float = 0.99, reward=None):
+        """fpv_rollout_step: forward() on the engine's raw observations and the env step of the same drones in ONE launch
+        (fpv_rollstep.hip); engine.obs then holds the next observations.  Arguments as for forward() and
+        FpvEngine.step_fused(); `partials` receives num_envs / 256 rows and must be a different table from
+        merge["partials"].  Bit-identical to forward() followed by engine.step_fused(clipped, ...)."""
+        n = engine.num_envs
+        if value is None:
+            value = torch.empty((n,), dtype=torch.float32, device=engine.device)
+        reward = engine.reward if reward is None else reward
+        if partials is not None and (partials.dtype != torch.float64 or not partials.is_contiguous()
+                                     or partials.shape[0] < n // 256 or partials.shape[1] != 44):
+            raise ValueError("partials must be a contiguous float64 [>= num_envs / 256, 44] device tensor")
+        io = L.FpvPolicyIo(n, _ptr(engine.obs), _ptr(rms), None, None, _ptr(obs_n), _ptr(action), _ptr(clipped),
+                           _ptr(value), _ptr(logp), None, self.seed, self.id_offset, float(clip_obs), float(eps_norm), 0, 3, 0, 0)
+        if merge is not None:
+            io.merge_partials, io.merge_rows = _ptr(merge["partials"]), merge["partials"].shape[0]
+            io.merge_count = float(merge["count"])
+            io.rms_out, io.ret_rms = _ptr(merge.get("rms_out")), _ptr(merge.get("ret_rms"))
+            io.ret_rms_out, io.merge_snapshot = _ptr(merge.get("ret_rms_out")), _ptr(merge.get("snapshot"))
+        ex = L.FpvStepExtras(_ptr(done), _ptr(ret), _ptr(partials), float(gamma), 0, None, None, None)
+        L.check(self.lib.fpv_rollout_step(engine._h, self._h, C.byref(io), _ptr(reward), _ptr(engine.terminated),
+                                          _ptr(engine.truncated), C.byref(ex),
+                                          C.c_void_p(torch.cuda.current_stream(engine.device).cuda_stream)),
+                "fpv_rollout_step")
+        return {"obs_n": obs_n, "action": action, "clipped": clipped, "value": value, "logp": logp, "reward": reward}
+
     def _grads(self):
         gs = []
         for t in self._params():

@@ -14,7 +14,9 @@ Every per-step operation is asynchronous device work on one stream; the T-step l
 captured once into a HIP graph and replayed, so the host issues one launch per rollout.
 
 Two step implementations:
-  * fused (default): TWO kernels per step — fpv_policy_forward (RunningMeanStd.update of both statistics
+  * fused, one_launch (default where served): ONE kernel per step — fpv_rollout_step = the two kernels below in one
+    launch, same bits (fpv_rollstep.hip).
+  * fused: TWO kernels per step — fpv_policy_forward (RunningMeanStd.update of both statistics
     with the previous step's moment sums in its prologue -> normalise -> pi, V on fp32 MFMA -> sample ->
     log-prob -> clip, writing straight into the rollout buffer) and fpv_step_fused (env step + done mask +
     discounted return + moment sums).  Reward scaling is applied once per rollout (fpv_reward_finalize)
@@ -52,7 +54,7 @@ class RolloutCollector:
                  lam: float = 0.95, norm_obs: bool = True, norm_reward: bool = True, use_graph: bool = True,
                  clip_obs: float = 10.0, clip_reward: float = 10.0, fused: bool = True, policy_seed: int = 0,
                  policy_gemm: str = "f32", overlap_critic: bool = False, merge_in_policy: bool = True,
-                 fused_step: bool = True, merge_in_step: bool = False):
+                 fused_step: bool = True, merge_in_step: bool = False, one_launch: bool | None = None):
         if engine.dtype != torch.float32:
             raise ValueError("the rollout collector runs on an fp32 engine")
         self.engine, self.policy = engine, policy
@@ -88,6 +90,7 @@ class RolloutCollector:
         self.last_val = torch.zeros((N,), dtype=f32, device=dev)
         self.snap = torch.zeros((T, max(44, 2 * O + 4)), dtype=torch.float64, device=dev)  # {obs_rms, ret_rms} after step t
         self.fused = bool(fused)
+        self._one_launch = self._one_launch_ok = False
         self.fused_policy = fused_policy
         if self.fused_policy:
             self.fp = FusedPolicy(policy, seed=policy_seed, id_offset=engine.id_offset,
@@ -115,6 +118,19 @@ class RolloutCollector:
                                      and not self.overlap_critic)   # (the table is <= 1 024 rows by construction)
             self._obs_rms_alt = torch.zeros_like(self.obs_norm.rms)
             self._ret_rms_alt = torch.zeros_like(self.rew_norm.rms)
+            # one_launch: policy forward and env step of a rollout step as ONE kernel (fpv_rollout_step, fpv_rollstep.hip) —
+            # bit-identical results.  Served for the hover task with motor noise, drone counts that are multiples of 256 up
+            # to 256 x 1 024, the exact-fp32 policy, and the statistics merge in the launch prologue (or no normalisation).
+            norm = self.norm_obs or self.norm_reward
+            can = (engine.task == "hover" and engine.noise_ratio > 0.0 and N % 256 == 0 and N // 256 <= 1024
+                   and policy_gemm == "f32" and not self.overlap_critic and not self._merge_in_step
+                   and (self._merge_in_policy or not norm))
+            if one_launch and not can:
+                raise ValueError("one_launch needs the hover task with motor noise, num_envs a multiple of 256 (<= 262 144), "
+                                 "policy_gemm='f32' and the default statistics-merge placement")
+            self._one_launch = self._one_launch_ok = can if one_launch is None else bool(one_launch)
+            if self._one_launch:    # launch t reads the rows of launch t - 1 while it writes its own: two tables
+                self._rs_partials = torch.zeros((2, N // 256, 2 * O + 4), dtype=torch.float64, device=dev)
         self.stats = torch.zeros((3,), dtype=torch.float64, device=dev)
         if self.fused_policy:
             # sync-free timeout bootstrap (fpv_ledger_scan / fpv_ledger_scatter): a drone is truncated at most once per
@@ -180,6 +196,17 @@ class RolloutCollector:
     def _step_fused(self, t: int) -> None:
         eng = self.engine
         rms = self.obs_norm.rms if self.norm_obs else None
+        if self._one_launch:
+            (o_in, r_in), (o_out, r_out) = self._stat_bufs(t - 1), self._stat_bufs(t)
+            merge = None
+            if self._merge_in_policy and t > 0:
+                merge = {"partials": self._rs_partials[(t - 1) % 2], "count": self.N, "rms_out": o_out, "ret_rms": r_in,
+                         "ret_rms_out": r_out, "snapshot": self.snap[t - 1]}
+            self.fp.rollout_step(eng, rms=self._stat_bufs(0)[0] if t == 0 else o_in, obs_n=self.buf_obs[t], action=self.buf_act[t],
+                                 value=self.buf_val[t], logp=self.buf_logp[t], clip_obs=self.obs_norm.clip,
+                                 eps_norm=self.obs_norm.eps, merge=merge, done=self._starts[t + 1], ret=self.rew_norm.ret,
+                                 partials=self._rs_partials[t % 2], gamma=self.gamma, reward=self.raw_rew[t])
+            return
         if self.overlap_critic:
             self.fp.forward(eng.obs, rms=rms, tick=eng.tick_ptr, obs_n=self.buf_obs[t], action=self.buf_act[t],
                             clipped=self.clipped, logp=self.buf_logp[t], clip_obs=self.obs_norm.clip,
@@ -225,7 +252,7 @@ class RolloutCollector:
         if not (self.fused and self._merge_in_policy):
             return
         o_in, r_in = self._stat_bufs(t_last)
-        ops.moments_merge(self.partials, self.N, obs_rms=self.obs_norm.rms if self.norm_obs else None,
+        ops.moments_merge(self._rs_partials[t_last % 2] if self._one_launch else self.partials, self.N, obs_rms=self.obs_norm.rms if self.norm_obs else None,
                           ret_rms=self.rew_norm.rms if self.norm_reward else None, snapshot=self.snap[t_last],
                           obs_rms_in=o_in, ret_rms_in=r_in)
 
@@ -310,6 +337,7 @@ class RolloutCollector:
         if not self.fused:
             raise ValueError("policy_gemm applies to the fused path")
         self.fp.set_gemm(gemm)
+        self._one_launch = self._one_launch_ok and gemm == "f32"    # fpv_rollout_step serves the exact-fp32 policy
         self.overlap_critic = self._vstream is not None and gemm == "f32"
         self._graph = None
 

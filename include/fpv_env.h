@@ -308,6 +308,21 @@ int fpv_policy_forward(fpv_policy* pol, const fpv_policy_io* io, void* stream);
  * with fp32-input MFMA on gfx950 (tools/mfma_mix), so the tanh work bounds both shapes alike. */
 int fpv_policy_set_gemm(fpv_policy* pol, int32_t mode);
 
+/* ---- one rollout step in one launch: fpv_policy_forward + fpv_step_fused of the same drones ----
+ * What SB3's collect_rollouts does per step over VecNormalize(VecEnv) (simulation/train_hover.py:42-60): policy forward on
+ * obs_t, Box clip, env.step with auto-reset, VecNormalize bookkeeping — by ONE kernel whose 512-thread workgroups evaluate
+ * pi / V for 256 drones and then step those drones (fpv_rollstep.hip): the action never leaves the chip and the env step
+ * shares the launch.  `io` as for fpv_policy_forward with io->obs = the handle's raw observation rows obs_t, which are
+ * REPLACED by obs_{t+1} (io->n = num_envs; eps_in, eps_out, deterministic, narrow, n_dev, nets other than 0 / 3 are not
+ * served); reward / terminated / truncated / extras as for fpv_step_fused (extras->obs_rms / ret_rms / snapshot must be
+ * NULL: the statistics update rides in the NEXT call's io->merge_* fields).  One row of moment sums per workgroup:
+ * extras->partials receives num_envs / 256 rows, and because every workgroup of call t + 1 reads call t's rows while it
+ * writes its own, the caller alternates between two tables (io->merge_partials != extras->partials).
+ * Results are bit-identical to fpv_policy_forward followed by fpv_step_fused.  Needs: fp32 hover handle with
+ * noise_ratio > 0, num_envs a multiple of 256, policy widths 20 / 4 in gemm mode 0; FPV_ERR_UNSUPPORTED otherwise. */
+int fpv_rollout_step(fpv_env* env, fpv_policy* pol, const fpv_policy_io* io, float* reward, uint8_t* terminated,
+                     uint8_t* truncated, const fpv_step_extras* extras, void* stream);
+
 /* ---- PPO minibatch gradient (SB3 PPO.train: clipped surrogate + vf_coef * MSE value loss - ent_coef * entropy) ----
  * The learner north_star puts in place of the SAC of simulation/train_hover.py:47-60.  One call = forward of both nets
  * over `rows` transitions, the loss derivatives, and the backward pass, as hand-written MFMA kernels (fpv_ppo.hip);
