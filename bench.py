@@ -5,7 +5,8 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, one rank per GPU
 over RCCL.  A "step" is one vectorised pass of the hot path over this rank's drones: policy MLP
 forward + Gaussian sample, the fused HIP env-step (12 physics sub-steps, obs, reward, done,
-auto-reset), VecNormalize of obs and reward, rollout-buffer writes; every n_steps steps the rollout
+auto-reset), VecNormalize of obs and reward, rollout-buffer writes — ONE kernel per step
+(fpv_rollout_step; `--two-launch` runs it as the policy kernel + the env-step kernel); every n_steps steps the rollout
 is closed with the value bootstrap, GAE (HIP) and the ONE all-gather of advantage statistics.
 K is timed exactly (barrier + synchronize on both sides, MAX over ranks); value = drones on all
 ranks x K / time.  Inputs are synthetic (random-init policy, seeded random-init drone states,
@@ -15,10 +16,11 @@ The K-step timed region is repeated `--repeats` times (default 5), each brackete
 synchronize and reduced with MAX over ranks; the line reports the MEDIAN repeat (all repeats are
 listed under `repeats_ms_per_step`).
 
-Adds to the JSON line: `roofline` for the kernel that dominates the timed region by time (the fused
-actor-critic forward, fp32 MFMA) and `roofline_env_step` for the HBM-bound dynamics kernel, both from
-device timestamps of the launches inside the replayed graph with a HIP-event back-to-back figure
-beside them; `cpu_baseline` (the C oracle on this box's host cores: all cores and one thread; rank 0,
+Adds to the JSON line: `roofline` for the kernel that dominates the timed region by time (the rollout-step
+kernel: actor-critic forward on fp32 MFMA + the env step of the same drones; its `phases` come from
+in-kernel clock stamps) and `roofline_env_step` for the HBM-bound dynamics (the env-step phase of that
+kernel, and the stand-alone env-step kernels), from device timestamps of the launches inside the
+replayed graph with a HIP-event back-to-back figure beside them; `cpu_baseline` (the C oracle on this box's host cores: all cores and one thread; rank 0,
 N = 1 only); `extra.value_f64_env` (the fp64 engine's env step alone).  oracle/ is used here ONLY for
 the cpu_baseline leg.
 """
@@ -237,7 +239,7 @@ def main() -> None:
     # node inside the replayed graph).  `roofline` is the kernel that dominates the timed region by time (the fused
     # actor-critic forward, MFMA-bound); `roofline_env_step` is the HBM-bound dynamics kernel BASELINE's "% HBM
     # roofline" refers to, as it runs in the rollout (with the VecNormalize bookkeeping fused in) and stand-alone.
-    roofline = roofline_env = roofline_env_plain = None
+    roofline = roofline_env = roofline_env_plain = roofline_env_fused = None
     if True:   # every rank runs the same passes (collect() contains the collective); only rank 0 reports them
         L = args.kernel_launches
         act = torch.rand((n, eng.act_words), device=dev) * 2 - 1
@@ -292,6 +294,31 @@ def main() -> None:
             except Exception:
                 return {}
 
+        def kernel_phases():
+            """Median in-kernel phase durations (us) of fpv::rollout_step_kernel from its diagnostic clock stamps
+            (fpv_debug_rollout_stamps): one extra captured rollout with the stamp buffer attached."""
+            try:
+                import ctypes as C
+                from fpv_drone_rl_agent_amd import _lib as LIB
+                import numpy as np
+                grid = n // 256
+                stamps = torch.zeros((grid, 8), dtype=torch.int64, device=dev)
+                LIB.load().fpv_debug_rollout_stamps(C.c_void_p(stamps.data_ptr()))
+                col._graph = None                     # the stamp pointer is a kernel argument: capture again
+                col.collect()
+                torch.cuda.synchronize(dev)
+                LIB.load().fpv_debug_rollout_stamps(None)
+                col._graph = None
+                col.collect()
+                torch.cuda.synchronize(dev)
+                st = stamps.cpu().numpy().astype(np.float64) / 100.0
+                names = ["staging + statistics merge", "policy (normalise, pi, V, sample)", "env step + bookkeeping"]
+                out = {nm: round(float(np.median(st[:, k + 1] - st[:, k])), 2) for k, nm in enumerate(names)}
+                out["first workgroup start -> last workgroup end"] = round(float(st[:, 3].max() - st[:, 0].min()), 2)
+                return out
+            except Exception:
+                return None
+
         def pick(times, needle, at_least=0.0):
             """mean duration of the launches of the kernel whose name contains `needle`; at_least drops the short launches
             of the same kernel (the rollout tail runs the policy kernel V-only and over the short done-ledger list)"""
@@ -307,7 +334,47 @@ def main() -> None:
         else:
             us_plain = timed(lambda: eng.step(act))
             roofline_env_plain = hbm("fpv::step_kernel<float,true,false>", us_plain, ALG_BYTES_PER_STEP)
-            if col.fused:
+            if col.fused and col._one_launch:
+                # ---- the rollout-step kernel (policy + env step in one launch)
+                ev_fused = timed(lambda: eng.step_fused(col.clipped, done=col._starts[1], ret=col.rew_norm.ret,
+                                                        partials=col.partials, gamma=col.gamma, reward=col.raw_rew[0]))
+                ev_one = timed(lambda: col.fp.rollout_step(eng, rms=col.obs_norm.rms, obs_n=col.buf_obs[0], action=col.buf_act[0],
+                                                           value=col.buf_val[0], logp=col.buf_logp[0], done=col._starts[1],
+                                                           ret=col.rew_norm.ret, partials=col._rs_partials[0], gamma=col.gamma,
+                                                           reward=col.raw_rew[0]))
+                in_graph = graph_kernel_times()
+                us_one = pick(in_graph, "rollout_step_kernel") or ev_one
+                if not 0.6 * ev_one < us_one < 1.6 * ev_one:
+                    in_graph, us_one = {}, ev_one                        # tracer output implausible: trust the events
+                how = "device timestamps of the launches inside the replayed rollout graph" if in_graph else \
+                      "HIP events around back-to-back launches"
+                phases = kernel_phases()
+                tf = POLICY_FLOP_PER_ROW * n / us_one / 1e6
+                roofline = {"bound": "mfma", "kernel": "fpv::rollout_step_kernel", "achieved": round(tf, 1),
+                            "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                            "traffic": traffic_of("fpv::rollout_step_kernel"), "us_per_launch": round(us_one, 2),
+                            "launches": L, "algorithmic_flop_per_launch": POLICY_FLOP_PER_ROW * n, "dtype": "f32",
+                            "measured": how, "us_per_launch_hip_events_back_to_back": round(ev_one, 2)}
+                roofline["note"] = ("one kernel per rollout step: actor-critic forward (the matrix work priced here) AND the env step of "
+                                    "the same drones (vector work, `phases`); peak = dense fp32-input MFMA rate (155 TF measured with "
+                                    "resident operands at a 2.38 GHz in-kernel clock, profiles/r02_mfma_peak.txt); vector instructions do "
+                                    "not co-execute with fp32-input MFMA (profiles/r02_mfma_valu_mix.txt), so tanh / heads / sampling "
+                                    "add to the product time (profiles/r02_policy_phase_stamps.md)")
+                roofline["traffic_source"] = "profiles/kernel_traffic.json (rocprofv3 --pmc passes of this command; not collectable in-process)"
+                if phases:
+                    roofline["phases_us"] = phases
+                    pol = phases.get("policy (normalise, pi, V, sample)")
+                    if pol:
+                        roofline["frac_of_peak_within_policy_phase"] = round(POLICY_FLOP_PER_ROW * n / pol / 1e6 / MFMA_F32_PEAK_TFLOPS, 4)
+                    envp = phases.get("env step + bookkeeping")
+                    if envp:
+                        roofline_env = hbm("env-step phase of fpv::rollout_step_kernel", envp, ALG_BYTES_PER_STEP)
+                        roofline_env.update(traffic=None, measured="in-kernel s_memrealtime stamps, median over workgroups "
+                                            "(the drone state is requested under the matrix work; this is the exposed part)")
+                roofline_env_fused = hbm("fpv::step_kernel<float,true,true>", ev_fused, ALG_BYTES_PER_STEP)
+                roofline_env_fused.update(measured="HIP events around back-to-back launches (the stand-alone fpv_step_fused kernel; "
+                                                   "not launched by the default rollout)")
+            elif col.fused:
                 io = dict(rms=col.obs_norm.rms, tick=eng.tick_ptr, obs_n=col.buf_obs[0], action=col.buf_act[0],
                           clipped=col.clipped, value=col.buf_val[0], logp=col.buf_logp[0])
                 ev_pol = timed(lambda: col.fp.forward(eng.obs, **io))
@@ -361,17 +428,21 @@ def main() -> None:
             "config": {"workload": ("BASELINE.json configs[4]: yaw-setpoint task with domain-randomised mass/drag, on-device "
                                     "PPO rollout (torch policy 12->1, HIP env-step, VecNormalize) + GAE + all-gather" if yaw else
                                     "BASELINE.json configs[2]: 65 536 hover drones per GPU, on-device PPO rollout "
-                                    "(two kernels per step: fp32-MFMA policy forward + sample with the VecNormalize statistics merge in its "
-                                    "prologue, HIP env-step + VecNormalize bookkeeping; done-ledger timeout bootstrap, GAE) "
-                                    "+ advantage-stat all-gather every n_steps"),
+                                    + ("(one kernel per step: VecNormalize statistics merge, fp32-MFMA policy forward + sample, then the "
+                                       "env step + VecNormalize bookkeeping of the same drones; " if col._one_launch else
+                                       "(two kernels per step: fp32-MFMA policy forward + sample with the VecNormalize statistics merge in "
+                                       "its prologue, HIP env-step + VecNormalize bookkeeping; ") +
+                                    "done-ledger timeout bootstrap, GAE) + advantage-stat all-gather every n_steps"),
                        "drones_per_gpu": n, "total_drones": n * world, "n_steps": T,
-                       "hip_graph": not args.no_graph, "detector": "analytic" if yaw else args.detector, "policy": "MlpPolicy pi/vf [128,128] tanh" + ("" if yaw else " (39 049 params), exact-fp32 MFMA"),
+                       "hip_graph": not args.no_graph, "kernels_per_step": 1 if col._one_launch else 2, "detector": "analytic" if yaw else args.detector, "policy": "MlpPolicy pi/vf [128,128] tanh" + ("" if yaw else " (39 049 params), exact-fp32 MFMA"),
                        "episodes_in_last_rollout": episodes},
             "roofline": roofline,
         }
         if roofline_env is not None:
             out["roofline_env_step"] = roofline_env
             out["roofline_env_step_unfused"] = roofline_env_plain
+        if roofline_env_fused is not None:
+            out["roofline_env_step_standalone_fused"] = roofline_env_fused
         if split_value is not None:
             out["extra"] = {"value_with_policy_gemm_bf16x6": split_value,
                             "note": "same workload with the policy's hidden GEMMs on a 6-term bf16 split (fp32-level error, "

@@ -41,6 +41,18 @@ class FpvStepExtras(C.Structure):
 PARTIAL_WORDS = 44
 
 
+class FpvRolloutIo(C.Structure):
+    _fields_ = [
+        ("T", C.c_int32), ("reserved", C.c_int32), ("obs", C.c_void_p), ("obs_n", C.c_void_p), ("action", C.c_void_p),
+        ("value", C.c_void_p), ("logp", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p),
+        ("terminated", C.c_void_p), ("truncated", C.c_void_p), ("ret", C.c_void_p),
+        ("gamma", C.c_float), ("clip_obs", C.c_float), ("eps_norm", C.c_float), ("reserved1", C.c_float),
+        ("seed", C.c_uint64), ("id_offset", C.c_uint64), ("rms", C.c_void_p), ("ret_rms", C.c_void_p),
+        ("rms_out", C.c_void_p * 2), ("ret_rms_out", C.c_void_p * 2), ("snapshots", C.c_void_p),
+        ("snapshot_stride", C.c_int64), ("partials", C.c_void_p * 2), ("status", C.c_void_p),
+    ]
+
+
 class FpvPolicyIo(C.Structure):
     _fields_ = [
         ("n", C.c_int64), ("obs", C.c_void_p), ("rms", C.c_void_p), ("eps_in", C.c_void_p), ("tick", C.c_void_p),
@@ -98,11 +110,13 @@ SIGNATURES = {
     "fpv_policy_set_gemm": (C.c_int, [_vp, _i32]),
     "fpv_policy_forward": (C.c_int, [_vp, C.POINTER(FpvPolicyIo), _vp]),
     "fpv_rollout_step": (C.c_int, [_vp, _vp, C.POINTER(FpvPolicyIo), _vp, _vp, _vp, C.POINTER(FpvStepExtras), _vp]),
+    "fpv_rollout_steps": (C.c_int, [_vp, _vp, C.POINTER(FpvRolloutIo), _vp]),
     "fpv_ppo_workspace_bytes": (C.c_int, [_vp, _i64, C.POINTER(_i64)]),
     "fpv_ppo_grad": (C.c_int, [_vp, C.POINTER(FpvPpoIo), _vp]),
     "fpv_adam_clip_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp]),
     "fpv_set_pair_threshold": (C.c_int, [_i64]),
     "fpv_noop": (C.c_int, [_vp]),
+    "fpv_debug_rollout_stamps": (C.c_int, [_vp]),
     "fpv_last_error": (C.c_char_p, []),
     "fpv_version": (C.c_int, []),
 }

@@ -39,6 +39,7 @@ struct fpv_env {
     void* tmpl;          // 56 reals
     uint64_t* tick;      // device [tiles]
     uint32_t* merge_ticket;   // device counter of the in-launch statistics merge (zero between launches)
+    uint32_t* rollout_sync;   // barrier words of fpv_rollout_steps (zeroed on the stream before every launch)
     uint32_t* led_count;
     int32_t* led_idx;
     uint32_t* led_info;
@@ -132,6 +133,11 @@ int fpv_set_pair_threshold(int64_t max_drones) {
     return FPV_OK;
 }
 
+int fpv_debug_rollout_stamps(uint64_t* device_buffer) {
+    fpv::g_rollout_stamps = device_buffer;
+    return FPV_OK;
+}
+
 int fpv_noop(void* stream) {
     hipLaunchKernelGGL(fpv_noop_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream);
     FPV_HIP(hipGetLastError());
@@ -180,6 +186,7 @@ int fpv_create(const fpv_config* cfg, fpv_env** out) {
     alloc(&e->tmpl, (size_t)(kStateWords + kObsWords) * e->word);
     alloc((void**)&e->tick, (size_t)e->tiles * sizeof(uint64_t));
     alloc((void**)&e->merge_ticket, 64);
+    alloc((void**)&e->rollout_sync, sizeof(uint32_t) * (size_t)rollout_sync_words());
     alloc((void**)&e->led_count, (size_t)e->tiles * sizeof(uint32_t));
     alloc((void**)&e->led_idx, (size_t)e->led_cap * sizeof(int32_t));
     alloc((void**)&e->led_info, (size_t)e->led_cap * sizeof(uint32_t));
@@ -211,7 +218,7 @@ int fpv_create(const fpv_config* cfg, fpv_env** out) {
 
 int fpv_destroy(fpv_env* e) {
     if (!e) return FPV_OK;
-    void* own[] = {e->state, e->tmpl, e->tick, e->merge_ticket};
+    void* own[] = {e->state, e->tmpl, e->tick, e->merge_ticket, e->rollout_sync};
     for (void* p : own)
         if (p) (void)hipFree(p);
     if (e->led_owned) {
@@ -605,6 +612,60 @@ int fpv_rollout_step(fpv_env* e, fpv_policy* p, const fpv_policy_io* io, float* 
     a.mg_count = (double)e->cfg.num_envs;
     FPV_HIP(launch_rollout_step(p->image, io->rms, io->obs_n, io->action, io->clipped, io->value, io->logp, io->seed, io->id_offset,
                                 io->clip_obs, io->eps_norm, mg, a, (hipStream_t)stream));
+    return FPV_OK;
+}
+
+int fpv_rollout_steps(fpv_env* e, fpv_policy* p, const fpv_rollout_io* io, void* stream) {
+    if (!e || !p || !io) return fail(FPV_ERR_ARG, "fpv_rollout_steps: null argument");
+    if (io->T <= 0) return fail(FPV_ERR_ARG, "fpv_rollout_steps: T must be positive");
+    if (!io->obs || !io->value || !io->reward || !io->terminated || !io->truncated || !io->status)
+        return fail(FPV_ERR_ARG, "fpv_rollout_steps: obs, value, reward, terminated, truncated and status are required");
+    if (e->cfg.precision != FPV_F32 || e->cfg.task != FPV_TASK_HOVER || e->cfg.noise_ratio == 0.0)
+        return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_steps: fp32 hover handles with motor noise only");
+    if (e->cfg.num_envs % 256 != 0 || e->cfg.num_envs / 256 > p->cus)
+        return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_steps: num_envs must be a multiple of 256 and at most 256 x %d (one workgroup per CU)", p->cus);
+    if (p->in_dim != 20 || p->act_dim != 4 || p->gemm != 0)
+        return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_steps: policy widths 20 / 4 in gemm mode 0 only");
+    if (((uintptr_t)io->obs | (uintptr_t)io->obs_n | (uintptr_t)io->action) & 15)
+        return fail(FPV_ERR_ARG, "fpv_rollout_steps: row buffers must be 16-byte aligned");
+    const bool norm = io->rms || io->ret_rms;
+    if (!io->partials[0] || !io->partials[1] || io->partials[0] == io->partials[1])
+        return fail(FPV_ERR_ARG, "fpv_rollout_steps: two different partials tables are required");
+    if (io->T > 1 && norm) {
+        if ((io->rms && (!io->rms_out[0] || !io->rms_out[1])) || (io->ret_rms && (!io->ret_rms_out[0] || !io->ret_rms_out[1])))
+            return fail(FPV_ERR_ARG, "fpv_rollout_steps: rms_out / ret_rms_out are required with their statistics");
+        if (io->snapshots && io->snapshot_stride < FPV_PARTIAL_WORDS)
+            return fail(FPV_ERR_ARG, "fpv_rollout_steps: snapshot_stride must be at least FPV_PARTIAL_WORDS");
+    }
+    StepArgs<float> a{};
+    a.state = (Vec4<float>*)e->state;
+    a.obs = io->obs; a.terminated = io->terminated; a.truncated = io->truncated;
+    a.tick = e->tick;
+    a.tmpl = (const float*)e->tmpl;
+    a.led_count = e->led_count; a.led_idx = e->led_idx; a.led_info = e->led_info; a.led_tag = e->led_tag;
+    a.led_ret = (float*)e->led_ret; a.led_obs = (float*)e->led_obs; a.led_rows = e->led_rows;
+    a.n = e->cfg.num_envs;
+    a.seed = e->cfg.seed;
+    a.id_offset = e->cfg.id_offset;
+    a.sigma = (float)e->cfg.noise_ratio;
+    a.floor_check = e->cfg.floor_check;
+    a.domain_rand = e->cfg.domain_rand;
+    a.detector = e->cfg.detector;
+    a.ret = io->ret;
+    a.gamma = io->gamma;
+    a.mg_count = (double)e->cfg.num_envs;
+    RollPersistHost h{};
+    h.image = p->image; h.pol_seed = io->seed; h.pol_id_offset = io->id_offset; h.clip_obs = io->clip_obs; h.eps_norm = io->eps_norm;
+    h.T = io->T;
+    h.obs_n = io->obs_n; h.action = io->action; h.value = io->value; h.logp = io->logp; h.reward = io->reward; h.done = io->done;
+    h.rms0 = io->rms; h.ret_rms0 = io->ret_rms;
+    h.rms_out[0] = io->rms_out[0]; h.rms_out[1] = io->rms_out[1];
+    h.ret_rms_out[0] = io->ret_rms_out[0]; h.ret_rms_out[1] = io->ret_rms_out[1];
+    h.snapshots = io->snapshots; h.snap_stride = io->snapshot_stride;
+    h.rows[0] = io->partials[0]; h.rows[1] = io->partials[1];
+    h.sync = e->rollout_sync; h.status = io->status;
+    h.timeout_ticks = 200000000ull;     // 2 s of the 100 MHz counter: far beyond any step, short enough to end a stuck launch
+    FPV_HIP(launch_rollout_persistent(h, a, (hipStream_t)stream));
     return FPV_OK;
 }
 

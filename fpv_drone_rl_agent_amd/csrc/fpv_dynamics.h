@@ -163,8 +163,10 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
                                               uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one 32 x 32 -> 64 multiply per product (v_mad_u64_u32) instead of a high and a low half (both quarter rate)
+        const uint64_t p0 = (uint64_t)0xD2511F53u * (uint64_t)c0, p1 = (uint64_t)0xCD9E8D57u * (uint64_t)c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         c0 = hi1 ^ c1 ^ k0;
         c1 = lo1;
         c2 = hi0 ^ c3 ^ k1;
@@ -623,24 +625,29 @@ __device__ __forceinline__ void tile_moment_sums(const float* lds_w, double* xch
     double s1 = 0.0, s2 = 0.0;
     if (lane < G * W) {
         const int g = lane / W, c = lane - g * W;
+        // every read is issued unconditionally (the index is clamped into the tile) and masked afterwards: a load under a
+        // run-time row test makes hipcc branch around each one and wait for it alone — 22 dependent LDS round trips
         float v[Q];
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const int r = G * q + g;
-            v[q] = r < rows ? lds_w[(r < kTile ? r : 0) * W + c] : 0.0f;
+            v[q] = lds_w[(r < kTile ? r : 0) * W + c];
         }
 #pragma unroll
-        for (int q = 0; q < Q; ++q) { const double d = (double)v[q]; s1 += d; s2 += d * d; }
+        for (int q = 0; q < Q; ++q) {
+            const double d = G * q + g < rows ? (double)v[q] : 0.0;
+            s1 += d; s2 += d * d;
+        }
     } else {
         const int g = lane - G * W;
         float v[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int r = 4 * q + g;
-            v[q] = r < rows ? lds_w[kTile * W + r] : 0.0f;
-        }
+        for (int q = 0; q < 16; ++q) v[q] = lds_w[kTile * W + 4 * q + g];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) { const double d = (double)v[q]; s1 += d; s2 += d * d; }
+        for (int q = 0; q < 16; ++q) {
+            const double d = 4 * q + g < rows ? (double)v[q] : 0.0;
+            s1 += d; s2 += d * d;
+        }
     }
     xch[2 * lane] = s1;
     xch[2 * lane + 1] = s2;

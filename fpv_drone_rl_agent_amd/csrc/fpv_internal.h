@@ -321,6 +321,24 @@ int policy16_image_floats();
 hipError_t launch_rollout_step(const float* image, const double* rms, float* obs_n, float* action, float* clipped, float* value,
                                float* logp, uint64_t pol_seed, uint64_t pol_id_offset, float clip_obs, float eps_norm,
                                const MergeArgs& merge, const StepArgs<float>& st, hipStream_t s);
+struct RollPersistHost {     // host-side description of a T-step launch (fpv_rollout_steps); fields as RollPersistArgs, fpv_rollstep.hip
+    const float* image;
+    uint64_t pol_seed, pol_id_offset;
+    float clip_obs, eps_norm;
+    int32_t T;
+    float *obs_n, *action, *value, *logp, *reward;
+    uint8_t* done;
+    const double *rms0, *ret_rms0;
+    double *rms_out[2], *ret_rms_out[2];
+    double* snapshots;
+    int64_t snap_stride;
+    double* rows[2];
+    uint32_t *sync, *status;
+    uint64_t timeout_ticks;
+};
+hipError_t launch_rollout_persistent(const RollPersistHost& h, const StepArgs<float>& st, hipStream_t s);
+int rollout_sync_words();
+extern uint64_t* g_rollout_stamps;   // diagnostic phase stamps of the persistent kernel (fpv_debug_rollout_stamps)
 // fpv_ppo.hip
 int64_t ppo_workspace_floats(int64_t rows, int cus);
 hipError_t launch_ppo_grad(const float* const* w, float* const* grads, const int64_t* index, const float* obs,

@@ -22,6 +22,7 @@ struct PolicyParams {
     const float *pi_w1, *pi_b1, *pi_w2, *pi_b2, *wa, *ba, *log_std;
     const float *vf_w1, *vf_b1, *vf_w2, *vf_b2, *wv, *bv;
     int in_dim, act_dim;   // 20 / 4 hover (hover.py:59-70), 12 / 1 yaw (yaw.py:37-45); in_dim % 4 == 0, <= 24; act_dim <= 4
+                           // layer 1 takes in_dim / 2 products per tile: lane half h supplies k = s + (in_dim / 2) h, no padding
 };
 
 __global__ void policy_pack_kernel(PolicyParams p, float* __restrict__ img) {
@@ -34,10 +35,10 @@ __global__ void policy_pack_kernel(PolicyParams p, float* __restrict__ img) {
         const float* b1 = net ? p.vf_b1 : p.pi_b1;
         const float* w2 = net ? p.vf_w2 : p.pi_w2;
         const float* b2 = net ? p.vf_b2 : p.pi_b2;
-        if (o < kOffB1) {                       // W1p[m][s][lane] = W1[m*32 + i][s + 12 h]
+        if (o < kOffB1) {                       // W1p[m][s][lane] = W1[m*32 + i][s + (in_dim / 2) h], s < in_dim / 2
             const int lane = o % 64, s = (o / 64) % 12, m = o / (64 * 12);
-            const int k = s + 12 * (lane >> 5);
-            v = k < p.in_dim ? w1[(m * 32 + (lane & 31)) * p.in_dim + k] : 0.0f;
+            const int half = p.in_dim / 2, k = s + half * (lane >> 5);
+            v = s < half ? w1[(m * 32 + (lane & 31)) * p.in_dim + k] : 0.0f;
         } else if (o < kOffW2) {                // b1p[m][h][r]
             const int q = o - kOffB1, r = q % 16, h = (q / 16) % 2, m = q / 32;
             v = b1[m * 32 + tile_row(r, h)];
@@ -102,13 +103,15 @@ __global__ __launch_bounds__(THREADS) void policy_forward_kernel(PolicyArgs p, i
     // the first chunk's observation rows are requested ahead of the weight image: their latency (the rows were just written
     // by the env step, on other XCDs) then hides under the 160 KB of staging instead of following it (4.9 k cycles of the
     // launch in profiles/r02_policy_phase_stamps.md)
-    f32x4 xpre[3];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int half = p.in_dim / 2;                   // words of a row held by one lane half: k = half * h + j
+    f32x2 xpre[6];
     {
         const int64_t d0 = (int64_t)blockIdx.x * (THREADS / 2) + (threadIdx.x >> 6) * 32 + (threadIdx.x & 31);
         const int hh = (threadIdx.x >> 5) & 1;
-        const f32x4* row = reinterpret_cast<const f32x4*>(p.obs + (d0 < p.n ? d0 : 0) * p.in_dim);
+        const f32x2* row = reinterpret_cast<const f32x2*>(p.obs + (d0 < p.n ? d0 : 0) * p.in_dim + half * hh);
 #pragma unroll
-        for (int q = 0; q < 3; ++q) xpre[q] = row[4 * (3 * hh + q) < p.in_dim ? 3 * hh + q : 0];
+        for (int q = 0; q < 6; ++q) xpre[q] = row[2 * q < half ? q : 0];
     }
     MergeRegs mr;
     if (p.mg.rows) merge_request(p.mg, mr);     // the tile sums travel together with the weight image
@@ -157,30 +160,30 @@ __global__ __launch_bounds__(THREADS) void policy_forward_kernel(PolicyArgs p, i
     for (int64_t base = (int64_t)blockIdx.x * kChunk; base < rows; base += (int64_t)gridDim.x * kChunk) {
         const int64_t d = base + wave * 32 + col;   // this lane's drone (both halves of the wave share it)
         const bool live = d < rows;
-        // ---- observation: half 0 holds k = 0..11, half 1 holds k = 12..23 (20..23 are zero padding)
+        // ---- observation: half h of the wave holds words k = half * h + j, j < half (10 + 10 for the hover row)
         float x[12];
         {
-            const f32x4* row = reinterpret_cast<const f32x4*>(p.obs + (live ? d : 0) * p.in_dim);
+            const f32x2* row = reinterpret_cast<const f32x2*>(p.obs + (live ? d : 0) * p.in_dim + half * h);
             const bool first_chunk = base == (int64_t)blockIdx.x * kChunk;     // its rows were requested before the staging
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const bool have = live && 4 * (3 * h + q) < p.in_dim;
-                f32x4 v = xpre[q];
-                if (!first_chunk) v = row[have ? 3 * h + q : 0];
-                if (!have) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
-                xpre[q] = f32x4{0.f, 0.f, 0.f, 0.f};      // dead from here on
+            for (int q = 0; q < 6; ++q) {
+                const bool have = live && 2 * q < half;
+                f32x2 v = xpre[q];
+                if (!first_chunk) v = row[have ? q : 0];
+                if (!have) v = f32x2{0.f, 0.f};
+                x[2 * q] = v.x; x[2 * q + 1] = v.y;
+                xpre[q] = f32x2{0.f, 0.f};      // dead from here on
             }
 #pragma unroll
             for (int j = 0; j < 12; ++j) {
-                const int k = 12 * h + j;
-                if (k < p.in_dim) x[j] = fminf(fmaxf((x[j] - hb[660 + k]) * hb[680 + k], -clip), clip);
+                const int k = half * h + j;
+                if (j < half) x[j] = fminf(fmaxf((x[j] - hb[660 + k]) * hb[680 + k], -clip), clip);
             }
             if (p.obs_n && live) {
-                f32x4* out = reinterpret_cast<f32x4*>(p.obs_n + d * p.in_dim);
+                f32x2* out = reinterpret_cast<f32x2*>(p.obs_n + d * p.in_dim + half * h);
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
-                    if (4 * (3 * h + q) < p.in_dim) out[3 * h + q] = f32x4{x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+                for (int q = 0; q < 6; ++q)
+                    if (2 * q < half) out[q] = f32x2{x[2 * q], x[2 * q + 1]};
             }
         }
 
@@ -190,14 +193,16 @@ __global__ __launch_bounds__(THREADS) void policy_forward_kernel(PolicyArgs p, i
         for (int sl = 0; sl < net_count; ++sl) {
             const int net = net_first + sl;
             const float* nb = lds + sl * kNetFloats;
-            // ---- layer 1: 20 (padded 24) -> 128
+            // ---- layer 1: in_dim -> 128, in_dim / 2 products per tile (10 for the hover row: no padded k)
             Hidden a;
             bias_init(a, nb + kOffB1, h);
 #pragma unroll
             for (int s = 0; s < 12; ++s)
+                if (s < half) {                   // uniform
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    a.t[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(nb[kOffW1 + (m * 12 + s) * 64 + lane], x[s], a.t[m], 0, 0, 0);
+                    for (int m = 0; m < 4; ++m)
+                        a.t[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(nb[kOffW1 + (m * 12 + s) * 64 + lane], x[s], a.t[m], 0, 0, 0);
+                }
             FPV_STAMP(4 + 5 * sl);
             tanh_all(a);
             FPV_STAMP(5 + 5 * sl);

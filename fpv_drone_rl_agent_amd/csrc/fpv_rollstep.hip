@@ -39,6 +39,7 @@ struct RollStepArgs {
     MergeArgs mg;            // mg.rows != null: fold the previous launch's rows into rms first
     // ---- env side: st.obs holds obs_t on entry and obs_{t+1} on exit; st.actions is not used
     StepArgs<float> st;
+    uint64_t* stamps;        // diagnostic (fpv_debug_rollout_stamps): [grid][8] s_memrealtime values, or null
 };
 
 // LDS map of phase 2, in floats from the start of the (dead) weight image
@@ -51,74 +52,69 @@ constexpr int kRsSum = kRsXch + 4 * 256;                    // 4 x kPartialWords
 static_assert((kRsXch * 4) % 8 == 0 && (kRsSum * 4) % 8 == 0, "fp64 areas must be 8-byte aligned");
 static_assert(kRsSum + 2 * 4 * kPartialWords <= 2 * kNetFloats, "phase-2 exchange must fit in the weight image's space");
 
+// Workgroup barrier that publishes LDS only: waits for this wave's LDS operations, not for its global stores.  __syncthreads()
+// drains vmcnt too, and in these kernels every barrier would then wait out the ~1-2 us of the rollout-buffer / ledger / flag
+// stores issued just before it.  Nothing here passes GLOBAL data between waves of a workgroup across a barrier (where a row is
+// handed to other workgroups the storing wave drains it explicitly).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---------------------------------------------------------------- phase 1: fpv_policy.hip's body for one 256-drone chunk
 #pragma clang fp contract(fast)
-__device__ __forceinline__ f32x4 rollstep_policy_phase(const RollStepArgs& p, float* lds) {
-    constexpr int THREADS = 512;
-    float* hb = lds + 2 * kNetFloats;                // heads [660], then normaliser mean[20], inv[20]
-    const int64_t n = p.st.n;
-    f32x4 xpre[3];
-    {
-        const int64_t d0 = (int64_t)blockIdx.x * (THREADS / 2) + (threadIdx.x >> 6) * 32 + (threadIdx.x & 31);
-        const int hh = (threadIdx.x >> 5) & 1;
-        const f32x4* row = reinterpret_cast<const f32x4*>(p.st.obs + (d0 < n ? d0 : 0) * kIn);
-#pragma unroll
-        for (int q = 0; q < 3; ++q) xpre[q] = row[4 * (3 * hh + q) < kIn ? 3 * hh + q : 0];
-    }
-    MergeRegs mr;
-    if (p.mg.rows) merge_request(p.mg, mr);
-    {
-        const f32x4* src = reinterpret_cast<const f32x4*>(p.image);
-        f32x4* dst = reinterpret_cast<f32x4*>(lds);
-        constexpr int kNetGran = kNetFloats / 4, kPer = (kNetGran + THREADS - 1) / THREADS;
-        constexpr int kHeadGran = (kImageFloats - kHeadBase) / 4;
-        const f32x4 hv = reinterpret_cast<const f32x4*>(p.image + kHeadBase)[threadIdx.x < kHeadGran ? threadIdx.x : 0];
-        for (int sl = 0; sl < 2; ++sl) {
-            f32x4 stage[kPer];
-#pragma unroll
-            for (int q = 0; q < kPer; ++q) {
-                const int g = q * THREADS + threadIdx.x;
-                stage[q] = src[sl * kNetGran + (g < kNetGran ? g : 0)];
-            }
-#pragma unroll
-            for (int q = 0; q < kPer; ++q) {
-                const int g = q * THREADS + threadIdx.x;
-                if (g < kNetGran) dst[sl * kNetGran + g] = stage[q];
-            }
-        }
-        if (threadIdx.x < kHeadGran) reinterpret_cast<f32x4*>(hb)[threadIdx.x] = hv;
-        if (!p.mg.rows && (int)threadIdx.x < kIn) {
-            hb[660 + threadIdx.x] = p.rms ? (float)p.rms[threadIdx.x] : 0.0f;
-            hb[680 + threadIdx.x] = p.rms ? (float)(1.0 / sqrt(p.rms[kIn + threadIdx.x] + (double)p.eps_norm)) : 1.0f;
-        }
-    }
-    if (p.mg.rows) merge_prologue(p.mg, mr, p.rms, reinterpret_cast<double*>(hb + 700), p.eps_norm, hb + 660, hb + 680);
-    __syncthreads();
+// per-step destinations of the policy outputs (each may be null except value)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int kHalf = kIn / 2;                              // 10: words of a row held by one lane half (k = 10 h + j)
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int col = lane & 31, h = lane >> 5;
-    const float clip = p.rms ? p.clip_obs : 3.0e38f;
-    const int64_t d = (int64_t)blockIdx.x * (THREADS / 2) + wave * 32 + col;
-    const bool live = d < n;
-    float x[12];
+struct PolicyOut {
+    float* obs_n; float* action; float* clipped; float* value; float* logp;
+};
+
+// weight-image floats [first, first + count) -> the same offsets of LDS; count a multiple of 4.  Every granule of a
+// thread is requested before the first one is written.
+template <int kMaxPer>
+__device__ __forceinline__ void rs_stage(const float* __restrict__ image, float* lds, int first, int count) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(image + first);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds + first);
+    const int gran = count / 4;
+    f32x4 stage[kMaxPer];
+#pragma unroll
+    for (int q = 0; q < kMaxPer; ++q) {
+        const int g = q * 512 + (int)threadIdx.x;
+        stage[q] = src[g < gran ? g : 0];
+    }
+#pragma unroll
+    for (int q = 0; q < kMaxPer; ++q) {
+        const int g = q * 512 + (int)threadIdx.x;
+        if (g < gran) dst[g] = stage[q];
+    }
+}
+
+// normalise -> pi, V -> sample -> log-prob -> clip for this lane's drone d (both halves of the wave share it); xraw = the raw
+// observation words 10 h .. 10 h + 9 of d.  Weights and normaliser are in LDS.
+// lane = threadIdx.x & 63, passed in so that a caller with a step loop can hide it from loop-invariant code motion (hipcc
+// otherwise precomputes every LDS address of the unrolled layers outside the loop, one register each).
+__device__ __forceinline__ f32x4 rs_policy_core(const float* lds, const f32x2 (&xraw)[5], int64_t d, bool live, bool normalise,
+                                                float clip_obs, const PolicyOut& out, uint64_t tick, uint64_t pol_seed,
+                                                uint64_t pol_id_offset, int lane) {
+    const float* hb = lds + 2 * kNetFloats;
+    const int h = lane >> 5;
+    const float clip = normalise ? clip_obs : 3.0e38f;
+    float x[kHalf];
     {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const bool have = live && 4 * (3 * h + q) < kIn;
-            f32x4 v = xpre[q];
-            if (!have) v = f32x4{0.f, 0.f, 0.f, 0.f};
-            x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+        for (int q = 0; q < kHalf / 2; ++q) {
+            f32x2 v = xraw[q];
+            if (!live) v = f32x2{0.f, 0.f};
+            x[2 * q] = v.x; x[2 * q + 1] = v.y;
         }
 #pragma unroll
-        for (int j = 0; j < 12; ++j) {
-            const int k = 12 * h + j;
-            if (k < kIn) x[j] = fminf(fmaxf((x[j] - hb[660 + k]) * hb[680 + k], -clip), clip);
+        for (int j = 0; j < kHalf; ++j) {
+            const int k = kHalf * h + j;
+            x[j] = fminf(fmaxf((x[j] - hb[660 + k]) * hb[680 + k], -clip), clip);
         }
-        if (p.obs_n && live) {
-            f32x4* out = reinterpret_cast<f32x4*>(p.obs_n + d * kIn);
+        if (out.obs_n && live) {
+            f32x2* o = reinterpret_cast<f32x2*>(out.obs_n + d * kIn + kHalf * h);
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
-                if (4 * (3 * h + q) < kIn) out[3 * h + q] = f32x4{x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+            for (int q = 0; q < kHalf / 2; ++q) o[q] = f32x2{x[2 * q], x[2 * q + 1]};
         }
     }
     float head[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
@@ -128,7 +124,7 @@ __device__ __forceinline__ f32x4 rollstep_policy_phase(const RollStepArgs& p, fl
         Hidden a;
         bias_init(a, nb + kOffB1, h);
 #pragma unroll
-        for (int s = 0; s < 12; ++s)
+        for (int s = 0; s < kHalf; ++s)            // 10 products per tile: no padded k (the image keeps 12 slots per tile)
 #pragma unroll
             for (int m = 0; m < 4; ++m)
                 a.t[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(nb[kOffW1 + (m * 12 + s) * 64 + lane], x[s], a.t[m], 0, 0, 0);
@@ -168,17 +164,15 @@ __device__ __forceinline__ f32x4 rollstep_policy_phase(const RollStepArgs& p, fl
     }
 #pragma unroll
     for (int j = 0; j < 5; ++j) head[j] = half_sum(head[j]);
-    if (live && h == 1) p.value[d] = head[4] + hb[644];
+    if (live && h == 1) out.value[d] = head[4] + hb[644];
     const float mu[4] = {head[0] + hb[640], head[1] + hb[641], head[2] + hb[642], head[3] + hb[643]};
 
-    // sample: Philox4x32-10 keyed like fpv_policy.hip (stream tag 'POL1'); the agent tick is this workgroup's own tile's copy
-    // (all copies are equal, and tile 0's is advanced by workgroup 0 in phase 2 while others may still be here)
+    // sample: Philox4x32-10 keyed like fpv_policy.hip (stream tag 'POL1')
     float eps[4];
     {
-        const uint64_t t = p.st.tick[(int64_t)blockIdx.x * 4];
         uint32_t xr[4];
-        philox4x32_10((uint32_t)(p.pol_id_offset + (uint64_t)d), (uint32_t)t, (uint32_t)(t >> 32), 0x504F4C31u,
-                      (uint32_t)p.pol_seed, (uint32_t)(p.pol_seed >> 32), xr);
+        philox4x32_10((uint32_t)(pol_id_offset + (uint64_t)d), (uint32_t)tick, (uint32_t)(tick >> 32), 0x504F4C31u,
+                      (uint32_t)pol_seed, (uint32_t)(pol_seed >> 32), xr);
         constexpr float k24 = 5.9604644775390625e-8f, m2ln2 = -1.3862943611198906f;
         const float u0 = ((float)(xr[0] >> 8) + 0.5f) * k24, u1 = ((float)(xr[1] >> 8) + 0.5f) * k24;
         const float u2 = ((float)(xr[2] >> 8) + 0.5f) * k24, u3 = ((float)(xr[3] >> 8) + 0.5f) * k24;
@@ -196,34 +190,67 @@ __device__ __forceinline__ f32x4 rollstep_policy_phase(const RollStepArgs& p, fl
                            fminf(fmaxf(act[2], -1.f), 1.f), fminf(fmaxf(act[3], -1.f), 1.f)};
     if (live) {
         if (h == 0) {
-            if (p.action) reinterpret_cast<f32x4*>(p.action)[d] = f32x4{act[0], act[1], act[2], act[3]};
-            if (p.clipped) reinterpret_cast<f32x4*>(p.clipped)[d] = cl;
-        } else if (p.logp) {
-            p.logp[d] = lp;
+            if (out.action) reinterpret_cast<f32x4*>(out.action)[d] = f32x4{act[0], act[1], act[2], act[3]};
+            if (out.clipped) reinterpret_cast<f32x4*>(out.clipped)[d] = cl;
+        } else if (out.logp) {
+            out.logp[d] = lp;
         }
     }
     return cl;
 }
+
+// staging, merge prologue and the observation rows (from memory) of the one-step kernel; ends with a workgroup barrier
+__device__ __forceinline__ void rollstep_prologue(const RollStepArgs& p, float* lds, f32x2 (&xpre)[5]) {
+    float* hb = lds + 2 * kNetFloats;                // heads [660], then normaliser mean[20], inv[20]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const int64_t d = (int64_t)blockIdx.x * 256 + wave * 32 + col;
+    {
+        const f32x2* row = reinterpret_cast<const f32x2*>(p.st.obs + (d < p.st.n ? d : 0) * kIn + kHalf * h);
+#pragma unroll
+        for (int q = 0; q < kHalf / 2; ++q) xpre[q] = row[q];
+    }
+    MergeRegs mr;
+    if (p.mg.rows) merge_request(p.mg, mr);
+    rs_stage<(kImageFloats / 4 + 511) / 512>(p.image, lds, 0, kImageFloats);
+    if (!p.mg.rows && (int)threadIdx.x < kIn) {
+        hb[660 + threadIdx.x] = p.rms ? (float)p.rms[threadIdx.x] : 0.0f;
+        hb[680 + threadIdx.x] = p.rms ? (float)(1.0 / sqrt(p.rms[kIn + threadIdx.x] + (double)p.eps_norm)) : 1.0f;
+    }
+    if (p.mg.rows) merge_prologue(p.mg, mr, p.rms, reinterpret_cast<double*>(hb + 700), p.eps_norm, hb + 660, hb + 680);
+    __syncthreads();
+}
 #pragma clang fp contract(on)
 
-// ---------------------------------------------------------------- the kernel
-__global__ __launch_bounds__(512) void rollout_step_kernel(RollStepArgs p) {
+// ---------------------------------------------------------------- phase 2: the env step of the workgroup's four tiles
+// Per-step destinations and switches of phase 2.
+struct TailOut {
+    float* reward; uint8_t* terminated; uint8_t* truncated; uint8_t* done;   // [n] each (done may be null)
+    double* partials;        // this step's row table (one row per workgroup) or null
+    bool store_obs;          // write the row-major observation tile to st.obs
+    bool row_write_through;  // publish the row with sc1 stores + drain (read by other workgroups inside this launch)
+    uint64_t* stamps;        // diagnostic: 4 s_memrealtime values of the tile-0 physics wave (pairs done, observed, barrier 6, 7) or null
+};
+
+// Physics-wave registers that live across steps in the persistent kernel; the one-step kernel loads / stores them around
+// one call.
+struct TileRegs {
+    Drone<float> d;
+    uint64_t agent_tick;
+    uint32_t led_fill;
+    float tmpl_lane;
+};
+
+// Called by all 512 threads after the clipped actions are in LDS (kRsAct) and a workgroup barrier.  Contains eight
+// workgroup barriers on every path.  On return the four observation tiles (+ returns) are still in LDS (kRsTile).
+__device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, TileRegs& tr, const TailOut& o_) {
     using T = float;
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const f32x4 cl = rollstep_policy_phase(p, lds);
-
-    const StepArgs<float>& s = p.st;
     const int lane = threadIdx.x & (kTile - 1), wave = threadIdx.x >> 6;
-    __syncthreads();                                   // every wave is done with the weight image: its space is free
-    if (lane < 32) reinterpret_cast<f32x4*>(lds + kRsAct)[wave * 32 + lane] = cl;
-    __syncthreads();
-
     const int tl = wave & 3;                           // tile of this workgroup served by this wave
     const bool helper = wave >= 4;
     const int64_t tile = (int64_t)blockIdx.x * 4 + tl;
     const int64_t i = tile * kTile + lane;
     const bool live = i < s.n;
-    const uint64_t agent_tick = s.tick[tile];
     const uint32_t gid = (uint32_t)(s.id_offset + (uint64_t)i);
     T(*nz)[8][kTile] = reinterpret_cast<T(*)[8][kTile]>(lds + kRsNoise + tl * (2 * 8 * kTile));
     Vec4<T>* tl_lds = reinterpret_cast<Vec4<T>*>(lds + kRsTile + tl * kRsTileFloats);
@@ -234,39 +261,46 @@ __global__ __launch_bounds__(512) void rollout_step_kernel(RollStepArgs p) {
 #pragma unroll 1
         for (int k = 0; k < kSubstepPairs; ++k) {
             T ga[4], gb[4];
-            normal8(s.seed, gid, agent_tick * (uint64_t)kSubstepPairs + (uint64_t)k, ga, gb);
+            normal8(s.seed, gid, tr.agent_tick * (uint64_t)kSubstepPairs + (uint64_t)k, ga, gb);
             T(*slot)[kTile] = nz[k & 1];
             slot[0][lane] = ga[0]; slot[1][lane] = ga[1]; slot[2][lane] = ga[2]; slot[3][lane] = ga[3];
             slot[4][lane] = gb[0]; slot[5][lane] = gb[1]; slot[6][lane] = gb[2]; slot[7][lane] = gb[3];
-            __syncthreads();
+            lds_barrier();
         }
-        __syncthreads();   // barrier 6: the physics wave has staged the observation tile (and the returns)
-        Vec4<T>* out = reinterpret_cast<Vec4<T>*>(s.obs + tile * (kTile * kObsWords));
+        lds_barrier();   // barrier 6: the physics wave has staged the observation tile (and the returns)
         const int64_t rows_left = s.n - tile * kTile;
-#pragma unroll
-        for (int r = 0; r < kObsWords / 4; ++r) {
-            const int f4 = r * kTile + lane;
-            if (f4 / (kObsWords / 4) < rows_left) out[f4] = tl_lds[f4];
-        }
-        if (s.partials) {
+        // the moment sums come first: their in-wave exchange fences would otherwise wait out the tile's global stores
+        if (o_.partials) {
             const int rows = (int)(rows_left < kTile ? (rows_left > 0 ? rows_left : 0) : kTile);
             tile_moment_sums<kObsWords>(reinterpret_cast<const float*>(tl_lds), reinterpret_cast<double*>(lds + kRsXch + tl * 256),
                                         rows, lane, bsum + tl * kPartialWords);
         }
-        __syncthreads();   // barrier 7: the four tiles' sums are in LDS
-        if (s.partials && wave == 4 && lane < kPartialWords)
-            s.partials[(int64_t)blockIdx.x * kPartialWords + lane] =
-                (bsum[lane] + bsum[kPartialWords + lane]) + (bsum[2 * kPartialWords + lane] + bsum[3 * kPartialWords + lane]);
+        if (o_.store_obs) {
+            Vec4<T>* out = reinterpret_cast<Vec4<T>*>(s.obs + tile * (kTile * kObsWords));
+#pragma unroll
+            for (int r = 0; r < kObsWords / 4; ++r) {
+                const int f4 = r * kTile + lane;
+                if (f4 / (kObsWords / 4) < rows_left) out[f4] = tl_lds[f4];
+            }
+        }
+        lds_barrier();   // barrier 7: the four tiles' sums are in LDS
+        if (o_.partials && wave == 4) {
+            if (lane < kPartialWords) {
+                const double v = (bsum[lane] + bsum[kPartialWords + lane]) + (bsum[2 * kPartialWords + lane] + bsum[3 * kPartialWords + lane]);
+                double* row = o_.partials + (int64_t)blockIdx.x * kPartialWords + lane;
+                if (o_.row_write_through) row_store_sc1(row, v);
+                else *row = v;
+            }
+            if (o_.row_write_through) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        tr.agent_tick += 1ull;
         return;
     }
 
     // ---------------- physics wave
-    Drone<T> d;
-    load_drone(d, s.state, tile, lane);
+    Drone<T>& d = tr.d;
     const f32x4 av = reinterpret_cast<const f32x4*>(lds + kRsAct)[tl * kTile + lane];
     const Vec4<T> act = live ? Vec4<T>{av.x, av.y, av.z, av.w} : Vec4<T>{T(0), T(0), T(0), T(-1)};
-    const uint32_t led_fill = s.led_count[tile];
-    const T tmpl_lane = s.tmpl[lane < kStateWords + kObsWords ? lane : 0];
     T ret_in = T(0);
     if (s.ret && live) ret_in = s.ret[i];
     const T spx = act.x * T(30), spy = act.y * T(30), spz = act.z * T(-30);
@@ -274,7 +308,7 @@ __global__ __launch_bounds__(512) void rollout_step_kernel(RollStepArgs p) {
     T pwm[4];
 #pragma unroll 1
     for (int k = 0; k < kSubstepPairs; ++k) {
-        __syncthreads();   // barrier k: pair k's noise is in nz[k & 1]
+        lds_barrier();   // barrier k: pair k's noise is in nz[k & 1]
         T(*slot)[kTile] = nz[k & 1];
         const T ga[4] = {slot[0][lane], slot[1][lane], slot[2][lane], slot[3][lane]};
         const T gb[4] = {slot[4][lane], slot[5][lane], slot[6][lane], slot[7][lane]};
@@ -282,6 +316,7 @@ __global__ __launch_bounds__(512) void rollout_step_kernel(RollStepArgs p) {
         physics_substep<T, true>(d, pwm, s.sigma, ga);
         physics_substep<T, true>(d, pwm, s.sigma, gb);
     }
+    if (o_.stamps && threadIdx.x == 0) o_.stamps[0] = __builtin_amdgcn_s_memrealtime();
     T roll, pitch, yaw;
     euler_from_quat(d.qx, d.qy, d.qz, d.qw, roll, pitch, yaw);
     T o[kObsWords];
@@ -292,22 +327,23 @@ __global__ __launch_bounds__(512) void rollout_step_kernel(RollStepArgs p) {
     d.steps += T(1);
     d.a0 = act.x; d.a1 = act.y; d.a2 = act.z; d.a3 = act.w;
     d.ep_ret += reward;
+    if (o_.stamps && threadIdx.x == 0) o_.stamps[1] = __builtin_amdgcn_s_memrealtime();
 
     const bool done = live && (bits & (kInfoTerm | kInfoTrunc)) != 0;
     const unsigned long long m = __ballot(done);
     if (m != 0ull) {
         Drone<T> r = d;
-        drone_from_template(r, tmpl_lane);
+        drone_from_template(r, tr.tmpl_lane);
         T ro[kObsWords];
 #pragma unroll
-        for (int j = 0; j < kObsWords; ++j) ro[j] = __shfl(tmpl_lane, kStateWords + j);
+        for (int j = 0; j < kObsWords; ++j) ro[j] = __shfl(tr.tmpl_lane, kStateWords + j);
         if (done) {
-            const int64_t row = (int64_t)led_fill + (int64_t)__popcll(m & ((1ull << lane) - 1ull));
+            const int64_t row = (int64_t)tr.led_fill + (int64_t)__popcll(m & ((1ull << lane) - 1ull));
             if (row < s.led_rows) {
                 const int64_t slot = tile * s.led_rows + row;
                 s.led_idx[slot] = (int32_t)i;
                 s.led_info[slot] = bits | ((uint32_t)d.steps << 8);
-                s.led_tag[slot] = (uint32_t)agent_tick;
+                s.led_tag[slot] = (uint32_t)tr.agent_tick;
                 s.led_ret[slot] = d.ep_ret;
                 Vec4<T>* lo = reinterpret_cast<Vec4<T>*>(s.led_obs + slot * kObsWords);
 #pragma unroll
@@ -317,7 +353,8 @@ __global__ __launch_bounds__(512) void rollout_step_kernel(RollStepArgs p) {
 #pragma unroll
             for (int j = 0; j < kObsWords; ++j) o[j] = ro[j];
         }
-        if (lane == 0) s.led_count[tile] = led_fill + (uint32_t)__popcll(m);
+        tr.led_fill += (uint32_t)__popcll(m);
+        if (lane == 0) s.led_count[tile] = tr.led_fill;
     }
 #pragma unroll
     for (int g = 0; g < kObsWords / 4; ++g)
@@ -329,20 +366,351 @@ __global__ __launch_bounds__(512) void rollout_step_kernel(RollStepArgs p) {
             if (live) s.ret[i] = done ? T(0) : ret;
         }
         reinterpret_cast<T*>(tl_lds)[kTile * kObsWords + lane] = ret;
-        if (live && s.done) s.done[i] = done ? 1 : 0;
+        if (live && o_.done) o_.done[i] = done ? 1 : 0;
     }
-    __syncthreads();   // barrier 6
-    store_drone(d, s.state, tile, lane);
-    if (lane == 0) s.tick[tile] = agent_tick + 1ull;
+    lds_barrier();   // barrier 6
+    if (o_.stamps && threadIdx.x == 0) o_.stamps[2] = __builtin_amdgcn_s_memrealtime();
     if (live) {
-        s.reward[i] = reward;
-        s.terminated[i] = (bits & kInfoTerm) ? 1 : 0;
-        s.truncated[i] = (bits & kInfoTrunc) ? 1 : 0;
+        o_.reward[i] = reward;
+        o_.terminated[i] = (bits & kInfoTerm) ? 1 : 0;
+        o_.truncated[i] = (bits & kInfoTrunc) ? 1 : 0;
     }
-    __syncthreads();   // barrier 7
+    tr.agent_tick += 1ull;
+    lds_barrier();   // barrier 7
+    if (o_.stamps && threadIdx.x == 0) o_.stamps[3] = __builtin_amdgcn_s_memrealtime();
 }
 
-// ---------------------------------------------------------------- launcher
+// physics waves: drone state, ledger fill and reset template of the wave's tile; every wave: the tile's agent tick
+__device__ __forceinline__ void rs_load_state(const StepArgs<float>& s, TileRegs& tr) {
+    const int lane = threadIdx.x & (kTile - 1), wave = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (wave & 3);
+    tr.led_fill = 0u;
+    tr.tmpl_lane = 0.0f;
+    if (wave < 4) {
+        load_drone(tr.d, s.state, tile, lane);
+        tr.led_fill = s.led_count[tile];
+        tr.tmpl_lane = s.tmpl[lane < kStateWords + kObsWords ? lane : 0];
+    }
+}
+__device__ __forceinline__ void rs_load_tile(const StepArgs<float>& s, TileRegs& tr) {
+    tr.agent_tick = s.tick[(int64_t)blockIdx.x * 4 + ((threadIdx.x >> 6) & 3)];
+    rs_load_state(s, tr);
+}
+__device__ __forceinline__ void rs_store_state(const StepArgs<float>& s, const TileRegs& tr) {
+    const int lane = threadIdx.x & (kTile - 1), wave = threadIdx.x >> 6;
+    if (wave < 4) store_drone(tr.d, s.state, (int64_t)blockIdx.x * 4 + (wave & 3), lane);
+}
+__device__ __forceinline__ void rs_store_tile(const StepArgs<float>& s, const TileRegs& tr) {
+    const int lane = threadIdx.x & (kTile - 1), wave = threadIdx.x >> 6;
+    rs_store_state(s, tr);
+    if (wave < 4 && lane == 0) s.tick[(int64_t)blockIdx.x * 4 + (wave & 3)] = tr.agent_tick;
+}
+
+// ---------------------------------------------------------------- the one-step kernel
+__global__ __launch_bounds__(512) void rollout_step_kernel(RollStepArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+#define RS1_STAMP(k) do { if (p.stamps && threadIdx.x == 0) p.stamps[(int64_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    RS1_STAMP(0);
+    f32x2 xpre[5];
+    rollstep_prologue(p, lds, xpre);
+    RS1_STAMP(1);
+    // the drone state is requested here: it is needed only in phase 2, so its latency hides under the matrix work
+    TileRegs tr;
+    rs_load_tile(p.st, tr);
+    f32x4 cl;
+    {
+        const int64_t d = (int64_t)blockIdx.x * 256 + (threadIdx.x >> 6) * 32 + (threadIdx.x & 31);
+        // the agent tick is this workgroup's own tile's copy (all copies are equal, and tile 0's is advanced by workgroup 0
+        // in phase 2 while other workgroups may still be here)
+        const PolicyOut out{p.obs_n, p.action, p.clipped, p.value, p.logp};
+        cl = rs_policy_core(lds, xpre, d, d < p.st.n, p.rms != nullptr, p.clip_obs, out, p.st.tick[(int64_t)blockIdx.x * 4],
+                            p.pol_seed, p.pol_id_offset, (int)(threadIdx.x & 63));
+    }
+    const int lane = threadIdx.x & (kTile - 1), wave = threadIdx.x >> 6;
+    lds_barrier();                                     // every wave is done with the weight image: its space is free
+    RS1_STAMP(2);
+    if (lane < 32) reinterpret_cast<f32x4*>(lds + kRsAct)[wave * 32 + lane] = cl;
+    lds_barrier();
+    const TailOut to{p.st.reward, p.st.terminated, p.st.truncated, p.st.done, p.st.partials, true, false,
+                     p.stamps ? p.stamps + (int64_t)blockIdx.x * 8 + 4 : nullptr};
+    rs_tail(p.st, lds, tr, to);
+    rs_store_tile(p.st, tr);
+    RS1_STAMP(3);
+#undef RS1_STAMP
+}
+
+// ---------------------------------------------------------------- the persistent kernel: T rollout steps in one launch
+// One workgroup per CU keeps the weight image in LDS and its 256 drones' state in registers for the whole rollout.  What
+// crosses workgroups is VecNormalize's statistics only: RunningMeanStd.update needs the moment sums of ALL drones of step t
+// before any drone's observation of step t + 1 is normalised (SB3 VecNormalize.step_wait), so the steps are separated by a
+// grid-wide barrier behind which every workgroup folds the same n / 256 rows in the same fixed order (the order of
+// merge_prologue, fpv_internal.h: identical bits) and carries the running statistics in registers.  A kernel boundary costs
+// the same wait plus a relaunch with cold weights; here the barrier replaces it.
+//   hand-off (cdna_hip_programming.md Guideline 16, R1): rows leave with sc1 (write-through) stores, drained by the storing
+//   wave, then a workgroup barrier, then thread 0 arrives: group counter (blockIdx & 7, one 128-B line each) -> top counter ->
+//   the last arriver writes every group's generation word; thread 0 polls its group's word (relaxed sc1 load + s_sleep);
+//   after a workgroup barrier all threads read the rows with sc1 loads.  Counters are monotonic over the launch and zeroed by
+//   the host before it.
+//   Every wait is bounded (s_memrealtime): on a timeout the waiter raises the abort word, every workgroup leaves its loop at
+//   its next wait, and the status word tells the host that the rollout is invalid.  All workgroups must be co-resident: the
+//   grid is at most one workgroup per CU (160 KB of LDS each) and the launch is a cooperative one, which checks that.
+// Per step the first kRsEnd floats of the image (the phase-2 exchange space) are staged again from L2 while the barrier is
+// awaited.
+constexpr int kRsEnd = kRsSum + 2 * 4 * kPartialWords;      // 11 872 floats = 47.5 KB
+constexpr int kSyncStride = 32;                            // words: one 128-B line per counter
+constexpr int kSyncGroups = kPrologueMergeWays;            // 9 groups = the 9 ways of merge_prologue's summation order
+constexpr int kSyncTop = kSyncGroups, kSyncGen = kSyncGroups + 1, kSyncAbort = 2 * kSyncGroups + 1;
+constexpr int kSyncCounterWords = (2 * kSyncGroups + 2) * kSyncStride;
+constexpr int kSyncWayDoubles = kSyncGroups * kPartialWords;                     // the groups' sums, then the total
+constexpr int kSyncWords = kSyncCounterWords + 2 * (kSyncWayDoubles + kPartialWords);
+
+struct RollPersistArgs {
+    const float* image;
+    uint64_t pol_seed, pol_id_offset;
+    float clip_obs, eps_norm;
+    StepArgs<float> st;          // state / tick / ledger / ret / gamma / noise; st.obs: obs_0 in, obs_T out; st.terminated / truncated:
+                                 // the last step's flags; st.reward / done / partials are not used
+    int32_t T;
+    float* obs_n;                // time-major rollout buffers, step t at base + t * n * width; obs_n / action / logp may be null
+    float* action;
+    float* value;
+    float* logp;
+    float* reward;               // [T][n] raw rewards
+    uint8_t* done;               // [T][n] or null
+    const double* rms0;          // [41] statistics entering step 0, or null (no observation normalisation)
+    const double* ret_rms0;      // [3] or null
+    double* rms_out[2];          // statistics after folding step t's sums -> [(t + 1) & 1]   (t = 0 .. T - 2)
+    double* ret_rms_out[2];
+    double* snapshots;           // row t <- statistics after folding step t's sums (t = 0 .. T - 2); may be null
+    int64_t snap_stride;
+    double* rows[2];             // [n / 256][kPartialWords]; step t's sums go to rows[t & 1]
+    uint32_t* sync;              // kSyncWords words, zero at launch
+    uint32_t* status;            // set to 1 when a grid wait timed out
+    uint64_t timeout_ticks;      // of s_memrealtime (100 MHz)
+    uint64_t* stamps;            // diagnostic (tools/rollout_phases.py): [grid][T][8] s_memrealtime values, or null
+};
+
+__device__ __forceinline__ uint32_t sync_load(const uint32_t* w) {
+    return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The grid-wide barrier that carries the reduction.  Called by ALL threads after the workgroup's row of step sums has been
+// stored write-through and drained and a workgroup barrier has passed.  On success xch[0 .. 43] holds the column sums of
+// all rows, added in merge_prologue's order: way g = rows g, g + 9, g + 18, ... in that order, then the ways 0 .. 8 in order.
+//   arrive on group counter g = blockIdx % 9; the group's last arriver adds the group's rows (that IS way g) and publishes the
+//   way sum; it then arrives on the top counter, whose last arriver adds the nine way sums, publishes the total and releases
+//   every group's generation word; everyone polls its group's word and reads the 352-byte total.
+// All cross-workgroup data moves with sc1 stores (drained before the next counter operation) and sc1 loads; counters are
+// monotonic over the launch.  epoch counts from 1.  flag: an LDS word.  Returns false when the wait was abandoned.
+__device__ __forceinline__ bool grid_reduce(uint32_t* w, const double* rows, uint32_t epoch, uint32_t nblocks, uint64_t timeout_ticks,
+                                            double* xch, int* flag) {
+    const int tid = threadIdx.x;
+    const uint32_t g = blockIdx.x % (uint32_t)kSyncGroups;
+    const uint32_t members = (nblocks - g + kSyncGroups - 1) / kSyncGroups;      // workgroups b < nblocks with b % 9 == g
+    const uint32_t groups = nblocks < (uint32_t)kSyncGroups ? nblocks : (uint32_t)kSyncGroups;
+    double* way = reinterpret_cast<double*>(w + kSyncCounterWords);
+    double* total = way + kSyncWayDoubles;
+    if (tid == 0) {
+        const uint32_t a = __hip_atomic_fetch_add(w + g * kSyncStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = a + 1u == members * epoch;
+    }
+    lds_barrier();
+    const bool group_last = *flag != 0;
+    lds_barrier();
+    if (group_last) {                                  // uniform
+        if (tid < kPartialWords) {
+            constexpr int kQ = (256 + kSyncGroups - 1) / kSyncGroups;             // 29: the grid has <= 256 rows
+            double v[kQ];
+#pragma unroll
+            for (int q = 0; q < kQ; ++q) {
+                const uint32_t b = g + (uint32_t)q * kSyncGroups;
+                v[q] = b < nblocks ? row_load_sc1(rows + (int64_t)b * kPartialWords + tid) : 0.0;
+            }
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < kQ; ++q) acc += v[q];
+            row_store_sc1(way + g * kPartialWords + tid, acc);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        lds_barrier();
+        if (tid == 0) {
+            const uint32_t b = __hip_atomic_fetch_add(w + kSyncTop * kSyncStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = b + 1u == groups * epoch;
+        }
+        lds_barrier();
+        const bool top_last = *flag != 0;
+        lds_barrier();
+        if (top_last) {                                // uniform
+            if (tid < kPartialWords) {
+                double v[kSyncGroups];
+#pragma unroll
+                for (int k = 0; k < kSyncGroups; ++k)
+                    v[k] = (uint32_t)k < groups ? row_load_sc1(way + k * kPartialWords + tid) : 0.0;
+                double tt = 0.0;
+#pragma unroll
+                for (int k = 0; k < kSyncGroups; ++k) tt += v[k];
+                row_store_sc1(total + tid, tt);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            lds_barrier();
+            if (tid == 0)
+                for (uint32_t k = 0; k < groups; ++k)
+                    __hip_atomic_store(w + (kSyncGen + k) * kSyncStride, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (tid == 0) {
+        bool ok = true;
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        uint32_t polls = 0;
+        while (sync_load(w + (kSyncGen + g) * kSyncStride) < epoch) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++polls & 15u) == 0u) {
+                if (sync_load(w + kSyncAbort * kSyncStride) != 0u) { ok = false; break; }
+                if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
+                    __hip_atomic_store(w + kSyncAbort * kSyncStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = false;
+                    break;
+                }
+            }
+        }
+        *flag = ok ? 1 : 0;
+    }
+    lds_barrier();
+    const bool ok = *flag != 0;
+    if (ok && tid < kPartialWords) xch[tid] = row_load_sc1(total + tid);
+    lds_barrier();
+    return ok;
+}
+
+__global__ __launch_bounds__(512) void rollout_persistent_kernel(RollPersistArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* hb = lds + 2 * kNetFloats;
+    double* xch = reinterpret_cast<double*>(hb + 700);
+    int* flag = reinterpret_cast<int*>(hb + 658);              // padding word of the head block: never read by the policy
+    const StepArgs<float>& s = p.st;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = lane & 31, h = lane >> 5;
+    const int64_t n = s.n;
+    const int64_t d = (int64_t)blockIdx.x * 256 + wave * 32 + col;
+    const bool normalise = p.rms0 != nullptr;
+
+    f32x2 xraw[5];
+    {
+        const f32x2* row = reinterpret_cast<const f32x2*>(s.obs + d * kIn + kHalf * h);
+#pragma unroll
+        for (int q = 0; q < kHalf / 2; ++q) xraw[q] = row[q];
+    }
+    rs_stage<(kImageFloats / 4 + 511) / 512>(p.image, lds, 0, kImageFloats);
+    // running statistics in registers: thread c < 20 owns observation channel c, thread 40 the discounted-return statistics
+    const bool own_obs = tid < kIn && normalise, own_ret = tid == 2 * kIn && p.ret_rms0 != nullptr;
+    double st_mean = 0.0, st_var = 1.0, st_cnt = 0.0;
+    if (own_obs) { st_mean = p.rms0[tid]; st_var = p.rms0[kIn + tid]; st_cnt = p.rms0[2 * kIn]; }
+    if (own_ret) { st_mean = p.ret_rms0[0]; st_var = p.ret_rms0[1]; st_cnt = p.ret_rms0[2]; }
+    if (tid < kIn) {
+        hb[660 + tid] = normalise ? (float)st_mean : 0.0f;
+        hb[680 + tid] = normalise ? (float)(1.0 / sqrt(st_var + (double)p.eps_norm)) : 1.0f;
+    }
+    // The drone state is NOT carried in registers across the policy pass (it would push that pass over its register budget):
+    // the physics waves store it at the end of their env step and ask for it again as soon as their policy pass is done —
+    // they are the older waves of their SIMDs and finish it ~28 k cycles before the younger ones, so the loads have landed
+    // by the time the workgroup meets.  The tick stays in a register (it is read by the helper waves too).
+    TileRegs tr;
+    tr.agent_tick = s.tick[(int64_t)blockIdx.x * 4 + (wave & 3)];
+    const uint64_t pol_tick0 = s.tick[(int64_t)blockIdx.x * 4];
+    const double bc = (double)n;
+    const int nrows = (int)gridDim.x;
+    bool ok = true;
+    lds_barrier();
+
+#define RS_STAMP(k) do { if (p.stamps && tid == 0) p.stamps[((int64_t)blockIdx.x * p.T + t) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#pragma unroll 1
+    for (int t = 0; t < p.T; ++t) {
+        RS_STAMP(0);
+        const int64_t off = (int64_t)t * n;
+        const PolicyOut out{p.obs_n ? p.obs_n + off * kIn : nullptr, p.action ? p.action + off * kAct : nullptr, nullptr,
+                            p.value + off, p.logp ? p.logp + off : nullptr};
+        // opaque per iteration: hipcc otherwise hoists the layers' LDS addresses and the head weights' LDS loads (hundreds of
+        // registers) out of the step loop
+        int lane_o = lane, zero = 0;
+        asm volatile("" : "+v"(lane_o), "+s"(zero));
+        const f32x4 cl = rs_policy_core(lds + zero, xraw, d, true, normalise, p.clip_obs, out, pol_tick0 + (uint64_t)t, p.pol_seed,
+                                        p.pol_id_offset, lane_o);
+        rs_load_state(s, tr);
+        lds_barrier();                               // every wave is done with the weight image's head: phase-2 space is free
+        RS_STAMP(1);
+        if (lane < 32) reinterpret_cast<f32x4*>(lds + kRsAct)[wave * 32 + lane] = cl;
+        lds_barrier();
+        const bool last = t == p.T - 1;
+        const TailOut to{p.reward + off, s.terminated, s.truncated, p.done ? p.done + off : nullptr, p.rows[t & 1], last, !last, nullptr};
+        rs_tail(s, lds, tr, to);
+        rs_store_state(s, tr);
+        RS_STAMP(2);
+        if (last) break;
+
+        // ---- hand-over to step t + 1
+        {   // this lane's raw observation words for the next policy pass, from the staged tiles
+            const float* tb = lds + kRsTile + (wave >> 1) * kRsTileFloats + ((wave & 1) * 32 + col) * kObsWords + kHalf * h;
+#pragma unroll
+            for (int q = 0; q < kHalf / 2; ++q) xraw[q] = *reinterpret_cast<const f32x2*>(tb + 2 * q);
+        }
+        {   // the weight image's head again: requested now, written once every wave has read its rows
+            constexpr int kGran = kRsEnd / 4, kPer = (kGran + 511) / 512;
+            const f32x4* src = reinterpret_cast<const f32x4*>(p.image);
+            f32x4 stage[kPer];
+#pragma unroll
+            for (int q = 0; q < kPer; ++q) {
+                const int g = q * 512 + tid;
+                stage[q] = src[g < kGran ? g : 0];
+            }
+            lds_barrier();                           // rows read; the row's write-through stores are drained (rs_tail)
+#pragma unroll
+            for (int q = 0; q < kPer; ++q) {
+                const int g = q * 512 + tid;
+                if (g < kGran) reinterpret_cast<f32x4*>(lds)[g] = stage[q];
+            }
+        }
+        RS_STAMP(3);
+        ok = grid_reduce(p.sync, p.rows[t & 1], (uint32_t)(t + 1), (uint32_t)nrows, p.timeout_ticks, xch, flag);
+        RS_STAMP(4);
+        if (!ok) break;                                // uniform
+
+        // ---- RunningMeanStd.update with step t's column sums, every workgroup alike (merge_prologue's expressions)
+        {
+            const bool publish = blockIdx.x == 0;
+            if (own_obs || own_ret) {
+                const double bm = (own_obs ? xch[tid] : xch[2 * kIn]) / bc;
+                double bv = (own_obs ? xch[kIn + tid] : xch[2 * kIn + 1]) / bc - bm * bm;
+                if (bv < 0.0) bv = 0.0;
+                const double delta = bm - st_mean, tot = st_cnt + bc;
+                const double nm = st_mean + delta * bc / tot;
+                const double nv = (st_var * st_cnt + bv * bc + delta * delta * st_cnt * bc / tot) / tot;
+                st_mean = nm; st_var = nv; st_cnt = tot;
+                double* snap = p.snapshots ? p.snapshots + (int64_t)t * p.snap_stride : nullptr;
+                if (own_obs) {
+                    hb[660 + tid] = (float)nm;
+                    hb[680 + tid] = (float)(1.0 / sqrt(nv + (double)p.eps_norm));
+                    if (publish) {
+                        double* ro = p.rms_out[(t + 1) & 1];
+                        if (ro) { ro[tid] = nm; ro[kIn + tid] = nv; if (tid == 0) ro[2 * kIn] = tot; }
+                        if (snap) { snap[tid] = nm; snap[kIn + tid] = nv; if (tid == 0) snap[2 * kIn] = tot; }
+                    }
+                } else if (publish) {
+                    double* ro = p.ret_rms_out[(t + 1) & 1];
+                    if (ro) { ro[0] = nm; ro[1] = nv; ro[2] = tot; }
+                    if (snap) { snap[41] = nm; snap[42] = nv; snap[43] = tot; }
+                }
+            }
+            lds_barrier();
+        }
+        RS_STAMP(5);
+    }
+#undef RS_STAMP
+    if (wave < 4 && lane == 0) s.tick[(int64_t)blockIdx.x * 4 + (wave & 3)] = tr.agent_tick;
+    if (!ok && tid == 0) *p.status = 1u;
+}
+
+// ---------------------------------------------------------------- launchers
+uint64_t* g_rollout_stamps = nullptr;
+
 // Preconditions (checked by fpv_rollout_step): fp32 hover handle with motor noise, n a multiple of 256, policy widths 20 / 4.
 hipError_t launch_rollout_step(const float* image, const double* rms, float* obs_n, float* action, float* clipped, float* value,
                                float* logp, uint64_t pol_seed, uint64_t pol_id_offset, float clip_obs, float eps_norm,
@@ -354,9 +722,38 @@ hipError_t launch_rollout_step(const float* image, const double* rms, float* obs
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    RollStepArgs p{image, rms, obs_n, action, clipped, value, logp, pol_seed, pol_id_offset, clip_obs, eps_norm, merge, st};
+    RollStepArgs p{image, rms, obs_n, action, clipped, value, logp, pol_seed, pol_id_offset, clip_obs, eps_norm, merge, st, g_rollout_stamps};
     hipLaunchKernelGGL(rollout_step_kernel, dim3((unsigned)(st.n / 256)), dim3(512), (size_t)full, s, p);
     return hipGetLastError();
+}
+
+int rollout_sync_words() { return kSyncWords; }
+
+hipError_t launch_rollout_persistent(const RollPersistHost& h, const StepArgs<float>& st, hipStream_t s) {
+    static bool attr_set = false;
+    const int full = (int)((2 * kNetFloats + (kImageFloats - kHeadBase) + 40) * sizeof(float)) + kMergeLdsBytes;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)rollout_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, full);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    RollPersistArgs p{};
+    p.image = h.image; p.pol_seed = h.pol_seed; p.pol_id_offset = h.pol_id_offset; p.clip_obs = h.clip_obs; p.eps_norm = h.eps_norm;
+    p.st = st; p.T = h.T;
+    p.obs_n = h.obs_n; p.action = h.action; p.value = h.value; p.logp = h.logp; p.reward = h.reward; p.done = h.done;
+    p.rms0 = h.rms0; p.ret_rms0 = h.ret_rms0;
+    p.rms_out[0] = h.rms_out[0]; p.rms_out[1] = h.rms_out[1];
+    p.ret_rms_out[0] = h.ret_rms_out[0]; p.ret_rms_out[1] = h.ret_rms_out[1];
+    p.snapshots = h.snapshots; p.snap_stride = h.snap_stride;
+    p.rows[0] = h.rows[0]; p.rows[1] = h.rows[1];
+    p.sync = h.sync; p.status = h.status; p.timeout_ticks = h.timeout_ticks;
+    p.stamps = g_rollout_stamps;
+    hipError_t e = hipMemsetAsync(h.sync, 0, sizeof(uint32_t) * kSyncCounterWords, s);
+    if (e != hipSuccess) return e;
+    void* args[] = {&p};
+    // cooperative launch: the runtime checks that the grid fits on the device at once (the barrier needs every workgroup resident)
+    return hipLaunchCooperativeKernel((const void*)rollout_persistent_kernel, dim3((unsigned)(st.n / 256)), dim3(512), args,
+                                      (unsigned)full, s);
 }
 
 }  // namespace fpv

@@ -119,6 +119,35 @@ class FusedPolicy:
                 "fpv_rollout_step")
         return {"obs_n": obs_n, "action": action, "clipped": clipped, "value": value, "logp": logp, "reward": reward}
 
+    def rollout_steps(self, engine, T: int, *, obs_n=None, action=None, value, logp=None, reward, done=None, ret=None,
+                      gamma: float = 0.99, clip_obs: float = 10.0, eps_norm: float = 1e-8, rms=None, ret_rms=None,
+                      rms_out=(None, None), ret_rms_out=(None, None), snapshots=None, partials, status):
+        """fpv_rollout_steps: T rollout steps in ONE persistent launch (fpv_rollstep.hip).  Time-major [T, n, ...] buffers;
+        partials = float64 [2, n / 256, 44]; status = uint32 device word (nonzero afterwards: a grid wait timed out)."""
+        n = engine.num_envs
+        for name, t, shape in (("value", value, (T, n)), ("reward", reward, (T, n)), ("obs_n", obs_n, (T, n, 20)),
+                               ("action", action, (T, n, 4)), ("logp", logp, (T, n)), ("done", done, (T, n))):
+            if t is not None and (not t.is_contiguous() or tuple(t.shape[:len(shape)]) != shape):
+                raise ValueError(f"{name} must be a contiguous tensor of shape {shape}")
+        if partials.dtype != torch.float64 or not partials.is_contiguous() or tuple(partials.shape) != (2, n // 256, 44):
+            raise ValueError("partials must be a contiguous float64 [2, num_envs / 256, 44] device tensor")
+        io = L.FpvRolloutIo()
+        io.T = int(T)
+        io.obs, io.obs_n, io.action, io.value, io.logp = _ptr(engine.obs), _ptr(obs_n), _ptr(action), _ptr(value), _ptr(logp)
+        io.reward, io.done, io.terminated, io.truncated = _ptr(reward), _ptr(done), _ptr(engine.terminated), _ptr(engine.truncated)
+        io.ret, io.gamma, io.clip_obs, io.eps_norm = _ptr(ret), float(gamma), float(clip_obs), float(eps_norm)
+        io.seed, io.id_offset = self.seed, self.id_offset
+        io.rms, io.ret_rms = _ptr(rms), _ptr(ret_rms)
+        for k in range(2):
+            io.rms_out[k], io.ret_rms_out[k] = _ptr(rms_out[k]), _ptr(ret_rms_out[k])
+            io.partials[k] = partials[k].data_ptr()
+        io.snapshots = _ptr(snapshots)
+        io.snapshot_stride = snapshots.stride(0) if snapshots is not None else 0
+        io.status = _ptr(status)
+        L.check(self.lib.fpv_rollout_steps(engine._h, self._h, C.byref(io),
+                                           C.c_void_p(torch.cuda.current_stream(engine.device).cuda_stream)),
+                "fpv_rollout_steps")
+
     def _grads(self):
         gs = []
         for t in self._params():

@@ -14,6 +14,8 @@ Every per-step operation is asynchronous device work on one stream; the T-step l
 captured once into a HIP graph and replayed, so the host issues one launch per rollout.
 
 Two step implementations:
+  * fused, persistent: ONE launch per ROLLOUT — fpv_rollout_steps keeps weights in LDS and drone state in registers across
+    the n_steps, with a grid-wide barrier + statistics merge between steps (fpv_rollstep.hip).  Same bits.
   * fused, one_launch (default where served): ONE kernel per step — fpv_rollout_step = the two kernels below in one
     launch, same bits (fpv_rollstep.hip).
   * fused: TWO kernels per step — fpv_policy_forward (RunningMeanStd.update of both statistics
@@ -54,7 +56,8 @@ class RolloutCollector:
                  lam: float = 0.95, norm_obs: bool = True, norm_reward: bool = True, use_graph: bool = True,
                  clip_obs: float = 10.0, clip_reward: float = 10.0, fused: bool = True, policy_seed: int = 0,
                  policy_gemm: str = "f32", overlap_critic: bool = False, merge_in_policy: bool = True,
-                 fused_step: bool = True, merge_in_step: bool = False, one_launch: bool | None = None):
+                 fused_step: bool = True, merge_in_step: bool = False, one_launch: bool | None = None,
+                 persistent: bool | None = None):
         if engine.dtype != torch.float32:
             raise ValueError("the rollout collector runs on an fp32 engine")
         self.engine, self.policy = engine, policy
@@ -91,6 +94,7 @@ class RolloutCollector:
         self.snap = torch.zeros((T, max(44, 2 * O + 4)), dtype=torch.float64, device=dev)  # {obs_rms, ret_rms} after step t
         self.fused = bool(fused)
         self._one_launch = self._one_launch_ok = False
+        self._persistent = self._persistent_ok = False
         self.fused_policy = fused_policy
         if self.fused_policy:
             self.fp = FusedPolicy(policy, seed=policy_seed, id_offset=engine.id_offset,
@@ -129,7 +133,14 @@ class RolloutCollector:
                 raise ValueError("one_launch needs the hover task with motor noise, num_envs a multiple of 256 (<= 262 144), "
                                  "policy_gemm='f32' and the default statistics-merge placement")
             self._one_launch = self._one_launch_ok = can if one_launch is None else bool(one_launch)
-            if self._one_launch:    # launch t reads the rows of launch t - 1 while it writes its own: two tables
+            # persistent: the WHOLE rollout of n_steps as one launch (fpv_rollout_steps): weights stay in LDS, drone state in
+            # registers, a grid-wide barrier + statistics merge between steps.  Same bits again.  Needs every workgroup resident:
+            # at most one per CU, i.e. num_envs <= 256 x CUs.
+            can_p = can and N // 256 <= torch.cuda.get_device_properties(dev).multi_processor_count
+            if persistent and not can_p:
+                raise ValueError("persistent needs what one_launch needs and num_envs <= 256 x the device's CU count")
+            self._persistent = self._persistent_ok = False if persistent is None else bool(persistent)
+            if self._one_launch or self._persistent:    # step t's rows are read while step t + 1's are written: two tables
                 self._rs_partials = torch.zeros((2, N // 256, 2 * O + 4), dtype=torch.float64, device=dev)
         self.stats = torch.zeros((3,), dtype=torch.float64, device=dev)
         if self.fused_policy:
@@ -142,6 +153,7 @@ class RolloutCollector:
             self._tv = torch.zeros((cap,), dtype=f32, device=dev)
             self._led_status = torch.zeros((8,), dtype=torch.float64, device=dev)   # counters[4] as int32 in [0:2], sums in [2:4]
             self._led_counters = self._led_status[:2].view(torch.int32)
+            self._rs_status = self._led_status[4:5].view(torch.int32)[0:1]      # fpv_rollout_steps' timeout word
             self._led_sums = self._led_status[2:4]
             self._status_host = [torch.zeros((8,), dtype=torch.float64).pin_memory() for _ in range(2)]
             self._status_event = [torch.cuda.Event() for _ in range(2)]
@@ -252,7 +264,7 @@ class RolloutCollector:
         if not (self.fused and self._merge_in_policy):
             return
         o_in, r_in = self._stat_bufs(t_last)
-        ops.moments_merge(self._rs_partials[t_last % 2] if self._one_launch else self.partials, self.N, obs_rms=self.obs_norm.rms if self.norm_obs else None,
+        ops.moments_merge(self._rs_partials[t_last % 2] if (self._one_launch or self._persistent) else self.partials, self.N, obs_rms=self.obs_norm.rms if self.norm_obs else None,
                           ret_rms=self.rew_norm.rms if self.norm_reward else None, snapshot=self.snap[t_last],
                           obs_rms_in=o_in, ret_rms_in=r_in)
 
@@ -279,13 +291,26 @@ class RolloutCollector:
         if self.fused_policy:
             self.engine.ledger_clear()
         self._starts[0].copy_(self._starts[self.T])
-        for t in range(self.T):
-            self._step(t)
+        if self._persistent:
+            self._rollout_persistent()
+        else:
+            for t in range(self.T):
+                self._step(t)
         self._merge_tail(self.T - 1)
         if self.fused and self.overlap_critic:
             torch.cuda.current_stream(self.device).wait_stream(self._vstream)   # join the critic passes
         if self.fused_policy:
             self._tail()
+
+    def _rollout_persistent(self) -> None:
+        """All T steps as one persistent launch (fpv_rollout_steps); leaves what T calls of _step_fused leave."""
+        o0, r0 = self._stat_bufs(0)
+        self.fp.rollout_steps(self.engine, self.T, obs_n=self.buf_obs, action=self.buf_act, value=self.buf_val,
+                              logp=self.buf_logp, reward=self.raw_rew, done=self._starts[1:], ret=self.rew_norm.ret,
+                              gamma=self.gamma, clip_obs=self.obs_norm.clip, eps_norm=self.obs_norm.eps, rms=o0, ret_rms=r0,
+                              rms_out=(self.obs_norm.rms, self._obs_rms_alt) if self.norm_obs else (None, None),
+                              ret_rms_out=(self.rew_norm.rms, self._ret_rms_alt) if self.norm_reward else (None, None),
+                              snapshots=self.snap, partials=self._rs_partials, status=self._rs_status)
 
     def _tail(self) -> None:
         """Everything between the last env step and the collective, without a host round trip (so it is part of the
@@ -320,13 +345,16 @@ class RolloutCollector:
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):       # warm-up outside capture: lazy allocations, rocBLAS handles
-            self._step(0)
-            self._merge_tail(0)
-            if self.fused_policy:
-                self._tail()                # first-call allocations of the tail (reduction scratch) happen here
+            if self._persistent:
+                self._all_steps()           # the persistent launch has no single-step form: one whole rollout
+            else:
+                self._step(0)
+                self._merge_tail(0)
+                if self.fused_policy:
+                    self._tail()            # first-call allocations of the tail (reduction scratch) happen here
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
-        self._tick0 += 1
+        self._tick0 += self.T if self._persistent else 1
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._all_steps()
@@ -337,7 +365,8 @@ class RolloutCollector:
         if not self.fused:
             raise ValueError("policy_gemm applies to the fused path")
         self.fp.set_gemm(gemm)
-        self._one_launch = self._one_launch_ok and gemm == "f32"    # fpv_rollout_step serves the exact-fp32 policy
+        self._one_launch = self._one_launch_ok and gemm == "f32"    # fpv_rollout_step(s) serve the exact-fp32 policy
+        self._persistent = self._persistent_ok and gemm == "f32"
         self.overlap_critic = self._vstream is not None and gemm == "f32"
         self._graph = None
 
@@ -356,6 +385,9 @@ class RolloutCollector:
         if self.fused_policy:
             slot = self._rollouts % 2
             self._check_status(slot)        # what this slot still holds is two rollouts old: no stall
+            if self._persistent and self._rollouts:
+                # the persistent launch wants the whole device: let the previous rollout's collective finish first
+                torch.cuda.current_stream(self.device).wait_event(self._stats_done[self._stats_last])
             if self.use_graph:
                 self._graph.replay()
             else:
@@ -410,6 +442,9 @@ class RolloutCollector:
         self._status_pending[slot] = False
         host = self._status_host[slot]
         k, valid, episodes, flags = (int(x) for x in host[:2].view(torch.int32))
+        if int(host[4:5].view(torch.int32)[0]) != 0:
+            raise RuntimeError("persistent rollout: a grid-wide wait timed out (not every workgroup was resident, or the device "
+                               "was shared); this rollout is invalid — use RolloutCollector(persistent=False)")
         if flags & 1:
             raise RuntimeError(f"done ledger overflow: {episodes} episode ends but only {valid} rows fit "
                                f"({self.engine.ledger_rows_per_tile} per 64-drone tile); create the engine with a larger "

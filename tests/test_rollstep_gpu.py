@@ -142,3 +142,69 @@ def test_unserved_requests_are_refused():
     with pytest.raises(ValueError, match="alternate two tables"):
         fp.rollout_step(eng, rms=rms, partials=part, merge={"partials": part, "count": 1024, "rms_out": rms.clone()})
     eng.close()
+
+
+@pytest.mark.parametrize("n,T", [(65536, 12), (1024, 5), (4096, 1)])
+def test_persistent_rollout_equals_step_by_step(oracle, n, T):
+    """RolloutCollector(persistent=True): the whole rollout as ONE launch (grid barrier + in-launch statistics merge between
+    steps) against one launch per step — identical batches, statistics, ledger-derived episode numbers, engine state."""
+    from fpv_drone_rl_agent_amd import _lib as L
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.rollout import RolloutCollector
+    L.load().fpv_set_pair_threshold(0)           # rows of four tiles in every path: bit-equal statistics at any size
+    try:
+        cols = []
+        for pers in (True, False):
+            eng = FpvEngine(n, 0, seed=2)
+            # eager launches: graph capture runs a warm-up outside the capture (one step, or one whole rollout in the persistent
+            # shape), which would leave the two collectors a different number of steps into their episodes
+            cols.append(RolloutCollector(eng, _policy(4), n_steps=T, policy_seed=9, persistent=pers, one_launch=True, use_graph=False))
+            cols[-1].start()
+            _synthetic(eng, oracle, 6)
+        assert cols[0]._persistent and not cols[1]._persistent
+        for r in range(4):
+            ba, bb = cols[0].collect(), cols[1].collect()
+            for k in ("obs", "actions", "values", "log_probs", "advantages", "returns"):
+                assert torch.equal(ba[k], bb[k]), (r, k)
+            assert torch.equal(cols[0].obs_norm.rms, cols[1].obs_norm.rms) and torch.equal(cols[0].rew_norm.rms, cols[1].rew_norm.rms)
+            assert torch.equal(cols[0].buf_rew, cols[1].buf_rew) and torch.equal(cols[0].buf_start, cols[1].buf_start)
+            assert torch.equal(cols[0].snap, cols[1].snap)
+            assert torch.equal(cols[0].engine.obs, cols[1].engine.obs)
+            assert torch.equal(cols[0].engine.get_state(), cols[1].engine.get_state())
+            ea, eb = cols[0].episodes, cols[1].episodes
+            assert ea["count"] == eb["count"] and ea["truncated"] == eb["truncated"]
+        assert cols[0].engine.get_tick() == cols[1].engine.get_tick()
+    finally:
+        L.load().fpv_set_pair_threshold(32768)
+
+
+def test_persistent_refuses_more_workgroups_than_cus():
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.rollout import RolloutCollector
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    with pytest.raises(ValueError, match="persistent"):
+        RolloutCollector(FpvEngine(256 * (cus + 1), 0), _policy(), n_steps=4, persistent=True)
+
+
+def test_persistent_rollout_replays_from_a_graph(oracle):
+    """The persistent launch (a cooperative launch behind a memset node) captured into the collector's HIP graph: ticks advance
+    by n_steps per replay, the timeout word stays clear, outputs are finite and change from rollout to rollout."""
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.rollout import RolloutCollector
+    n, T = 65536, 8
+    eng = FpvEngine(n, 0, seed=1)
+    col = RolloutCollector(eng, _policy(2), n_steps=T, persistent=True)
+    col.start()
+    _synthetic(eng, oracle, 7)
+    t0 = eng.get_tick()
+    prev = None
+    for r in range(3):
+        b = col.collect()
+        torch.cuda.synchronize()
+        assert torch.isfinite(b["advantages"]).all() and torch.isfinite(b["obs"]).all()
+        if prev is not None:
+            assert not torch.equal(prev, b["values"])
+        prev = b["values"].clone()
+    assert col._graph is not None
+    assert eng.get_tick() == t0 + 4 * T          # the capture's warm-up rollout + three replays
+    assert col.episodes["count"] > 0             # reading the episode numbers checks the status words (timeout flag clear)

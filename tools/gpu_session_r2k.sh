@@ -1,14 +1,9 @@
 #!/bin/bash
-# round 2, session k: first run of the one-launch rollout step (fpv_rollstep.hip): parity tests, then both bench shapes
 set -e
 mkdir -p gpurun_out/r2k
-timeout -k 10 600 python -m pytest tests/test_rollstep_gpu.py -x -q > gpurun_out/r2k/tests.log 2>&1 || { tail -30 gpurun_out/r2k/tests.log; exit 1; }
+timeout -k 10 300 python tools/rollout_phases.py > gpurun_out/r2k/phases_step.txt 2>&1 || { tail -20 gpurun_out/r2k/phases_step.txt; exit 1; }
+cat gpurun_out/r2k/phases_step.txt
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/r2k/tests.log 2>&1 || { tail -40 gpurun_out/r2k/tests.log; exit 1; }
 tail -3 gpurun_out/r2k/tests.log
-timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-split-extra > gpurun_out/r2k/bench_one.json 2> gpurun_out/r2k/bench_one.err
-timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-split-extra --two-launch > gpurun_out/r2k/bench_two.json 2> gpurun_out/r2k/bench_two.err
-python - <<'PY'
-import json
-for k in ("one", "two"):
-    d = json.load(open(f"gpurun_out/r2k/bench_{k}.json"))
-    print(k, d["value"], d["ms_per_step"], d["repeats_ms_per_step"])
-PY
+timeout -k 10 300 python tools/rollout_shapes.py > gpurun_out/r2k/shapes.txt 2>&1 || { tail -20 gpurun_out/r2k/shapes.txt; exit 1; }
+cat gpurun_out/r2k/shapes.txt

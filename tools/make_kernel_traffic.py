@@ -6,7 +6,8 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
 s = json.load(open(f"profiles/{tag}_summary.json"))
 f, w = s["pmc_raw_KB_per_launch"]["FETCH_SIZE"], s["pmc_raw_KB_per_launch"]["WRITE_SIZE"]
-want = {"fpv::policy_forward_kernel": "policy_forward_kernel<512>",
+want = {"fpv::rollout_step_kernel": "rollout_step_kernel",
+        "fpv::policy_forward_kernel": "policy_forward_kernel<512>",
         "fpv::step_kernel<float,true,true>": "step_kernel<float, true, true",
         "fpv::step_kernel<float,true,false>": "step_kernel<float, true, false",
         "fpv::gae_kernel": "fpv::gae_kernel",
