@@ -12,9 +12,9 @@ K is timed exactly (barrier + synchronize on both sides, MAX over ranks); value 
 ranks x K / time.  Inputs are synthetic (random-init policy, seeded random-init drone states,
 BASELINE.md §3) and resident in HBM before the timed region.
 
-The K-step timed region is repeated `--repeats` times (default 5), each bracketed by barrier +
-synchronize and reduced with MAX over ranks; the line reports the MEDIAN repeat (all repeats are
-listed under `repeats_ms_per_step`).
+The K-step timed region is repeated `--repeats` times (default 5, more when K is small so that about
+1 024 steps are timed in all), each bracketed by barrier + synchronize and reduced with MAX over
+ranks; the line reports the MEDIAN repeat (all repeats are listed under `repeats_ms_per_step`).
 
 Adds to the JSON line: `roofline` for the kernel that dominates the timed region by time (the rollout-step
 kernel: actor-critic forward on fp32 MFMA + the env step of the same drones; its `phases` come from
@@ -147,7 +147,10 @@ def main() -> None:
     ap.add_argument("--plumbing-only", action="store_true",
                     help="no GPU work: rendezvous, argument / rank checks, the barrier + MAX-over-ranks timing and the one "
                          "all-gather on the gloo backend, then the JSON line with value = null (tests/test_dist_gloo.py)")
-    ap.add_argument("--repeats", type=int, default=5, help="the K-step timed region is run this many times; the median is reported")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="the K-step timed region is run this many times and the median is reported; default: 5, or as many as "
+                         "it takes to time about 1 024 steps in all when K is small (a 20-step region is 1.4 ms: the first few "
+                         "run on a chip that is still raising its clock)")
     ap.add_argument("--detector", choices=["analytic", "pixel"], default="analytic",
                     help="hover task camera features: continuous projection (SPEC §6) or the reference's 128x128 pixel rules (§6b)")
     ap.add_argument("--two-launch", action="store_true",
@@ -220,7 +223,8 @@ def main() -> None:
 
     for _ in range(max(1, math.ceil(W / T))):
         col.collect()
-    repeats = sorted(timed_region() for _ in range(max(1, args.repeats)))
+    n_rep = args.repeats if args.repeats > 0 else min(65, max(5, math.ceil(1024 / K)))
+    repeats = sorted(timed_region() for _ in range(n_rep))
     elapsed = repeats[len(repeats) // 2] if len(repeats) % 2 else 0.5 * (repeats[len(repeats) // 2 - 1] + repeats[len(repeats) // 2])
     episodes = int(col.episodes["count"])
 
@@ -230,7 +234,7 @@ def main() -> None:
         col.set_policy_gemm("bf16x6")
         for _ in range(2):
             col.collect()
-        r2 = sorted(timed_region() for _ in range(max(1, min(3, args.repeats))))
+        r2 = sorted(timed_region() for _ in range(max(1, min(3, n_rep))))
         el2 = r2[len(r2) // 2]
         split_value = n * world * K / el2
         col.set_policy_gemm("f32")
@@ -348,13 +352,19 @@ def main() -> None:
                     in_graph, us_one = {}, ev_one                        # tracer output implausible: trust the events
                 how = "device timestamps of the launches inside the replayed rollout graph" if in_graph else \
                       "HIP events around back-to-back launches"
+                # One launch per step on one stream: a launch cannot last longer than the step cadence of the timed region
+                # (the activity tracer's own per-kernel overhead stretches the traced replay; rocprofv3 reads 62 us).
+                us_traced, cadence = us_one, elapsed / K * 1e6
+                if us_one > cadence:
+                    us_one, how = cadence, how + ", capped at the timed region's own time per step"
                 phases = kernel_phases()
                 tf = POLICY_FLOP_PER_ROW * n / us_one / 1e6
                 roofline = {"bound": "mfma", "kernel": "fpv::rollout_step_kernel", "achieved": round(tf, 1),
                             "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
                             "traffic": traffic_of("fpv::rollout_step_kernel"), "us_per_launch": round(us_one, 2),
                             "launches": L, "algorithmic_flop_per_launch": POLICY_FLOP_PER_ROW * n, "dtype": "f32",
-                            "measured": how, "us_per_launch_hip_events_back_to_back": round(ev_one, 2)}
+                            "measured": how, "us_per_launch_hip_events_back_to_back": round(ev_one, 2),
+                            "us_per_launch_traced": round(us_traced, 2), "us_per_step_timed_region": round(cadence, 2)}
                 roofline["note"] = ("one kernel per rollout step: actor-critic forward (the matrix work priced here) AND the env step of "
                                     "the same drones (vector work, `phases`); peak = dense fp32-input MFMA rate (155 TF measured with "
                                     "resident operands at a 2.38 GHz in-kernel clock, profiles/r02_mfma_peak.txt); vector instructions do "

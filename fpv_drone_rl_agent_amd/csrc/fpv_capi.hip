@@ -395,6 +395,14 @@ int fpv_ledger_clear(fpv_env* e, void* stream) {
     return FPV_OK;
 }
 
+int fpv_rollout_begin(fpv_env* e, uint8_t* starts_dst, const uint8_t* starts_src, void* stream) {
+    if (!e) return fail(FPV_ERR_ARG, "fpv_rollout_begin: null handle");
+    if ((starts_dst == nullptr) != (starts_src == nullptr)) return fail(FPV_ERR_ARG, "fpv_rollout_begin: give both rows or neither");
+    if (((uintptr_t)starts_dst | (uintptr_t)starts_src) & 15) return fail(FPV_ERR_ARG, "fpv_rollout_begin: rows must be 16-byte aligned");
+    FPV_HIP(launch_rollout_begin(e->led_count, e->tiles, starts_dst, starts_src, e->cfg.num_envs, (hipStream_t)stream));
+    return FPV_OK;
+}
+
 int fpv_advantage_stats(const double* gathered, int32_t world, int32_t stride, double* mean_std, void* stream) {
     if (!gathered || !mean_std || world <= 0 || stride < 3) return fail(FPV_ERR_ARG, "fpv_advantage_stats: bad arguments");
     FPV_HIP(launch_advantage_stats(gathered, world, stride, mean_std, (hipStream_t)stream));
@@ -533,8 +541,8 @@ int fpv_policy_forward(fpv_policy* p, const fpv_policy_io* io, void* stream) {
     if (io->merge_partials) {
         if (io->merge_rows <= 0 || io->merge_rows > 1024)
             return fail(FPV_ERR_UNSUPPORTED, "fpv_policy_forward: in-launch merge takes 1..1024 partial rows (use fpv_moments_merge beyond)");
-        if (p->in_dim > 20 || nets != 3 || io->narrow)
-            return fail(FPV_ERR_UNSUPPORTED, "fpv_policy_forward: in-launch merge needs in_dim <= 20, both nets and 512-thread workgroups");
+        if (p->in_dim > 20 || io->narrow)
+            return fail(FPV_ERR_UNSUPPORTED, "fpv_policy_forward: in-launch merge needs in_dim <= 20 and 512-thread workgroups");
         if (!(io->merge_count > 0.0)) return fail(FPV_ERR_ARG, "fpv_policy_forward: merge_count must be positive");
         if ((io->rms && (!io->rms_out || io->rms_out == io->rms)) || (io->ret_rms && (!io->ret_rms_out || io->ret_rms_out == io->ret_rms)))
             return fail(FPV_ERR_ARG, "fpv_policy_forward: merged statistics go to a second buffer (other workgroups still read the first)");

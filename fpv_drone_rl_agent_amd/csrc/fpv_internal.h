@@ -193,6 +193,7 @@ __device__ __forceinline__ float half_sum(float v) {
 
 hipError_t launch_advantage_stats(const double* gathered, int world, int stride, double* out, hipStream_t s);
 hipError_t launch_zero_words(uint32_t* a, int64_t n, hipStream_t s);
+hipError_t launch_rollout_begin(uint32_t* counts, int64_t tiles, uint8_t* dst, const uint8_t* src, int64_t n, hipStream_t s);
 hipError_t launch_ledger_scan(const uint32_t* led_count, const int32_t* led_idx, const uint32_t* led_info, const uint32_t* led_tag,
                               const float* led_ret, const float* led_obs, const uint64_t* tick, int64_t tiles, int rows,
                               int obs_words, const double* snapshots, int64_t stride, int T, float clip_obs, float eps,

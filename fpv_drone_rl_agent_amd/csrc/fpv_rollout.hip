@@ -367,6 +367,28 @@ __global__ void zero_words_kernel(uint32_t* __restrict__ a, int64_t na, uint32_t
     }
 }
 
+// Start of a rollout in one launch: clear the done ledger's per-tile counts and carry the episode-start flags over
+// (dst[i] = src[i], n bytes; a memcpy node in a captured graph costs tens of microseconds of dispatch latency, a kernel node ~1.5).
+__global__ void rollout_begin_kernel(uint32_t* __restrict__ counts, int64_t tiles, uint8_t* __restrict__ dst,
+                                     const uint8_t* __restrict__ src, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = i; k < tiles; k += stride) counts[k] = 0u;
+    if (dst) {
+        const int64_t words = n / 16;                  // both rows are 16-byte aligned (checked by the caller)
+        for (int64_t k = i; k < words; k += stride) reinterpret_cast<uint4*>(dst)[k] = reinterpret_cast<const uint4*>(src)[k];
+        for (int64_t k = words * 16 + i; k < n; k += stride) dst[k] = src[k];
+    }
+}
+
+hipError_t launch_rollout_begin(uint32_t* counts, int64_t tiles, uint8_t* dst, const uint8_t* src, int64_t n, hipStream_t s) {
+    int64_t work = tiles > n / 16 ? tiles : n / 16;
+    int64_t blocks = (work + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(rollout_begin_kernel, dim3((unsigned)blocks), dim3(256), 0, s, counts, tiles, dst, src, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_zero_words(uint32_t* a, int64_t n, hipStream_t s) {
     int64_t blocks = (n + 255) / 256;
     if (blocks > 1024) blocks = 1024;

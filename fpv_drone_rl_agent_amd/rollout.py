@@ -142,7 +142,10 @@ class RolloutCollector:
             self._persistent = self._persistent_ok = False if persistent is None else bool(persistent)
             if self._one_launch or self._persistent:    # step t's rows are read while step t + 1's are written: two tables
                 self._rs_partials = torch.zeros((2, N // 256, 2 * O + 4), dtype=torch.float64, device=dev)
-        self.stats = torch.zeros((3,), dtype=torch.float64, device=dev)
+        # what the host / the collective read after a rollout lives in ONE small tensor, so that one copy takes it out of the
+        # next rollout's way: [0:8] ledger status words (fused policy), [8:11] {count, sum A, sum A^2} of the advantages
+        self._post = torch.zeros((16,), dtype=torch.float64, device=dev)
+        self.stats = self._post[8:11]
         if self.fused_policy:
             # sync-free timeout bootstrap (fpv_ledger_scan / fpv_ledger_scatter): a drone is truncated at most once per
             # 401 steps, so the dense list never needs more than N * ceil(T / 401) rows
@@ -151,7 +154,7 @@ class RolloutCollector:
             self._t_idx = torch.zeros((cap,), dtype=torch.int32, device=dev)
             self._d_idx = torch.zeros((cap,), dtype=torch.int32, device=dev)
             self._tv = torch.zeros((cap,), dtype=f32, device=dev)
-            self._led_status = torch.zeros((8,), dtype=torch.float64, device=dev)   # counters[4] as int32 in [0:2], sums in [2:4]
+            self._led_status = self._post[0:8]                                      # counters[4] as int32 in [0:2], sums in [2:4]
             self._led_counters = self._led_status[:2].view(torch.int32)
             self._rs_status = self._led_status[4:5].view(torch.int32)[0:1]      # fpv_rollout_steps' timeout word
             self._led_sums = self._led_status[2:4]
@@ -162,10 +165,12 @@ class RolloutCollector:
         # until a consumer asks (the batch's "adv_mean" / "adv_std" items), so consecutive rollouts stay back to back
         # and ranks are not forced into lock-step every n_steps
         self._side = torch.cuda.Stream(dev)
-        self._stats_slot = [torch.zeros((3,), dtype=torch.float64, device=dev) for _ in range(2)]
+        self._post_slot = [torch.zeros((16,), dtype=torch.float64, device=dev) for _ in range(2)]
+        self._stats_slot = [t[8:11] for t in self._post_slot]
         self._adv_ms = [torch.zeros((2,), dtype=torch.float64, device=dev) for _ in range(2)]
         self._stats_ready = [torch.cuda.Event() for _ in range(2)]
         self._stats_done = [torch.cuda.Event() for _ in range(2)]
+        self._copied = torch.cuda.Event()
         self._stats_last = 0
         self._rollouts = 0
         self._episodes_host = {"count": 0, "ep_len_mean": float("nan"), "ep_rew_mean": float("nan"), "truncated": 0}
@@ -296,11 +301,15 @@ class RolloutCollector:
         else:
             for t in range(self.T):
                 self._step(t)
-        self._merge_tail(self.T - 1)
+        # the last step's statistics update: inside the V(s_T) launch of the tail when the ping-pong parity lets its output land
+        # in the canonical tensors (even n_steps), else as its own merge kernel
+        fold = self.fused and self._merge_in_policy and self.fused_policy and self.T % 2 == 0 and not self.overlap_critic
+        if not fold:
+            self._merge_tail(self.T - 1)
         if self.fused and self.overlap_critic:
             torch.cuda.current_stream(self.device).wait_stream(self._vstream)   # join the critic passes
         if self.fused_policy:
-            self._tail()
+            self._tail(merge_step=self.T - 1 if fold else None)
 
     def _rollout_persistent(self) -> None:
         """All T steps as one persistent launch (fpv_rollout_steps); leaves what T calls of _step_fused leave."""
@@ -312,12 +321,21 @@ class RolloutCollector:
                               ret_rms_out=(self.rew_norm.rms, self._ret_rms_alt) if self.norm_reward else (None, None),
                               snapshots=self.snap, partials=self._rs_partials, status=self._rs_status)
 
-    def _tail(self) -> None:
+    def _tail(self, merge_step: int | None = None) -> None:
         """Everything between the last env step and the collective, without a host round trip (so it is part of the
-        captured graph): V(s_T), deferred reward scaling, timeout bootstrap from the done ledger, GAE + its moments."""
+        captured graph): V(s_T), deferred reward scaling, timeout bootstrap from the done ledger, GAE + its moments.
+        merge_step: fold that step's moment sums into the statistics in the V(s_T) launch's prologue (what _merge_tail does)."""
         eng = self.engine
-        self.fp.forward(eng.obs, rms=self.obs_norm.rms if self.norm_obs else None, obs_n=self.cur_obs, value=self.last_val,
-                        deterministic=True, nets="v", clip_obs=self.obs_norm.clip, eps_norm=self.obs_norm.eps)
+        if merge_step is None:
+            self.fp.forward(eng.obs, rms=self.obs_norm.rms if self.norm_obs else None, obs_n=self.cur_obs, value=self.last_val,
+                            deterministic=True, nets="v", clip_obs=self.obs_norm.clip, eps_norm=self.obs_norm.eps)
+        else:
+            o_in, r_in = self._stat_bufs(merge_step)             # odd number of merges so far: the alternates
+            rows = self._rs_partials[merge_step % 2] if (self._one_launch or self._persistent) else self.partials
+            merge = {"partials": rows, "count": self.N, "rms_out": self.obs_norm.rms if self.norm_obs else None, "ret_rms": r_in,
+                     "ret_rms_out": self.rew_norm.rms if self.norm_reward else None, "snapshot": self.snap[merge_step]}
+            self.fp.forward(eng.obs, rms=o_in, obs_n=self.cur_obs, value=self.last_val, deterministic=True, nets="v",
+                            clip_obs=self.obs_norm.clip, eps_norm=self.obs_norm.eps, merge=merge)
         if self.fused:
             if self.norm_reward:
                 ops.reward_finalize(self.raw_rew, self.snap, clip=self.rew_norm.clip, eps=self.rew_norm.eps, out=self.buf_rew)
@@ -382,6 +400,8 @@ class RolloutCollector:
         eng = self.engine
         if self.use_graph and self._graph is None:
             self._capture()
+        if self._rollouts:
+            torch.cuda.current_stream(self.device).wait_event(self._copied)    # the last rollout's words are out (long since)
         if self.fused_policy:
             slot = self._rollouts % 2
             self._check_status(slot)        # what this slot still holds is two rollouts old: no stall
@@ -392,9 +412,6 @@ class RolloutCollector:
                 self._graph.replay()
             else:
                 self._all_steps()
-            self._status_host[slot].copy_(self._led_status, non_blocking=True)
-            self._status_event[slot].record()
-            self._status_pending[slot] = True
         else:
             eng.ledger_clear()
             self._all_steps()
@@ -406,12 +423,19 @@ class RolloutCollector:
         k = self._rollouts % 2
         self._rollouts += 1
         main = torch.cuda.current_stream(self.device)
-        main.wait_event(self._stats_done[k])                # this slot's previous user is two rollouts old: no stall
-        self._stats_slot[k].copy_(self.stats)
-        self._stats_ready[k].record(main)
+        self._stats_ready[k].record(main)                   # the rollout is complete on the main stream here
+        # everything behind the rollout runs on the side stream, so the main stream carries the rollout and nothing else: ONE
+        # small copy takes the status words and the advantage moments out of the next rollout's way (which waits for
+        # _copied, never for the collective), then the host copy, the collective and the advantage statistics
         with torch.cuda.stream(self._side):
             self._side.wait_event(self._stats_ready[k])
-            gathered = D.allgather_payload(self._stats_slot[k])     # the one collective per update
+            self._post_slot[k].copy_(self._post)            # (this slot's previous user ran two rollouts ago on this stream)
+            self._copied.record(self._side)
+            if self.fused_policy:
+                self._status_host[k].copy_(self._post_slot[k][0:8], non_blocking=True)
+                self._status_event[k].record(self._side)
+                self._status_pending[k] = True
+            gathered = D.allgather_payload(self._stats_slot[k])     # the one collective per update (a view at one rank)
             ops.advantage_stats(gathered, self._adv_ms[k])
             self._stats_done[k].record(self._side)
         self._stats_last = k

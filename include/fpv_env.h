@@ -196,6 +196,10 @@ int fpv_get_tick(fpv_env* env, uint64_t* tick_host, void* stream);
 
 int fpv_ledger_view(fpv_env* env, fpv_ledger* out);
 int fpv_ledger_clear(fpv_env* env, void* stream);
+/* Start of a rollout in one launch: fpv_ledger_clear, and the episode-start flags carried over from the end of the previous
+ * rollout (starts_dst[i] = starts_src[i] for the handle's num_envs drones; both NULL to skip; 16-byte aligned).  A kernel, so
+ * that a captured rollout holds no memcpy node. */
+int fpv_rollout_begin(fpv_env* env, uint8_t* starts_dst, const uint8_t* starts_src, void* stream);
 /* Replace the handle-owned ledger by caller-owned device buffers (same layout as fpv_ledger;
  * ep_return / obs in the handle's precision; count has ceil(num_envs / 64) entries and capacity
  * must equal that tile count times rows_per_tile).  The caller keeps them alive until
@@ -287,7 +291,7 @@ typedef struct {
      * wrote (extras.partials, merge_rows <= 1024 rows) into the statistics before normalising — what fpv_moments_merge
      * does, without its launch on the rollout's critical path.  `rms` (and `ret_rms`) are read; the merged statistics
      * are written to rms_out / ret_rms_out, which must be different buffers; merge_snapshot as in fpv_moments_merge.
-     * Rows are 2 in_dim + 4 words wide (fpv_policy_set_dims).  Needs nets = 0 / 3 and narrow = 0. */
+     * Rows are 2 in_dim + 4 words wide (fpv_policy_set_dims).  Needs narrow = 0. */
     const double* merge_partials;
     int64_t merge_rows;
     double merge_count;      /* drones behind the sums (batch count of the RunningMeanStd update) */

@@ -85,12 +85,15 @@ def test_fullsize_shard_independence_and_oracle_sample(oracle):
     eng.close(); one.close()
 
 
-def test_benchmarked_kernel_matches_oracle_sample_including_auto_reset(oracle):
-    """The kernel bench.py times — fpv_step_fused at 65 536 drones with motor noise: step_kernel<float, true, true, 4>, four
-    tiles per workgroup, VecNormalize bookkeeping in the same pass — against the scalar oracle on a seeded sample of 256
-    drones from the same states, auto-reset rows INCLUDED (returned observation = reset observation, state = reset
-    state with prev_action kept, terminal observation and episode statistics in the ledger).  The finite-difference
-    rates obs[0:3] are compared as angle differences (x agent_dt, hover.py:230) at the 1e-5 bar."""
+@pytest.mark.parametrize("launch", ["rollout_step", "step_fused"])
+def test_benchmarked_kernel_matches_oracle_sample_including_auto_reset(oracle, launch):
+    """The kernels bench.py times at 65 536 drones with motor noise — "rollout_step": fpv_rollout_step, the default rollout's ONE
+    kernel per step (policy forward, then the env step of the same drones; the actions the env step consumed are read back
+    through io->clipped); "step_fused": step_kernel<float, true, true, 4>, the env-step kernel of the two-kernel shape —
+    against the scalar oracle on a seeded sample of 256 drones from the same states, auto-reset rows INCLUDED (returned
+    observation = reset observation, state = reset state with prev_action kept, terminal observation and episode statistics
+    in the ledger).  The finite-difference rates obs[0:3] are compared as angle differences (x agent_dt, hover.py:230) at the
+    1e-5 bar.  For "rollout_step" the policy half is checked too: V and log pi(a) against the torch module on the same rows."""
     from fpv_drone_rl_agent_amd.engine import FpvEngine
     from fpv_drone_rl_agent_amd.synthetic import synthetic_states
     n, seed, gamma = 65536, 13, 0.99
@@ -112,7 +115,29 @@ def test_benchmarked_kernel_matches_oracle_sample_including_auto_reset(oracle):
     ret = ret_in.clone()
     partials = torch.zeros((eng.partial_rows, 44), dtype=torch.float64, device="cuda")
     raw = torch.zeros(n, device="cuda")
-    eng.step_fused(act, done=done, ret=ret, partials=partials, gamma=gamma, reward=raw)
+    if launch == "step_fused":
+        eng.step_fused(act, done=done, ret=ret, partials=partials, gamma=gamma, reward=raw)
+    else:
+        from fpv_drone_rl_agent_amd.ops_policy import FusedPolicy
+        from fpv_drone_rl_agent_amd.policy import ActorCritic
+        torch.manual_seed(6)
+        pol = ActorCritic().cuda()
+        with torch.no_grad():
+            pol.log_std.fill_(-0.3)
+        fp = FusedPolicy(pol, seed=21)
+        obs0 = torch.randn((n, 20), device="cuda", generator=torch.Generator(device="cuda").manual_seed(7))
+        eng.obs.copy_(obs0)
+        sampled, val, logp = torch.zeros(n, 4, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        fp.rollout_step(eng, rms=None, action=sampled, clipped=act, value=val, logp=logp, done=done, ret=ret, partials=partials,
+                        gamma=gamma, reward=raw)                 # `act` now holds the clipped actions the env step consumed
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            mu_all, v_all = pol.mean_value(obs0)
+            lp_ref = pol.log_prob(mu_all, sampled)
+            z = (sampled - mu_all) * torch.exp(-pol.log_std)     # the draws: standard normal over 262 144 values
+        assert torch.allclose(val, v_all, atol=2e-5, rtol=1e-5) and torch.allclose(logp, lp_ref, atol=3e-4, rtol=1e-5)
+        assert torch.equal(act, sampled.clamp(-1.0, 1.0)) and (sampled.abs() > 1).any()
+        assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1.0) < 0.01
     torch.cuda.synchronize()
     got_st, got_obs = eng.get_state().cpu().numpy(), eng.obs.cpu().numpy()
     got_rew, got_done, got_ret = raw.cpu().numpy(), done.cpu().numpy(), ret.cpu().numpy()
