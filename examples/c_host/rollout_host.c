@@ -46,6 +46,9 @@ static float* upload_uniform(size_t n, float scale, unsigned* seed) {
 int main(int argc, char** argv) {
     const int64_t n = argc > 1 ? atoll(argv[1]) : 65536;
     const int T = argc > 2 ? atoi(argv[2]) : 32, rollouts = argc > 3 ? atoi(argv[3]) : 16;
+    /* 4th argument 2: policy forward and env step as two kernels per step; default 1: fpv_rollout_step, both in one kernel
+     * (served when n is a multiple of 256) */
+    const int one_kernel = (argc > 4 ? atoi(argv[4]) : 1) == 1 && n % 256 == 0;
     const float gamma = 0.99f, lam = 0.95f;
     hipStream_t s;
     HK(hipSetDevice(0));
@@ -80,7 +83,9 @@ int main(int argc, char** argv) {
     uint8_t *term = dmalloc(n), *trunc = dmalloc(n), *starts = dmalloc((size_t)(T + 1) * n);
     int64_t rows = 0;
     CK(fpv_partial_rows(env, &rows));
-    double *partials = dmalloc((size_t)rows * 44 * 8), *snap = dmalloc((size_t)T * 44 * 8), *adv_stats = dmalloc(3 * 8), *mean_std = dmalloc(2 * 8);
+    if (one_kernel) rows = n / 256;                     /* fpv_rollout_step: one row of moment sums per 256-drone workgroup */
+    double* part2[2] = {dmalloc((size_t)rows * 44 * 8), dmalloc((size_t)rows * 44 * 8)};   /* step t writes part2[t & 1] */
+    double *partials = part2[0], *snap = dmalloc((size_t)T * 44 * 8), *adv_stats = dmalloc(3 * 8), *mean_std = dmalloc(2 * 8);
     double* stats[2] = {dmalloc(41 * 8), dmalloc(41 * 8)};
     double* rstats[2] = {dmalloc(3 * 8), dmalloc(3 * 8)};
     {   /* RunningMeanStd initial state: mean 0, var 1, count 1e-4 */
@@ -104,8 +109,7 @@ int main(int argc, char** argv) {
     struct timespec t0, t1;
     for (int r = -2; r < rollouts; ++r) {           /* two warm-up rollouts */
         if (r == 0) { HK(hipStreamSynchronize(s)); clock_gettime(CLOCK_MONOTONIC, &t0); }
-        CK(fpv_ledger_clear(env, s));
-        HK(hipMemcpyAsync(starts, starts + (size_t)T * n, n, hipMemcpyDeviceToDevice, s));
+        CK(fpv_rollout_begin(env, starts, starts + (size_t)T * n, s));     /* ledger clear + episode-start carry, one kernel */
         for (int t = 0; t < T; ++t) {
             fpv_policy_io io;
             memset(&io, 0, sizeof io);
@@ -113,19 +117,26 @@ int main(int argc, char** argv) {
             io.obs_n = buf_obs + (size_t)t * n * 20; io.action = buf_act + (size_t)t * n * 4; io.clipped = clipped;
             io.value = buf_val + (size_t)t * n; io.logp = buf_logp + (size_t)t * n;
             io.seed = 3; io.clip_obs = 10.f; io.eps_norm = 1e-8f;
+            double* rows_in = one_kernel ? part2[(t - 1) & 1] : partials;      /* the table step t - 1 wrote */
+            double* rows_out = one_kernel ? part2[t & 1] : partials;
             if (t > 0) {
-                io.merge_partials = partials; io.merge_rows = rows; io.merge_count = (double)n;
+                io.merge_partials = rows_in; io.merge_rows = rows; io.merge_count = (double)n;
                 io.rms_out = stats[t & 1]; io.ret_rms = rstats[(t - 1) & 1]; io.ret_rms_out = rstats[t & 1];
                 io.merge_snapshot = snap + (size_t)(t - 1) * 44;
             }
-            CK(fpv_policy_forward(pol, &io, s));
             fpv_step_extras ex;
             memset(&ex, 0, sizeof ex);
-            ex.done = starts + (size_t)(t + 1) * n; ex.ret = ret_acc; ex.partials = partials; ex.gamma = gamma;
-            CK(fpv_step_fused(env, clipped, raw_obs, raw_rew + (size_t)t * n, term, trunc, &ex, s));
+            ex.done = starts + (size_t)(t + 1) * n; ex.ret = ret_acc; ex.partials = rows_out; ex.gamma = gamma;
+            if (one_kernel) {
+                io.tick = NULL; io.clipped = NULL;                               /* the action stays on the chip */
+                CK(fpv_rollout_step(env, pol, &io, raw_rew + (size_t)t * n, term, trunc, &ex, s));
+            } else {
+                CK(fpv_policy_forward(pol, &io, s));
+                CK(fpv_step_fused(env, clipped, raw_obs, raw_rew + (size_t)t * n, term, trunc, &ex, s));
+            }
         }
-        CK(fpv_moments_merge_to(rows, 20, partials, (double)n, stats[(T - 1) & 1], rstats[(T - 1) & 1], stats[0], rstats[0],
-                                snap + (size_t)(T - 1) * 44, s));
+        CK(fpv_moments_merge_to(rows, 20, one_kernel ? part2[(T - 1) & 1] : partials, (double)n, stats[(T - 1) & 1],
+                                rstats[(T - 1) & 1], stats[0], rstats[0], snap + (size_t)(T - 1) * 44, s));
         fpv_policy_io vio;
         memset(&vio, 0, sizeof vio);
         vio.n = n; vio.obs = raw_obs; vio.rms = stats[0]; vio.obs_n = cur_obs; vio.value = last_val;
@@ -152,10 +163,10 @@ int main(int argc, char** argv) {
     HK(hipMemcpy(hm, mean_std, sizeof hm, hipMemcpyDeviceToHost));
     HK(hipMemcpy(hstats, stats[0], sizeof hstats, hipMemcpyDeviceToHost));
     const int ok = hc[3] == 0 && isfinite(hm[0]) && hm[1] > 0.0 && hstats[40] > (double)n * T * rollouts;
-    printf("{\"drones\": %lld, \"T\": %d, \"rollouts\": %d, \"env_steps_per_s\": %.4g, \"us_per_step\": %.2f, "
+    printf("{\"drones\": %lld, \"T\": %d, \"rollouts\": %d, \"kernels_per_step\": %d, \"env_steps_per_s\": %.4g, \"us_per_step\": %.2f, "
            "\"episodes_last_rollout\": %d, \"truncated_last_rollout\": %d, \"ledger_flags\": %d, \"ep_len_mean\": %.1f, "
            "\"adv_mean\": %.4g, \"adv_std\": %.4g, \"obs_count\": %.0f, \"ok\": %s}\n",
-           (long long)n, T, rollouts, (double)n * T * rollouts / sec, sec * 1e6 / ((double)T * rollouts), hc[2], hc[0], hc[3],
+           (long long)n, T, rollouts, one_kernel ? 1 : 2, (double)n * T * rollouts / sec, sec * 1e6 / ((double)T * rollouts), hc[2], hc[0], hc[3],
            hc[1] ? hs[1] / hc[1] : 0.0, hm[0], hm[1], hstats[40], ok ? "true" : "false");
     CK(fpv_policy_destroy(pol));
     CK(fpv_destroy(env));

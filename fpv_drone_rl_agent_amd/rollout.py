@@ -142,10 +142,12 @@ class RolloutCollector:
             self._persistent = self._persistent_ok = False if persistent is None else bool(persistent)
             if self._one_launch or self._persistent:    # step t's rows are read while step t + 1's are written: two tables
                 self._rs_partials = torch.zeros((2, N // 256, 2 * O + 4), dtype=torch.float64, device=dev)
-        # what the host / the collective read after a rollout lives in ONE small tensor, so that one copy takes it out of the
-        # next rollout's way: [0:8] ledger status words (fused policy), [8:11] {count, sum A, sum A^2} of the advantages
-        self._post = torch.zeros((16,), dtype=torch.float64, device=dev)
-        self.stats = self._post[8:11]
+        # What the host / the collective read after a rollout — [0:8] ledger status words (fused policy), [8:11] {count, sum A,
+        # sum A^2} of the advantages — exists twice, and so does the captured graph: rollouts alternate between the two, so the
+        # side stream reads rollout r's words while rollout r + 1 already runs, with no copy and no wait between them
+        # (a slot is written again two rollouts later).  self._slot selects the pair in use (see the properties below).
+        self._post = [torch.zeros((16,), dtype=torch.float64, device=dev) for _ in range(2)]
+        self._slot = 0
         if self.fused_policy:
             # sync-free timeout bootstrap (fpv_ledger_scan / fpv_ledger_scatter): a drone is truncated at most once per
             # 401 steps, so the dense list never needs more than N * ceil(T / 401) rows
@@ -154,10 +156,10 @@ class RolloutCollector:
             self._t_idx = torch.zeros((cap,), dtype=torch.int32, device=dev)
             self._d_idx = torch.zeros((cap,), dtype=torch.int32, device=dev)
             self._tv = torch.zeros((cap,), dtype=f32, device=dev)
-            self._led_status = self._post[0:8]                                      # counters[4] as int32 in [0:2], sums in [2:4]
-            self._led_counters = self._led_status[:2].view(torch.int32)
-            self._rs_status = self._led_status[4:5].view(torch.int32)[0:1]      # fpv_rollout_steps' timeout word
-            self._led_sums = self._led_status[2:4]
+            # per slot: counters[4] as int32 in words [0:2], sums in [2:4], fpv_rollout_steps' timeout word in [4]
+            self._led_counters_k = [t[0:2].view(torch.int32) for t in self._post]
+            self._rs_status_k = [t[4:5].view(torch.int32)[0:1] for t in self._post]
+            self._led_sums_k = [t[2:4] for t in self._post]
             self._status_host = [torch.zeros((8,), dtype=torch.float64).pin_memory() for _ in range(2)]
             self._status_event = [torch.cuda.Event() for _ in range(2)]
             self._status_pending = [False, False]
@@ -165,18 +167,44 @@ class RolloutCollector:
         # until a consumer asks (the batch's "adv_mean" / "adv_std" items), so consecutive rollouts stay back to back
         # and ranks are not forced into lock-step every n_steps
         self._side = torch.cuda.Stream(dev)
-        self._post_slot = [torch.zeros((16,), dtype=torch.float64, device=dev) for _ in range(2)]
-        self._stats_slot = [t[8:11] for t in self._post_slot]
+        self._stats_k = [t[8:11] for t in self._post]
         self._adv_ms = [torch.zeros((2,), dtype=torch.float64, device=dev) for _ in range(2)]
         self._stats_ready = [torch.cuda.Event() for _ in range(2)]
         self._stats_done = [torch.cuda.Event() for _ in range(2)]
-        self._copied = torch.cuda.Event()
         self._stats_last = 0
         self._rollouts = 0
         self._episodes_host = {"count": 0, "ep_len_mean": float("nan"), "ep_rew_mean": float("nan"), "truncated": 0}
-        self._graph = None
+        self._graphs = [None, None]
         self._tick0 = 0
         self._started = False
+
+    # ------------------------------------------------------------------ the slot in use (alternates per rollout)
+    @property
+    def stats(self):
+        return self._stats_k[self._slot]
+
+    @property
+    def _led_counters(self):
+        return self._led_counters_k[self._slot]
+
+    @property
+    def _led_sums(self):
+        return self._led_sums_k[self._slot]
+
+    @property
+    def _rs_status(self):
+        return self._rs_status_k[self._slot]
+
+    @property
+    def _graph(self):
+        return self._graphs[self._slot]
+
+    @_graph.setter
+    def _graph(self, g):
+        if g is None:
+            self._graphs = [None, None]      # dropping the capture drops both slots' graphs
+        else:
+            self._graphs[self._slot] = g
 
     # ------------------------------------------------------------------ one vectorised step
     def _normalise_obs(self, raw, out, update=True):
@@ -398,16 +426,16 @@ class RolloutCollector:
         if not self._started:
             self.start()
         eng = self.engine
+        k = self._slot = self._rollouts % 2
         if self.use_graph and self._graph is None:
             self._capture()
-        if self._rollouts:
-            torch.cuda.current_stream(self.device).wait_event(self._copied)    # the last rollout's words are out (long since)
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(self._stats_done[k])                # this slot's words were last read two rollouts ago: no stall
         if self.fused_policy:
-            slot = self._rollouts % 2
-            self._check_status(slot)        # what this slot still holds is two rollouts old: no stall
+            self._check_status(k)           # what this slot still holds is two rollouts old: no stall
             if self._persistent and self._rollouts:
                 # the persistent launch wants the whole device: let the previous rollout's collective finish first
-                torch.cuda.current_stream(self.device).wait_event(self._stats_done[self._stats_last])
+                main.wait_event(self._stats_done[self._stats_last])
             if self.use_graph:
                 self._graph.replay()
             else:
@@ -420,22 +448,17 @@ class RolloutCollector:
             self._bootstrap_timeouts()
             ops.gae(self.buf_rew, self.buf_val, self.buf_start, self.last_val, self.episode_start, self.gamma,
                     self.lam, advantages=self.adv, returns=self.ret, stats=self.stats)
-        k = self._rollouts % 2
         self._rollouts += 1
-        main = torch.cuda.current_stream(self.device)
         self._stats_ready[k].record(main)                   # the rollout is complete on the main stream here
-        # everything behind the rollout runs on the side stream, so the main stream carries the rollout and nothing else: ONE
-        # small copy takes the status words and the advantage moments out of the next rollout's way (which waits for
-        # _copied, never for the collective), then the host copy, the collective and the advantage statistics
+        # everything behind the rollout runs on the side stream and reads this slot's words where the rollout left them; the
+        # main stream carries rollouts and nothing else
         with torch.cuda.stream(self._side):
             self._side.wait_event(self._stats_ready[k])
-            self._post_slot[k].copy_(self._post)            # (this slot's previous user ran two rollouts ago on this stream)
-            self._copied.record(self._side)
             if self.fused_policy:
-                self._status_host[k].copy_(self._post_slot[k][0:8], non_blocking=True)
+                self._status_host[k].copy_(self._post[k][0:8], non_blocking=True)
                 self._status_event[k].record(self._side)
                 self._status_pending[k] = True
-            gathered = D.allgather_payload(self._stats_slot[k])     # the one collective per update (a view at one rank)
+            gathered = D.allgather_payload(self._stats_k[k])        # the one collective per update (a view at one rank)
             ops.advantage_stats(gathered, self._adv_ms[k])
             self._stats_done[k].record(self._side)
         self._stats_last = k

@@ -187,7 +187,7 @@ def test_persistent_refuses_more_workgroups_than_cus():
 
 
 def test_persistent_rollout_replays_from_a_graph(oracle):
-    """The persistent launch (a cooperative launch behind a memset node) captured into the collector's HIP graph: ticks advance
+    """The persistent launch (a cooperative launch behind a memset node) captured into the collector's HIP graphs: ticks advance
     by n_steps per replay, the timeout word stays clear, outputs are finite and change from rollout to rollout."""
     from fpv_drone_rl_agent_amd.engine import FpvEngine
     from fpv_drone_rl_agent_amd.rollout import RolloutCollector
@@ -206,5 +206,6 @@ def test_persistent_rollout_replays_from_a_graph(oracle):
             assert not torch.equal(prev, b["values"])
         prev = b["values"].clone()
     assert col._graph is not None
-    assert eng.get_tick() == t0 + 4 * T          # the capture's warm-up rollout + three replays
+    assert eng.get_tick() == t0 + 5 * T          # two captures (the collector alternates between two graphs), each with a
+                                                 # warm-up rollout, + three replays
     assert col.episodes["count"] > 0             # reading the episode numbers checks the status words (timeout flag clear)

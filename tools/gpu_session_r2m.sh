@@ -7,9 +7,10 @@ timeout -k 10 300 python tools/region_overhead.py > gpurun_out/r2m/region.txt 2>
 cat gpurun_out/r2m/region.txt
 python bench.py --no-cpu-baseline --no-split-extra > gpurun_out/r2m/bench.json 2> gpurun_out/r2m/bench.err
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-split-extra > gpurun_out/r2m/bench_s20.json 2> gpurun_out/r2m/bench_s20.err
+python bench.py --no-graph --no-cpu-baseline --no-split-extra > gpurun_out/r2m/bench_eager.json 2> gpurun_out/r2m/bench_eager.err
 python - <<'PY'
 import json
-for k in ("bench", "bench_s20"):
+for k in ("bench", "bench_s20", "bench_eager"):
     d = json.load(open(f"gpurun_out/r2m/{k}.json"))
     print(k, round(d["value"]), round(d["ms_per_step"] * 1e3, 2))
 PY
