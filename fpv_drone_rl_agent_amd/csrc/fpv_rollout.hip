@@ -47,7 +47,32 @@ __global__ __launch_bounds__(kRedBlock) void gae_kernel(int64_t T, int64_t n, co
         float next_v = last_values[i];
         float next_nt = 1.0f - (float)last_dones[i];
         float last = 0.0f;
-        for (int64_t t = T - 1; t >= 0; --t) {
+        // the scan is a dependent chain, its inputs are not: four time steps' rows are requested before the first is used
+        // (a plain loop waits out one memory round trip per step); same operations in the same order
+        int64_t t = T - 1;
+        for (; t >= 3; t -= 4) {
+            float v4[4], r4[4];
+            uint8_t s4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t e = (t - q) * n + i;
+                v4[q] = values[e]; r4[q] = rewards[e]; s4[q] = starts[e];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int64_t e = (t - q) * n + i;
+                const float v = v4[q];
+                const float delta = r4[q] + gamma * next_v * next_nt - v;
+                last = delta + gamma * lam * next_nt * last;
+                adv[e] = last;
+                returns[e] = last + v;
+                s1 += (double)last;
+                s2 += (double)last * (double)last;
+                next_v = v;
+                next_nt = 1.0f - (float)s4[q];
+            }
+        }
+        for (; t >= 0; --t) {
             const int64_t e = t * n + i;
             const float v = values[e];
             const float delta = rewards[e] + gamma * next_v * next_nt - v;
@@ -428,53 +453,79 @@ __global__ __launch_bounds__(256) void ledger_scan_kernel(LedgerScanArgs a) {
     const uint32_t tick0 = (uint32_t)(a.tick[0] - (uint64_t)a.T);
     double sr = 0.0, sl = 0.0;
     int nv = 0, episodes = 0, flags = 0;
+    // Two rounds of independent loads instead of kScanPerThread dependent ones: every slot's tile count first, then — with the
+    // index clamped to slot 0 where the slot is empty, so that no load sits under a run-time test — info / return / tag.
+    uint32_t cnt_[kScanPerThread], info_[kScanPerThread], tag_[kScanPerThread];
+    float ret_[kScanPerThread];
+#pragma unroll
+    for (int it = 0; it < kScanPerThread; ++it) {
+        const int64_t s = ((int64_t)blockIdx.x * kScanPerThread + it) * 256 + threadIdx.x;
+        const int tile = s < slots ? (int)((uint32_t)s / (uint32_t)a.rows) : 0;     // slots < 2^31 (checked by the launcher)
+        cnt_[it] = a.led_count[tile];
+    }
+#pragma unroll
+    for (int it = 0; it < kScanPerThread; ++it) {
+        const int64_t s = ((int64_t)blockIdx.x * kScanPerThread + it) * 256 + threadIdx.x;
+        const int tile = s < slots ? (int)((uint32_t)s / (uint32_t)a.rows) : 0;
+        const int row = (int)s - tile * a.rows;
+        const uint32_t lim = cnt_[it] < (uint32_t)a.rows ? cnt_[it] : (uint32_t)a.rows;
+        const int64_t q = (s < slots && (uint32_t)row < lim) ? s : 0;
+        info_[it] = a.led_info[q]; ret_[it] = a.led_ret[q]; tag_[it] = a.led_tag[q];
+    }
+#pragma unroll
     for (int it = 0; it < kScanPerThread; ++it) {
         const int64_t s = ((int64_t)blockIdx.x * kScanPerThread + it) * 256 + threadIdx.x;
         bool trunc = false;
         int32_t t = 0;
         if (s < slots) {
-            const int tile = (int)((uint32_t)s / (uint32_t)a.rows);     // slots < 2^31 (checked by the launcher)
+            const int tile = (int)((uint32_t)s / (uint32_t)a.rows);
             const int row = (int)s - tile * a.rows;
-            const uint32_t cnt = a.led_count[tile];
+            const uint32_t cnt = cnt_[it];
             if (row == 0) {
                 episodes += (int)cnt;
                 if (cnt > (uint32_t)a.rows) flags |= 1;
             }
             if ((uint32_t)row < (cnt < (uint32_t)a.rows ? cnt : (uint32_t)a.rows)) {
-                const uint32_t info = a.led_info[s];
+                const uint32_t info = info_[it];
                 ++nv;
-                sr += (double)a.led_ret[s];
+                sr += (double)ret_[it];
                 sl += (double)(info >> 8);
-                t = (int32_t)(a.led_tag[s] - tick0);
+                t = (int32_t)(tag_[it] - tick0);
                 trunc = (info & kInfoTrunc) && !(info & kInfoTerm);
                 if (trunc && (t < 0 || t >= a.T)) { flags |= 2; trunc = false; }
             }
         }
-        // truncated-not-terminated entries -> dense list (one atomic per wave that has any; they are rare)
-        const unsigned long long m = __ballot(trunc);
+        // truncated-not-terminated entries -> dense list (one atomic per wave that has any; they are rare).  The terminal
+        // observation of each entry is normalised and copied by the WAVE, one lane per word, entry after entry — a lane doing
+        // its own entry's obs_words fp64 normalisations one after the other was most of this kernel's time.
+        unsigned long long m = __ballot(trunc);
         if (m) {
             int base = 0;
             if (lane == 0) base = atomicAdd(&a.counters[0], __popcll(m));
             base = __shfl(base, 0);
+            const int64_t pos = (int64_t)base + __popcll(m & ((1ull << lane) - 1ull));
             if (trunc) {
-                const int64_t pos = (int64_t)base + __popcll(m & ((1ull << lane) - 1ull));
                 if (pos < a.cap) {
                     a.t_idx[pos] = t;
                     a.d_idx[pos] = a.led_idx[s];
-                    const float* src = a.led_obs + s * a.obs_words;
-                    float* dst = a.tobs + pos * a.obs_words;
-                    for (int j = 0; j < a.obs_words; ++j) {
-                        float x = src[j];
-                        if (a.snapshots) {
-                            const double mean = a.snapshots[(int64_t)t * a.stride + j];
-                            const double var = a.snapshots[(int64_t)t * a.stride + a.obs_words + j];
-                            const double z = ((double)x - mean) / sqrt(var + (double)a.eps);
-                            x = (float)fmin(fmax(z, -(double)a.clip_obs), (double)a.clip_obs);
-                        }
-                        dst[j] = x;
-                    }
                 } else {
                     flags |= 4;
+                }
+            }
+            while (m) {
+                const int b = __ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                const int64_t sb = __shfl(s, b), pb = __shfl(pos, b);      // 64-bit shuffles: two dwords each
+                const int tb = __shfl(t, b);
+                if (pb < a.cap && lane < a.obs_words) {
+                    float x = a.led_obs[sb * a.obs_words + lane];
+                    if (a.snapshots) {
+                        const double mean = a.snapshots[(int64_t)tb * a.stride + lane];
+                        const double var = a.snapshots[(int64_t)tb * a.stride + a.obs_words + lane];
+                        const double z = ((double)x - mean) / sqrt(var + (double)a.eps);
+                        x = (float)fmin(fmax(z, -(double)a.clip_obs), (double)a.clip_obs);
+                    }
+                    a.tobs[pb * a.obs_words + lane] = x;
                 }
             }
         }
