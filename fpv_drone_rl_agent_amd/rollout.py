@@ -117,7 +117,7 @@ class RolloutCollector:
             # env step grows 16.1 -> 23.0 us (the reducer's ticket + eight dependent sc1 round trips sit on the step's
             # tail), 72.5 -> 77.1 us per rollout step, so it is not the default.  Both off: the stand-alone merge kernel.
             self._merge_in_step = bool(merge_in_step) and (self.norm_obs or self.norm_reward)
-            self._merge_in_policy = (not self._merge_in_step and bool(merge_in_policy) and engine.tiles <= 1024
+            self._merge_in_policy = (not self._merge_in_step and bool(merge_in_policy) and engine.partial_rows <= 1024
                                      and (self.norm_obs or self.norm_reward)
                                      and not self.overlap_critic)   # (the table is <= 1 024 rows by construction)
             self._obs_rms_alt = torch.zeros_like(self.obs_norm.rms)
@@ -132,11 +132,15 @@ class RolloutCollector:
             if one_launch and not can:
                 raise ValueError("one_launch needs the hover task with motor noise, num_envs a multiple of 256 (<= 262 144), "
                                  "policy_gemm='f32' and the default statistics-merge placement")
-            self._one_launch = self._one_launch_ok = can if one_launch is None else bool(one_launch)
+            # Default: where every workgroup finds a CU of its own (num_envs <= 256 x CUs).  Beyond that the second round of
+            # workgroups stages the weight image again, while the two-kernel shape's policy kernel keeps it in LDS across its
+            # chunks: measured 128.2 vs 126.3 us per step at 131 072 drones, 257.2 vs 234.9 at 262 144.
+            cus = torch.cuda.get_device_properties(dev).multi_processor_count
+            self._one_launch = self._one_launch_ok = (can and N // 256 <= cus) if one_launch is None else bool(one_launch)
             # persistent: the WHOLE rollout of n_steps as one launch (fpv_rollout_steps): weights stay in LDS, drone state in
             # registers, a grid-wide barrier + statistics merge between steps.  Same bits again.  Needs every workgroup resident:
             # at most one per CU, i.e. num_envs <= 256 x CUs.
-            can_p = can and N // 256 <= torch.cuda.get_device_properties(dev).multi_processor_count
+            can_p = can and N // 256 <= cus
             if persistent and not can_p:
                 raise ValueError("persistent needs what one_launch needs and num_envs <= 256 x the device's CU count")
             self._persistent = self._persistent_ok = False if persistent is None else bool(persistent)

@@ -19,6 +19,8 @@ shapes = {"two_kernels_per_step": dict(one_launch=False, persistent=False),
           "one_kernel_per_step": dict(one_launch=True, persistent=False),
           "one_launch_per_rollout": dict(one_launch=True, persistent=True)}
 for name, kw in shapes.items():
+    if kw["persistent"] and n // 256 > torch.cuda.get_device_properties(0).multi_processor_count:
+        continue                      # the persistent launch needs one workgroup per CU at most
     torch.manual_seed(0)
     eng = FpvEngine(n, 0, noise_ratio=0.02, seed=0, ledger_capacity=n * max(2, T // 8))
     col = RolloutCollector(eng, ActorCritic().cuda(), n_steps=T, **kw)
