@@ -30,6 +30,14 @@ __device__ __forceinline__ float fast_tanh(float x) {
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// tanh of a pre-activation that arrives already multiplied by 2 log2(e): the exact-fp32 policy image (fpv_policy.hip's
+// pack kernel) carries that factor in the hidden layers' weights and biases, which takes one multiply out of every tanh —
+// vector instructions do not overlap the fp32 MFMA stream, so each one is launch time.
+constexpr float kTanhPrescale = 2.8853900817779268f;
+__device__ __forceinline__ float fast_tanh_prescaled(float z) {
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
+}
+
 // bias image [m][h][16] -> accumulator tiles
 __device__ __forceinline__ void bias_init(Hidden& a, const float* __restrict__ lb, int h) {
 #pragma unroll
@@ -41,6 +49,13 @@ __device__ __forceinline__ void bias_init(Hidden& a, const float* __restrict__ l
             a.t[m][4 * q] = v.x; a.t[m][4 * q + 1] = v.y; a.t[m][4 * q + 2] = v.z; a.t[m][4 * q + 3] = v.w;
         }
     }
+}
+
+__device__ __forceinline__ void tanh_all_prescaled(Hidden& a) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a.t[m][r] = fast_tanh_prescaled(a.t[m][r]);
 }
 
 __device__ __forceinline__ void tanh_all(Hidden& a) {

@@ -3,14 +3,12 @@ set -e
 mkdir -p gpurun_out/r2m
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/r2m/tests.txt 2>&1 || { tail -30 gpurun_out/r2m/tests.txt; exit 1; }
 tail -2 gpurun_out/r2m/tests.txt
-timeout -k 10 300 python tools/region_overhead.py > gpurun_out/r2m/region.txt 2>&1 || { tail -20 gpurun_out/r2m/region.txt; exit 1; }
-cat gpurun_out/r2m/region.txt
+python tools/rollout_phases.py 2>/dev/null | cut -c1-420
 python bench.py --no-cpu-baseline --no-split-extra > gpurun_out/r2m/bench.json 2> gpurun_out/r2m/bench.err
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-split-extra > gpurun_out/r2m/bench_s20.json 2> gpurun_out/r2m/bench_s20.err
-python bench.py --no-graph --no-cpu-baseline --no-split-extra > gpurun_out/r2m/bench_eager.json 2> gpurun_out/r2m/bench_eager.err
+python bench.py --two-launch --no-cpu-baseline --no-split-extra > gpurun_out/r2m/bench_two.json 2> gpurun_out/r2m/bench_two.err
 python - <<'PY'
 import json
-for k in ("bench", "bench_s20", "bench_eager"):
+for k in ("bench", "bench_two"):
     d = json.load(open(f"gpurun_out/r2m/{k}.json"))
-    print(k, round(d["value"]), round(d["ms_per_step"] * 1e3, 2))
+    print(k, round(d["value"]), round(d["ms_per_step"] * 1e3, 2), d["roofline"]["frac"], d["roofline"].get("frac_of_peak_within_policy_phase"))
 PY
