@@ -357,7 +357,7 @@ def main() -> None:
                 us_traced, cadence = us_one, elapsed / K * 1e6
                 if us_one > cadence:
                     us_one, how = cadence, how + ", capped at the timed region's own time per step"
-                phases = kernel_phases()
+                phases = kernel_phases() if world == 1 else None      # (extra captures + collects: kept off the multi-rank runs)
                 tf = POLICY_FLOP_PER_ROW * n / us_one / 1e6
                 roofline = {"bound": "mfma", "kernel": "fpv::rollout_step_kernel", "achieved": round(tf, 1),
                             "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
