@@ -325,9 +325,12 @@ class RolloutCollector:
         self._starts[t + 1].copy_(self.done)
 
     def _all_steps(self) -> None:
-        if self.fused_policy:
-            self.engine.ledger_clear()
-        self._starts[0].copy_(self._starts[self.T])
+        if self.fused_policy and self.N % 16 == 0:
+            self.engine.rollout_begin(self._starts[0], self._starts[self.T])     # ledger clear + episode-start carry: one kernel
+        else:
+            if self.fused_policy:
+                self.engine.ledger_clear()
+            self._starts[0].copy_(self._starts[self.T])
         if self._persistent:
             self._rollout_persistent()
         else:
