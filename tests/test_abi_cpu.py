@@ -33,6 +33,42 @@ def test_config_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.FpvLedger) == 64
 
 
+def test_every_struct_layout_matches_the_header(tmp_path):
+    """sizeof and every field offset of the ctypes mirrors against what gcc makes of include/fpv_env.h."""
+    import subprocess
+    from fpv_drone_rl_agent_amd import _lib
+    pairs = {"fpv_config": _lib.FpvConfig, "fpv_ledger": _lib.FpvLedger, "fpv_step_extras": _lib.FpvStepExtras,
+             "fpv_policy_io": _lib.FpvPolicyIo, "fpv_ppo_io": _lib.FpvPpoIo, "fpv_rollout_io": _lib.FpvRolloutIo}
+    header = open(os.path.join(ROOT, "include", "fpv_env.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "fpv_env.h"', 'int main(void) {']
+    fields = {}
+    for cname, cls in pairs.items():
+        body = re.search(r"typedef struct\s*\{([^}]*)\}\s*" + cname + r"\s*;", header, flags=re.S).group(1)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            first, *rest = decl.split(",")
+            names.append(re.findall(r"([A-Za-z_][A-Za-z0-9_]*)\s*(?:\[[^\]]*\])?\s*$", first.strip())[0])
+            names += [re.findall(r"([A-Za-z_][A-Za-z0-9_]*)", r)[0] for r in rest]
+        fields[cname] = names
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        lines += [f'printf("{cname}.{f} %zu\\n", offsetof({cname}, {f}));' for f in names]
+    lines += ["return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in pairs.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        assert [n for n, *_ in cls._fields_] == fields[cname], f"{cname}: field names / order differ from the header"
+        for f in fields[cname]:
+            assert int(got[f"{cname}.{f}"]) == getattr(cls, f).offset, f"{cname}.{f}"
+
+
 def test_argument_errors_reported_without_gpu():
     from fpv_drone_rl_agent_amd import _lib
     lib = _lib.load()
@@ -41,6 +77,9 @@ def test_argument_errors_reported_without_gpu():
     assert lib.fpv_step(None, None, None, None, None, None, None) == -1
     assert lib.fpv_gae(0, 0, None, None, None, None, None, 0.99, 0.95, None, None, None, None) == -1
     assert lib.fpv_destroy(None) == 0
+    assert lib.fpv_rollout_step(None, None, None, None, None, None, None, None) == -1 and b"fpv_rollout_step" in lib.fpv_last_error()
+    assert lib.fpv_rollout_steps(None, None, None, None) == -1 and b"fpv_rollout_steps" in lib.fpv_last_error()
+    assert lib.fpv_rollout_begin(None, None, None, None) == -1
     with pytest.raises(ValueError):
         _lib.check(-1, "x")
     with pytest.raises(RuntimeError):
