@@ -118,6 +118,7 @@ SIGNATURES = {
     "fpv_set_pair_threshold": (C.c_int, [_i64]),
     "fpv_noop": (C.c_int, [_vp]),
     "fpv_debug_rollout_stamps": (C.c_int, [_vp]),
+    "fpv_debug_rollout_timeout": (C.c_int, [_u64]),
     "fpv_last_error": (C.c_char_p, []),
     "fpv_version": (C.c_int, []),
 }

@@ -138,6 +138,12 @@ int fpv_debug_rollout_stamps(uint64_t* device_buffer) {
     return FPV_OK;
 }
 
+static uint64_t g_rollout_timeout_ticks = 0;     // 0: the default of fpv_rollout_steps
+int fpv_debug_rollout_timeout(uint64_t ticks) {
+    g_rollout_timeout_ticks = ticks;
+    return FPV_OK;
+}
+
 int fpv_noop(void* stream) {
     hipLaunchKernelGGL(fpv_noop_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream);
     FPV_HIP(hipGetLastError());
@@ -672,7 +678,8 @@ int fpv_rollout_steps(fpv_env* e, fpv_policy* p, const fpv_rollout_io* io, void*
     h.snapshots = io->snapshots; h.snap_stride = io->snapshot_stride;
     h.rows[0] = io->partials[0]; h.rows[1] = io->partials[1];
     h.sync = e->rollout_sync; h.status = io->status;
-    h.timeout_ticks = 200000000ull;     // 2 s of the 100 MHz counter: far beyond any step, short enough to end a stuck launch
+    // 2 s of the 100 MHz counter: far beyond any step, short enough to end a stuck launch (fpv_debug_rollout_timeout overrides)
+    h.timeout_ticks = g_rollout_timeout_ticks ? g_rollout_timeout_ticks : 200000000ull;
     FPV_HIP(launch_rollout_persistent(h, a, (hipStream_t)stream));
     return FPV_OK;
 }

@@ -564,7 +564,7 @@ __device__ __forceinline__ bool grid_reduce(uint32_t* w, const double* rows, uin
         uint32_t polls = 0;
         while (sync_load(w + (kSyncGen + g) * kSyncStride) < epoch) {
             __builtin_amdgcn_s_sleep(1);
-            if ((++polls & 15u) == 0u) {
+            if ((++polls & 15u) == 1u) {                // on the first poll and every sixteenth after it
                 if (sync_load(w + kSyncAbort * kSyncStride) != 0u) { ok = false; break; }
                 if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
                     __hip_atomic_store(w + kSyncAbort * kSyncStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

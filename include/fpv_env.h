@@ -414,6 +414,10 @@ int fpv_noop(void* stream);
  * [workgroup][T][8] into it: 0 step begins, 1 policy done, 2 env step done, 3 arriving at the grid barrier, 4 barrier passed,
  * 5 statistics merged (tools/rollout_phases.py).  NULL switches it off again. */
 int fpv_debug_rollout_stamps(uint64_t* device_buffer);
+/* Diagnostic: bound of every grid-wide wait inside fpv_rollout_steps in ticks of the 100 MHz counter (0 = the default, 2 s).
+ * A bound of one tick makes the first wait give up: the way tests/test_rollstep_gpu.py exercises the abandon path (every
+ * workgroup leaves its loop, the status word is set, nothing hangs). */
+int fpv_debug_rollout_timeout(uint64_t ticks);
 
 const char* fpv_last_error(void);
 int fpv_version(void);

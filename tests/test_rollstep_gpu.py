@@ -209,3 +209,30 @@ def test_persistent_rollout_replays_from_a_graph(oracle):
     assert eng.get_tick() == t0 + 5 * T          # two captures (the collector alternates between two graphs), each with a
                                                  # warm-up rollout, + three replays
     assert col.episodes["count"] > 0             # reading the episode numbers checks the status words (timeout flag clear)
+
+
+def test_persistent_rollout_gives_up_cleanly_when_a_grid_wait_times_out(oracle):
+    """Every grid-wide wait of fpv_rollout_steps is bounded.  With the bound set to one tick (fpv_debug_rollout_timeout) the
+    first wait is abandoned: the launch must still END — every workgroup leaves its step loop — with the status word set,
+    which the collector turns into an error; with the default bound back the same collector shape works again."""
+    from fpv_drone_rl_agent_amd import _lib as L
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.rollout import RolloutCollector
+    lib = L.load()
+    n, T = 65536, 6
+    try:
+        lib.fpv_debug_rollout_timeout(1)
+        col = RolloutCollector(FpvEngine(n, 0, seed=4), _policy(3), n_steps=T, persistent=True, use_graph=False)
+        col.start()
+        col.collect()
+        torch.cuda.synchronize()                 # returns: the launch ended although its barrier never completed
+        with pytest.raises(RuntimeError, match="timed out"):
+            _ = col.episodes
+    finally:
+        lib.fpv_debug_rollout_timeout(0)
+    col = RolloutCollector(FpvEngine(n, 0, seed=4), _policy(3), n_steps=T, persistent=True, use_graph=False)
+    col.start()
+    _synthetic(col.engine, oracle, 6)
+    col.collect()
+    col.collect()
+    assert col.episodes["count"] >= 0            # status words clean
