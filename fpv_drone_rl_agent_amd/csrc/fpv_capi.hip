@@ -581,17 +581,18 @@ int fpv_rollout_step(fpv_env* e, fpv_policy* p, const fpv_policy_io* io, float* 
                      const fpv_step_extras* ex, void* stream) {
     if (!e || !p || !io) return fail(FPV_ERR_ARG, "fpv_rollout_step: null argument");
     if (!io->obs || !io->value || !reward || !terminated || !truncated) return fail(FPV_ERR_ARG, "fpv_rollout_step: null buffer");
-    if (e->cfg.precision != FPV_F32 || e->cfg.task != FPV_TASK_HOVER || e->cfg.noise_ratio == 0.0)
-        return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: fp32 hover handles with motor noise only");
+    if (e->cfg.precision != FPV_F32 || e->cfg.noise_ratio == 0.0)
+        return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: fp32 handles with motor noise only");
     if (e->cfg.num_envs % 256 != 0) return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: num_envs must be a multiple of 256");
     if (io->n != e->cfg.num_envs) return fail(FPV_ERR_ARG, "fpv_rollout_step: io->n must equal num_envs");
-    if (p->in_dim != 20 || p->act_dim != 4 || p->gemm != 0)
-        return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: policy widths 20 / 4 in gemm mode 0 only");
+    const bool yaw = e->cfg.task == FPV_TASK_YAW;
+    if (p->in_dim != e->obs_words || p->act_dim != e->act_words || p->gemm != 0)
+        return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: policy widths must be the task's (%d / %d), gemm mode 0", e->obs_words, e->act_words);
     if (io->eps_in || io->eps_out || io->deterministic || io->narrow || io->n_dev || (io->nets != 0 && io->nets != 3))
         return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: eps_in / eps_out / deterministic / narrow / n_dev / single nets are not served");
     if (ex && (ex->obs_rms || ex->ret_rms || ex->snapshot))
         return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: the statistics update rides in the next call's io->merge_* fields");
-    if (((uintptr_t)io->obs | (uintptr_t)io->obs_n | (uintptr_t)io->action | (uintptr_t)io->clipped) & 15)
+    if (((uintptr_t)io->obs | (uintptr_t)io->obs_n | (yaw ? 0 : ((uintptr_t)io->action | (uintptr_t)io->clipped))) & 15)
         return fail(FPV_ERR_ARG, "fpv_rollout_step: row buffers must be 16-byte aligned");
     MergeArgs mg{};
     if (io->merge_partials) {
@@ -625,7 +626,7 @@ int fpv_rollout_step(fpv_env* e, fpv_policy* p, const fpv_policy_io* io, float* 
     a.gamma = ex ? ex->gamma : 0.0f;
     a.mg_count = (double)e->cfg.num_envs;
     FPV_HIP(launch_rollout_step(p->image, io->rms, io->obs_n, io->action, io->clipped, io->value, io->logp, io->seed, io->id_offset,
-                                io->clip_obs, io->eps_norm, mg, a, (hipStream_t)stream));
+                                io->clip_obs, io->eps_norm, mg, a, yaw ? 1 : 0, (hipStream_t)stream));
     return FPV_OK;
 }
 

@@ -22,6 +22,7 @@
 #include "fpv_mlp.h"
 #include "fpv_policy_image.h"
 #include "fpv_step_parts.h"
+#include "fpv_yaw_parts.h"
 
 namespace fpv {
 
@@ -89,32 +90,35 @@ __device__ __forceinline__ void rs_stage(const float* __restrict__ image, float*
 }
 
 // normalise -> pi, V -> sample -> log-prob -> clip for this lane's drone d (both halves of the wave share it); xraw = the raw
-// observation words 10 h .. 10 h + 9 of d.  Weights and normaliser are in LDS.
+// observation words (IN / 2) h .. (IN / 2) h + IN / 2 - 1 of d.  IN / ACT: 20 / 4 hover, 12 / 1 yaw.  Weights and normaliser
+// are in LDS.
 // lane = threadIdx.x & 63, passed in so that a caller with a step loop can hide it from loop-invariant code motion (hipcc
 // otherwise precomputes every LDS address of the unrolled layers outside the loop, one register each).
-__device__ __forceinline__ f32x4 rs_policy_core(const float* lds, const f32x2 (&xraw)[5], int64_t d, bool live, bool normalise,
+template <int IN, int ACT>
+__device__ __forceinline__ f32x4 rs_policy_core(const float* lds, const f32x2 (&xraw)[IN / 4], int64_t d, bool live, bool normalise,
                                                 float clip_obs, const PolicyOut& out, uint64_t tick, uint64_t pol_seed,
                                                 uint64_t pol_id_offset, int lane) {
+    constexpr int HALF = IN / 2;
     const float* hb = lds + 2 * kNetFloats;
     const int h = lane >> 5;
     const float clip = normalise ? clip_obs : 3.0e38f;
-    float x[kHalf];
+    float x[HALF];
     {
 #pragma unroll
-        for (int q = 0; q < kHalf / 2; ++q) {
+        for (int q = 0; q < HALF / 2; ++q) {
             f32x2 v = xraw[q];
             if (!live) v = f32x2{0.f, 0.f};
             x[2 * q] = v.x; x[2 * q + 1] = v.y;
         }
 #pragma unroll
-        for (int j = 0; j < kHalf; ++j) {
-            const int k = kHalf * h + j;
+        for (int j = 0; j < HALF; ++j) {
+            const int k = HALF * h + j;
             x[j] = fminf(fmaxf((x[j] - hb[660 + k]) * hb[680 + k], -clip), clip);
         }
         if (out.obs_n && live) {
-            f32x2* o = reinterpret_cast<f32x2*>(out.obs_n + d * kIn + kHalf * h);
+            f32x2* o = reinterpret_cast<f32x2*>(out.obs_n + d * IN + HALF * h);
 #pragma unroll
-            for (int q = 0; q < kHalf / 2; ++q) o[q] = f32x2{x[2 * q], x[2 * q + 1]};
+            for (int q = 0; q < HALF / 2; ++q) o[q] = f32x2{x[2 * q], x[2 * q + 1]};
         }
     }
     float head[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
@@ -124,7 +128,7 @@ __device__ __forceinline__ f32x4 rs_policy_core(const float* lds, const f32x2 (&
         Hidden a;
         bias_init(a, nb + kOffB1, h);
 #pragma unroll
-        for (int s = 0; s < kHalf; ++s)            // 10 products per tile: no padded k (the image keeps 12 slots per tile)
+        for (int s = 0; s < HALF; ++s)             // IN / 2 products per tile: no padded k (the image keeps 12 slots per tile)
 #pragma unroll
             for (int m = 0; m < 4; ++m)
                 a.t[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(nb[kOffW1 + (m * 12 + s) * 64 + lane], x[s], a.t[m], 0, 0, 0);
@@ -184,14 +188,22 @@ __device__ __forceinline__ f32x4 rs_policy_core(const float* lds, const f32x2 (&
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         act[j] = mu[j] + hb[652 + j] * eps[j];
-        lp -= 0.5f * eps[j] * eps[j];
+        if (j < ACT) lp -= 0.5f * eps[j] * eps[j];
     }
     const f32x4 cl = f32x4{fminf(fmaxf(act[0], -1.f), 1.f), fminf(fmaxf(act[1], -1.f), 1.f),
                            fminf(fmaxf(act[2], -1.f), 1.f), fminf(fmaxf(act[3], -1.f), 1.f)};
     if (live) {
         if (h == 0) {
-            if (out.action) reinterpret_cast<f32x4*>(out.action)[d] = f32x4{act[0], act[1], act[2], act[3]};
-            if (out.clipped) reinterpret_cast<f32x4*>(out.clipped)[d] = cl;
+            if constexpr (ACT == 4) {
+                if (out.action) reinterpret_cast<f32x4*>(out.action)[d] = f32x4{act[0], act[1], act[2], act[3]};
+                if (out.clipped) reinterpret_cast<f32x4*>(out.clipped)[d] = cl;
+            } else {
+#pragma unroll
+                for (int j = 0; j < ACT; ++j) {
+                    if (out.action) out.action[d * ACT + j] = act[j];
+                    if (out.clipped) out.clipped[d * ACT + j] = cl[j];
+                }
+            }
         } else if (out.logp) {
             out.logp[d] = lp;
         }
@@ -200,22 +212,23 @@ __device__ __forceinline__ f32x4 rs_policy_core(const float* lds, const f32x2 (&
 }
 
 // staging, merge prologue and the observation rows (from memory) of the one-step kernel; ends with a workgroup barrier
-__device__ __forceinline__ void rollstep_prologue(const RollStepArgs& p, float* lds, f32x2 (&xpre)[5]) {
+template <int IN>
+__device__ __forceinline__ void rollstep_prologue(const RollStepArgs& p, float* lds, f32x2 (&xpre)[IN / 4]) {
     float* hb = lds + 2 * kNetFloats;                // heads [660], then normaliser mean[20], inv[20]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = lane & 31, h = lane >> 5;
     const int64_t d = (int64_t)blockIdx.x * 256 + wave * 32 + col;
     {
-        const f32x2* row = reinterpret_cast<const f32x2*>(p.st.obs + (d < p.st.n ? d : 0) * kIn + kHalf * h);
+        const f32x2* row = reinterpret_cast<const f32x2*>(p.st.obs + (d < p.st.n ? d : 0) * IN + (IN / 2) * h);
 #pragma unroll
-        for (int q = 0; q < kHalf / 2; ++q) xpre[q] = row[q];
+        for (int q = 0; q < IN / 4; ++q) xpre[q] = row[q];
     }
     MergeRegs mr;
     if (p.mg.rows) merge_request(p.mg, mr);
     rs_stage<(kImageFloats / 4 + 511) / 512>(p.image, lds, 0, kImageFloats);
-    if (!p.mg.rows && (int)threadIdx.x < kIn) {
+    if (!p.mg.rows && (int)threadIdx.x < IN) {
         hb[660 + threadIdx.x] = p.rms ? (float)p.rms[threadIdx.x] : 0.0f;
-        hb[680 + threadIdx.x] = p.rms ? (float)(1.0 / sqrt(p.rms[kIn + threadIdx.x] + (double)p.eps_norm)) : 1.0f;
+        hb[680 + threadIdx.x] = p.rms ? (float)(1.0 / sqrt(p.rms[IN + threadIdx.x] + (double)p.eps_norm)) : 1.0f;
     }
     if (p.mg.rows) merge_prologue(p.mg, mr, p.rms, reinterpret_cast<double*>(hb + 700), p.eps_norm, hb + 660, hb + 680);
     __syncthreads();
@@ -406,25 +419,168 @@ __device__ __forceinline__ void rs_store_tile(const StepArgs<float>& s, const Ti
     if (wave < 4 && lane == 0) s.tick[(int64_t)blockIdx.x * 4 + (wave & 3)] = tr.agent_tick;
 }
 
-// ---------------------------------------------------------------- the one-step kernel
+// ---------------------------------------------------------------- phase 2 of the yaw task (fpv_yaw.hip's step body)
+// One aviary step = one control tick + two sub-steps per agent step (yaw.py:126-127): the physics wave draws its own eight
+// normals, so there is no noise hand-off; waves 4..7 only take the observation tile (row-major store, moment sums).
+// LDS: kRsAct as above, then per tile [64][12] observations + 64 returns, 128 doubles of exchange, 4 x 28 doubles of sums.
+constexpr int kRsYawTileFloats = kTile * kYawObsWords + kTile;
+constexpr int kRsYawTile = kRsNoise, kRsYawXch = kRsYawTile + 4 * kRsYawTileFloats, kRsYawSum = kRsYawXch + 4 * 256;
+constexpr int kYawRow = 2 * kYawObsWords + 4;
+static_assert((kRsYawXch * 4) % 8 == 0 && (kRsYawSum * 4) % 8 == 0 && kRsYawSum + 2 * 4 * kYawRow <= 2 * kNetFloats, "yaw phase-2 map");
+
+struct YawTileRegs {
+    Drone<float> d;
+    YawExtra<float> e;
+    uint64_t agent_tick;
+    uint32_t led_fill;
+};
+
+__device__ __forceinline__ void rs_load_tile_yaw(const StepArgs<float>& s, YawTileRegs& tr) {
+    const int lane = threadIdx.x & (kTile - 1), wave = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (wave & 3);
+    tr.agent_tick = s.tick[tile];
+    tr.led_fill = 0u;
+    if (wave < 4) {
+        load_drone<float, kYawGranules>(tr.d, s.state, tile, lane);
+        const Vec4<float>* ext = s.state + tile * (kYawGranules * kTile) + lane;
+        const Vec4<float> g9 = ext[9 * kTile], g10 = ext[10 * kTile];
+        tr.e = YawExtra<float>{g9.x, g9.y, g9.z, g9.w, g10.x, g10.y, g10.z, g10.w};
+        tr.led_fill = s.led_count[tile];
+    }
+}
+
+// Called by all 512 threads after the clipped actions are in LDS and a workgroup barrier.  Two workgroup barriers on every path.
+__device__ __forceinline__ void rs_tail_yaw(const StepArgs<float>& s, float* lds, YawTileRegs& tr, const TailOut& o_) {
+    using T = float;
+    const int lane = threadIdx.x & (kTile - 1), wave = threadIdx.x >> 6;
+    const int tl = wave & 3;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + tl;
+    const int64_t i = tile * kTile + lane;
+    const bool live = i < s.n;
+    Vec4<T>* tl_lds = reinterpret_cast<Vec4<T>*>(lds + kRsYawTile + tl * kRsYawTileFloats);
+    double* bsum = reinterpret_cast<double*>(lds + kRsYawSum);
+    if (wave >= 4) {
+        lds_barrier();   // A: the physics wave has staged the observation tile (and the returns)
+        const int64_t rows_left = s.n - tile * kTile;
+        if (o_.partials) {
+            const int rows = (int)(rows_left < kTile ? (rows_left > 0 ? rows_left : 0) : kTile);
+            tile_moment_sums<kYawObsWords>(reinterpret_cast<const float*>(tl_lds), reinterpret_cast<double*>(lds + kRsYawXch + tl * 256),
+                                           rows, lane, bsum + tl * kYawRow);
+        }
+        if (o_.store_obs) {
+            Vec4<T>* out = reinterpret_cast<Vec4<T>*>(s.obs + tile * (kTile * kYawObsWords));
+#pragma unroll
+            for (int r = 0; r < kYawObsWords / 4; ++r) {
+                const int f4 = r * kTile + lane;
+                if (f4 / (kYawObsWords / 4) < rows_left) out[f4] = tl_lds[f4];
+            }
+        }
+        lds_barrier();   // B: the four tiles' sums are in LDS
+        if (o_.partials && wave == 4 && lane < kYawRow)
+            o_.partials[(int64_t)blockIdx.x * kYawRow + lane] =
+                (bsum[lane] + bsum[kYawRow + lane]) + (bsum[2 * kYawRow + lane] + bsum[3 * kYawRow + lane]);
+        return;
+    }
+    // ---------------- physics wave: yaw_step_kernel's body
+    Drone<T>& d = tr.d;
+    YawExtra<T>& e = tr.e;
+    const T a = live ? lds[kRsAct + 4 * (tl * kTile + lane)] : T(0);
+    T ret_in = T(0);
+    if (s.ret && live) ret_in = s.ret[i];
+    const uint32_t gid = (uint32_t)(s.id_offset + (uint64_t)i);
+    const T prev_a = e.h3;
+    e.h0 = e.h1; e.h1 = e.h2; e.h2 = e.h3; e.h3 = a;                   // yaw.py:107
+    T pwm[4];
+    control_tick(d, T(0), T(0), a * T(-30), T(0), pwm);                // yaw.py:110-121
+    T ga[4], gb[4];
+    normal8(s.seed, gid, tr.agent_tick, ga, gb);
+    const T inv_mass = rcp_(e.mass), k_lin = T(0.5 * 1.225 * 3.0e-4) * e.cd;
+    physics_substep<T, true>(d, pwm, s.sigma, ga, inv_mass, k_lin, e.kpqr);
+    physics_substep<T, true>(d, pwm, s.sigma, gb, inv_mass, k_lin, e.kpqr);
+    T roll, pitch, yaw;
+    euler_from_quat(d.qx, d.qy, d.qz, d.qw, roll, pitch, yaw);
+    uint32_t bits = 0;
+    if (d.steps >= T(400)) bits |= kInfoTrunc;                          // yaw.py:138
+    if (sqrt_(d.px * d.px + d.py * d.py + d.pz * d.pz) > T(3.0)) bits |= kInfoTerm | kInfoOob;  // yaw.py:141-143
+    d.steps += T(1);                                                    // yaw.py:145
+    const T av0 = clip_(wrap_angle(roll - d.er) * T(4), T(-1), T(1));
+    const T av1 = clip_(wrap_angle(pitch - d.ep) * T(4), T(-1), T(1));
+    const T av2 = clip_(wrap_angle(yaw - d.eyaw) * T(4), T(-1), T(1));
+    T o[kYawObsWords];
+    const bool vis = yaw_observe(d, e, roll, pitch, yaw, av0, av1, av2, o);
+    const T target = vis ? -sqrt_(o[3] * o[3] + o[4] * o[4]) : T(-2);
+    const T reward = T(1) + target - T(0.01) * d.wz * d.wz - T(0.2) * abs_(a - prev_a);
+    d.er = roll; d.ep = pitch; d.eyaw = yaw;
+    d.ep_ret += reward;
+    const bool done = live && bits != 0;
+    const unsigned long long m = __ballot(done);
+    if (m != 0ull) {
+        if (done) {
+            const int64_t row = (int64_t)tr.led_fill + (int64_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (row < s.led_rows) {
+                const int64_t slot = tile * s.led_rows + row;
+                s.led_idx[slot] = (int32_t)i;
+                s.led_info[slot] = bits | ((uint32_t)d.steps << 8);
+                s.led_tag[slot] = (uint32_t)tr.agent_tick;
+                s.led_ret[slot] = d.ep_ret;
+                Vec4<T>* lo = reinterpret_cast<Vec4<T>*>(s.led_obs + slot * kYawObsWords);
+#pragma unroll
+                for (int g = 0; g < kYawObsWords / 4; ++g) lo[g] = Vec4<T>{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+            }
+            yaw_reset(d, e, warm_throttle<T>(), s.seed, gid, tr.agent_tick, s.domain_rand != 0, o);
+        }
+        tr.led_fill += (uint32_t)__popcll(m);
+        if (lane == 0) s.led_count[tile] = tr.led_fill;
+    }
+#pragma unroll
+    for (int g = 0; g < kYawObsWords / 4; ++g)
+        tl_lds[lane * (kYawObsWords / 4) + g] = Vec4<T>{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+    {
+        T ret = T(0);
+        if (s.ret) {
+            ret = live ? ret_in * (T)s.gamma + reward : T(0);
+            if (live) s.ret[i] = done ? T(0) : ret;
+        }
+        reinterpret_cast<T*>(tl_lds)[kTile * kYawObsWords + lane] = ret;
+        if (live && o_.done) o_.done[i] = done ? 1 : 0;
+    }
+    lds_barrier();   // A
+    store_drone<T, kYawGranules>(d, s.state, tile, lane);
+    Vec4<T>* ext = s.state + tile * (kYawGranules * kTile) + lane;
+    ext[9 * kTile] = Vec4<T>{e.h0, e.h1, e.h2, e.h3};
+    ext[10 * kTile] = Vec4<T>{e.mass, e.cd, e.kpqr, e.spare};
+    if (lane == 0) s.tick[tile] = tr.agent_tick + 1ull;
+    if (live) {
+        o_.reward[i] = reward;
+        o_.terminated[i] = (bits & kInfoTerm) ? 1 : 0;
+        o_.truncated[i] = (bits & kInfoTrunc) ? 1 : 0;
+    }
+    lds_barrier();   // B
+}
+
+// ---------------------------------------------------------------- the one-step kernel (TASK 0: hover, 1: yaw)
+template <int TASK>
 __global__ __launch_bounds__(512) void rollout_step_kernel(RollStepArgs p) {
+    constexpr int IN = TASK == 0 ? kIn : kYawObsWords, ACT = TASK == 0 ? kAct : 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 #define RS1_STAMP(k) do { if (p.stamps && threadIdx.x == 0) p.stamps[(int64_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     RS1_STAMP(0);
-    f32x2 xpre[5];
-    rollstep_prologue(p, lds, xpre);
+    f32x2 xpre[IN / 4];
+    rollstep_prologue<IN>(p, lds, xpre);
     RS1_STAMP(1);
     // the drone state is requested here: it is needed only in phase 2, so its latency hides under the matrix work
     TileRegs tr;
-    rs_load_tile(p.st, tr);
+    YawTileRegs ytr;
+    if constexpr (TASK == 0) rs_load_tile(p.st, tr);
+    else rs_load_tile_yaw(p.st, ytr);
     f32x4 cl;
     {
         const int64_t d = (int64_t)blockIdx.x * 256 + (threadIdx.x >> 6) * 32 + (threadIdx.x & 31);
         // the agent tick is this workgroup's own tile's copy (all copies are equal, and tile 0's is advanced by workgroup 0
         // in phase 2 while other workgroups may still be here)
         const PolicyOut out{p.obs_n, p.action, p.clipped, p.value, p.logp};
-        cl = rs_policy_core(lds, xpre, d, d < p.st.n, p.rms != nullptr, p.clip_obs, out, p.st.tick[(int64_t)blockIdx.x * 4],
-                            p.pol_seed, p.pol_id_offset, (int)(threadIdx.x & 63));
+        cl = rs_policy_core<IN, ACT>(lds, xpre, d, d < p.st.n, p.rms != nullptr, p.clip_obs, out,
+                                     p.st.tick[(int64_t)blockIdx.x * 4], p.pol_seed, p.pol_id_offset, (int)(threadIdx.x & 63));
     }
     const int lane = threadIdx.x & (kTile - 1), wave = threadIdx.x >> 6;
     lds_barrier();                                     // every wave is done with the weight image: its space is free
@@ -433,8 +589,12 @@ __global__ __launch_bounds__(512) void rollout_step_kernel(RollStepArgs p) {
     lds_barrier();
     const TailOut to{p.st.reward, p.st.terminated, p.st.truncated, p.st.done, p.st.partials, true, false,
                      p.stamps ? p.stamps + (int64_t)blockIdx.x * 8 + 4 : nullptr};
-    rs_tail(p.st, lds, tr, to);
-    rs_store_tile(p.st, tr);
+    if constexpr (TASK == 0) {
+        rs_tail(p.st, lds, tr, to);
+        rs_store_tile(p.st, tr);
+    } else {
+        rs_tail_yaw(p.st, lds, ytr, to);
+    }
     RS1_STAMP(3);
 #undef RS1_STAMP
 }
@@ -632,7 +792,7 @@ __global__ __launch_bounds__(512) void rollout_persistent_kernel(RollPersistArgs
         // registers) out of the step loop
         int lane_o = lane, zero = 0;
         asm volatile("" : "+v"(lane_o), "+s"(zero));
-        const f32x4 cl = rs_policy_core(lds + zero, xraw, d, true, normalise, p.clip_obs, out, pol_tick0 + (uint64_t)t, p.pol_seed,
+        const f32x4 cl = rs_policy_core<kIn, kAct>(lds + zero, xraw, d, true, normalise, p.clip_obs, out, pol_tick0 + (uint64_t)t, p.pol_seed,
                                         p.pol_id_offset, lane_o);
         rs_load_state(s, tr);
         lds_barrier();                               // every wave is done with the weight image's head: phase-2 space is free
@@ -714,16 +874,19 @@ uint64_t* g_rollout_stamps = nullptr;
 // Preconditions (checked by fpv_rollout_step): fp32 hover handle with motor noise, n a multiple of 256, policy widths 20 / 4.
 hipError_t launch_rollout_step(const float* image, const double* rms, float* obs_n, float* action, float* clipped, float* value,
                                float* logp, uint64_t pol_seed, uint64_t pol_id_offset, float clip_obs, float eps_norm,
-                               const MergeArgs& merge, const StepArgs<float>& st, hipStream_t s) {
+                               const MergeArgs& merge, const StepArgs<float>& st, int yaw, hipStream_t s) {
     static bool attr_set = false;
     const int full = (int)((2 * kNetFloats + (kImageFloats - kHeadBase) + 40) * sizeof(float)) + kMergeLdsBytes;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)rollout_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, full);
+        hipError_t e = hipFuncSetAttribute((const void*)rollout_step_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, full);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)rollout_step_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, full);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     RollStepArgs p{image, rms, obs_n, action, clipped, value, logp, pol_seed, pol_id_offset, clip_obs, eps_norm, merge, st, g_rollout_stamps};
-    hipLaunchKernelGGL(rollout_step_kernel, dim3((unsigned)(st.n / 256)), dim3(512), (size_t)full, s, p);
+    if (yaw) hipLaunchKernelGGL(rollout_step_kernel<1>, dim3((unsigned)(st.n / 256)), dim3(512), (size_t)full, s, p);
+    else hipLaunchKernelGGL(rollout_step_kernel<0>, dim3((unsigned)(st.n / 256)), dim3(512), (size_t)full, s, p);
     return hipGetLastError();
 }
 

@@ -103,8 +103,8 @@ class FusedPolicy:
             value = torch.empty((n,), dtype=torch.float32, device=engine.device)
         reward = engine.reward if reward is None else reward
         if partials is not None and (partials.dtype != torch.float64 or not partials.is_contiguous()
-                                     or partials.shape[0] < n // 256 or partials.shape[1] != 44):
-            raise ValueError("partials must be a contiguous float64 [>= num_envs / 256, 44] device tensor")
+                                     or partials.shape[0] < n // 256 or partials.shape[1] != 2 * self.obs_dim + 4):
+            raise ValueError(f"partials must be a contiguous float64 [>= num_envs / 256, {2 * self.obs_dim + 4}] device tensor")
         io = L.FpvPolicyIo(n, _ptr(engine.obs), _ptr(rms), None, None, _ptr(obs_n), _ptr(action), _ptr(clipped),
                            _ptr(value), _ptr(logp), None, self.seed, self.id_offset, float(clip_obs), float(eps_norm), 0, 3, 0, 0)
         if merge is not None:

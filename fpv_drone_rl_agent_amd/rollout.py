@@ -123,15 +123,15 @@ class RolloutCollector:
             self._obs_rms_alt = torch.zeros_like(self.obs_norm.rms)
             self._ret_rms_alt = torch.zeros_like(self.rew_norm.rms)
             # one_launch: policy forward and env step of a rollout step as ONE kernel (fpv_rollout_step, fpv_rollstep.hip) —
-            # bit-identical results.  Served for the hover task with motor noise, drone counts that are multiples of 256 up
+            # bit-identical results.  Served for both tasks with motor noise, drone counts that are multiples of 256 up
             # to 256 x 1 024, the exact-fp32 policy, and the statistics merge in the launch prologue (or no normalisation).
             norm = self.norm_obs or self.norm_reward
-            can = (engine.task == "hover" and engine.noise_ratio > 0.0 and N % 256 == 0 and N // 256 <= 1024
+            can = (engine.noise_ratio > 0.0 and N % 256 == 0 and N // 256 <= 1024
                    and policy_gemm == "f32" and not self.overlap_critic and not self._merge_in_step
                    and (self._merge_in_policy or not norm))
             if one_launch and not can:
-                raise ValueError("one_launch needs the hover task with motor noise, num_envs a multiple of 256 (<= 262 144), "
-                                 "policy_gemm='f32' and the default statistics-merge placement")
+                raise ValueError("one_launch needs motor noise, num_envs a multiple of 256 (<= 262 144), policy_gemm='f32' and the "
+                                 "default statistics-merge placement")
             # Default: where every workgroup finds a CU of its own (num_envs <= 256 x CUs).  Beyond that the second round of
             # workgroups stages the weight image again, while the two-kernel shape's policy kernel keeps it in LDS across its
             # chunks: measured 128.2 vs 126.3 us per step at 131 072 drones, 257.2 vs 234.9 at 262 144.
@@ -140,7 +140,7 @@ class RolloutCollector:
             # persistent: the WHOLE rollout of n_steps as one launch (fpv_rollout_steps): weights stay in LDS, drone state in
             # registers, a grid-wide barrier + statistics merge between steps.  Same bits again.  Needs every workgroup resident:
             # at most one per CU, i.e. num_envs <= 256 x CUs.
-            can_p = can and N // 256 <= cus
+            can_p = can and N // 256 <= cus and engine.task == "hover"
             if persistent and not can_p:
                 raise ValueError("persistent needs what one_launch needs and num_envs <= 256 x the device's CU count")
             self._persistent = self._persistent_ok = False if persistent is None else bool(persistent)

@@ -132,7 +132,8 @@ def test_unserved_requests_are_refused():
     from fpv_drone_rl_agent_amd.engine import FpvEngine
     from fpv_drone_rl_agent_amd.ops_policy import FusedPolicy
     fp = FusedPolicy(_policy())
-    for eng in (FpvEngine(1000, 0), FpvEngine(1024, 0, noise_ratio=0.0), FpvEngine(1024, 0, precision="f64")):
+    for eng in (FpvEngine(1000, 0), FpvEngine(1024, 0, noise_ratio=0.0), FpvEngine(1024, 0, precision="f64"),
+                FpvEngine(1024, 0, task="yaw")):       # (a 20 -> 4 policy on the yaw task's 12-word observations)
         with pytest.raises(RuntimeError, match="fpv_rollout_step"):
             fp.rollout_step(eng)
         eng.close()
@@ -236,3 +237,92 @@ def test_persistent_rollout_gives_up_cleanly_when_a_grid_wait_times_out(oracle):
     col.collect()
     col.collect()
     assert col.episodes["count"] >= 0            # status words clean
+
+
+def test_yaw_task_one_launch_equals_policy_then_step():
+    """The yaw task (12-word observations, one action, domain-randomised airframes, in-kernel Philox reset) through
+    fpv_rollout_step against fpv_policy_forward + fpv_step_fused: everything bit for bit over 60 steps with episode ends."""
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.ops_policy import FusedPolicy
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    n, O = 65536, 12
+    torch.manual_seed(3)
+    pol = ActorCritic(obs_dim=12, act_dim=1).cuda()
+    with torch.no_grad():
+        pol.log_std.fill_(-0.2)
+    fp = FusedPolicy(pol, seed=17)
+    engs = [FpvEngine(n, 0, seed=8, task="yaw", domain_rand=True, ledger_capacity=4 * n) for _ in range(2)]
+    g = torch.Generator(device="cuda").manual_seed(2)
+    steps0 = torch.randint(0, 401, (n,), device="cuda", generator=g).float()
+    bufs = []
+    for e in engs:
+        e.reset()
+        st = e.get_state()
+        st[:, 34] = steps0                     # staggered step counts: truncations (yaw.py:138) from the first steps on
+        e.set_state(st)
+        bufs.append({k: torch.zeros(sh, dtype=dt, device="cuda") for k, sh, dt in (
+            ("obs_n", (n, O), torch.float32), ("act", (n, 1), torch.float32), ("clipped", (n, 1), torch.float32),
+            ("val", (n,), torch.float32), ("logp", (n,), torch.float32), ("done", (n,), torch.uint8),
+            ("ret", (n,), torch.float32), ("raw", (n,), torch.float32))})
+    assert torch.equal(engs[0].obs, engs[1].obs)
+    rows = n // 256
+    assert engs[1].partial_rows == rows
+    part_a = torch.zeros((2, rows, 2 * O + 4), dtype=torch.float64, device="cuda")
+    part_b = torch.zeros((rows, 2 * O + 4), dtype=torch.float64, device="cuda")
+    rms = [[torch.cat([torch.zeros(O), torch.ones(O), torch.tensor([1e-4])]).double().cuda() for _ in range(2)] for _ in range(2)]
+    ret_rms = [[torch.tensor([0.0, 1.0, 1e-4], dtype=torch.float64, device="cuda") for _ in range(2)] for _ in range(2)]
+    snap = [torch.zeros((64, 44), dtype=torch.float64, device="cuda") for _ in range(2)]
+    dones = 0
+    for t in range(60):
+        a, b = bufs
+        k_in, k_out = (t - 1) % 2, t % 2
+        mg = [None, None]
+        if t > 0:
+            mg[0] = {"partials": part_a[(t - 1) % 2], "count": n, "rms_out": rms[0][k_out], "ret_rms": ret_rms[0][k_in],
+                     "ret_rms_out": ret_rms[0][k_out], "snapshot": snap[0][t - 1]}
+            mg[1] = {"partials": part_b, "count": n, "rms_out": rms[1][k_out], "ret_rms": ret_rms[1][k_in],
+                     "ret_rms_out": ret_rms[1][k_out], "snapshot": snap[1][t - 1]}
+        fp.rollout_step(engs[0], rms=rms[0][k_in if t else 0], obs_n=a["obs_n"], action=a["act"], clipped=a["clipped"],
+                        value=a["val"], logp=a["logp"], merge=mg[0], done=a["done"], ret=a["ret"], partials=part_a[t % 2],
+                        gamma=0.99, reward=a["raw"])
+        fp.forward(engs[1].obs, rms=rms[1][k_in if t else 0], tick=engs[1].tick_ptr, obs_n=b["obs_n"], action=b["act"],
+                   clipped=b["clipped"], value=b["val"], logp=b["logp"], merge=mg[1])
+        engs[1].step_fused(b["clipped"], done=b["done"], ret=b["ret"], partials=part_b, gamma=0.99, reward=b["raw"])
+        for k in a:
+            assert torch.equal(a[k], b[k]), (t, k)
+        assert torch.equal(engs[0].obs, engs[1].obs), t
+        assert torch.equal(engs[0].terminated, engs[1].terminated) and torch.equal(engs[0].truncated, engs[1].truncated)
+        assert torch.equal(engs[0].get_state(), engs[1].get_state()), t
+        assert torch.equal(part_a[t % 2], part_b), t
+        if t > 0:
+            assert torch.equal(rms[0][k_out], rms[1][k_out]) and torch.equal(ret_rms[0][k_out], ret_rms[1][k_out])
+        dones += int(a["done"].sum())
+    assert dones > n // 20
+    la, lb = engs[0].ledger_read(), engs[1].ledger_read()
+    assert la["count"] == lb["count"] == dones
+    for k in ("idx", "info", "tag", "ep_return", "obs"):
+        assert np.array_equal(la[k], lb[k]), k
+    for e in engs:
+        e.close()
+
+
+def test_yaw_collector_takes_the_one_launch_path():
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    from fpv_drone_rl_agent_amd.rollout import RolloutCollector
+    cols = []
+    for one in (None, False):
+        torch.manual_seed(0)
+        eng = FpvEngine(4096, 0, seed=1, task="yaw", domain_rand=True)
+        cols.append(RolloutCollector(eng, ActorCritic(obs_dim=12, act_dim=1).cuda(), n_steps=6, one_launch=one, use_graph=False))
+    assert cols[0]._one_launch and not cols[1]._one_launch
+    from fpv_drone_rl_agent_amd import _lib as L
+    L.load().fpv_set_pair_threshold(0)
+    try:
+        for r in range(2):
+            ba, bb = cols[0].collect(), cols[1].collect()
+            for k in ("obs", "actions", "values", "log_probs", "advantages", "returns"):
+                assert torch.equal(ba[k], bb[k]), (r, k)
+            assert torch.equal(cols[0].obs_norm.rms, cols[1].obs_norm.rms)
+    finally:
+        L.load().fpv_set_pair_threshold(32768)
