@@ -17,8 +17,9 @@
 // step_kernel<.., 4>.  The statistics rows of step t are read by every workgroup of launch t + 1 while launch t + 1
 // writes its own rows: the caller alternates between two row tables.
 //
-// Reference path replaced: QuadXHoverEnv.step()/reset() simulation/hover.py:72-114,334-358 under SB3's VecEnv auto-reset,
-// together with MlpPolicy.forward + VecNormalize of simulation/train_hover.py:43-58.
+// Reference path replaced: QuadXHoverEnv.step()/reset() simulation/hover.py:72-114,334-358 (rollout_step_kernel<0>) and the yaw
+// task's step simulation/yaw.py:76-149 (rollout_step_kernel<1>) under SB3's VecEnv auto-reset, together with MlpPolicy.forward +
+// VecNormalize of simulation/train_hover.py:43-58.
 #include "fpv_mlp.h"
 #include "fpv_policy_image.h"
 #include "fpv_step_parts.h"
@@ -871,7 +872,7 @@ __global__ __launch_bounds__(512) void rollout_persistent_kernel(RollPersistArgs
 // ---------------------------------------------------------------- launchers
 uint64_t* g_rollout_stamps = nullptr;
 
-// Preconditions (checked by fpv_rollout_step): fp32 hover handle with motor noise, n a multiple of 256, policy widths 20 / 4.
+// Preconditions (checked by fpv_rollout_step): fp32 handle with motor noise, n a multiple of 256, the task's policy widths.
 hipError_t launch_rollout_step(const float* image, const double* rms, float* obs_n, float* action, float* clipped, float* value,
                                float* logp, uint64_t pol_seed, uint64_t pol_id_offset, float clip_obs, float eps_norm,
                                const MergeArgs& merge, const StepArgs<float>& st, int yaw, hipStream_t s) {
