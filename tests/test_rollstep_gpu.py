@@ -326,3 +326,18 @@ def test_yaw_collector_takes_the_one_launch_path():
             assert torch.equal(cols[0].obs_norm.rms, cols[1].obs_norm.rms)
     finally:
         L.load().fpv_set_pair_threshold(32768)
+
+
+def test_rollout_begin_clears_the_ledger_and_carries_the_episode_starts():
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    for n in (4096, 65536, 1008):
+        eng = FpvEngine(n, 0, seed=1)
+        eng.led_count.fill_(7)
+        src = (torch.rand(n, device="cuda") < 0.3).to(torch.uint8)
+        dst = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
+        eng.rollout_begin(dst, src)
+        assert torch.equal(dst, src) and int(eng.led_count.abs().sum()) == 0
+        eng.led_count.fill_(3)
+        eng.rollout_begin()
+        assert int(eng.led_count.abs().sum()) == 0 and torch.equal(dst, src)
+        eng.close()
