@@ -40,6 +40,9 @@ ALG_BYTES_PER_STEP = 382  # 35 words r+w, 16 B action, 80 B ob
 HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA (= vector fp32) peak
 POLICY_FLOP_PER_ROW = 2 * (2 * (20 * 128 + 128 * 128) + 128 * 4 + 128)  # 77 056: both MLPs + heads
+# fp32 operations of one hover env step per drone, counted (profiles/r02_step_instruction_mix.json, per 64-drone wave: 529 add +
+# 692 mul + 831 fma (x 2) + 120 transcendental); SURVEY.md §8(d) had estimated 5.2 k
+ENV_FLOP_PER_STEP = 529 + 692 + 2 * 831 + 120  # 3 003
 
 
 def synthetic_states(n: int, seed: int):
@@ -358,11 +361,16 @@ def main() -> None:
                 if us_one > cadence:
                     us_one, how = cadence, how + ", capped at the timed region's own time per step"
                 phases = kernel_phases() if world == 1 else None      # (extra captures + collects: kept off the multi-rank runs)
-                tf = POLICY_FLOP_PER_ROW * n / us_one / 1e6
+                # the kernel's algorithmic work: the policy's matrix flops AND the env step's vector flops — fp32 both, and the
+                # fp32-input MFMA peak is the vector fp32 peak (MI355X_MICROARCH.md), so one roofline prices both
+                flop = (POLICY_FLOP_PER_ROW + ENV_FLOP_PER_STEP) * n
+                tf = flop / us_one / 1e6
                 roofline = {"bound": "mfma", "kernel": "fpv::rollout_step_kernel", "achieved": round(tf, 1),
                             "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
                             "traffic": traffic_of("fpv::rollout_step_kernel"), "us_per_launch": round(us_one, 2),
-                            "launches": L, "algorithmic_flop_per_launch": POLICY_FLOP_PER_ROW * n, "dtype": "f32",
+                            "launches": L, "algorithmic_flop_per_launch": flop,
+                            "algorithmic_flop_per_drone": {"policy (MFMA)": POLICY_FLOP_PER_ROW, "env step (VALU, counted)": ENV_FLOP_PER_STEP},
+                            "frac_policy_flops_only": round(POLICY_FLOP_PER_ROW * n / us_one / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "dtype": "f32",
                             "measured": how, "us_per_launch_hip_events_back_to_back": round(ev_one, 2),
                             "us_per_launch_traced": round(us_traced, 2), "us_per_step_timed_region": round(cadence, 2)}
                 roofline["note"] = ("one kernel per rollout step: actor-critic forward (the matrix work priced here) AND the env step of "
