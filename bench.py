@@ -335,12 +335,15 @@ def main() -> None:
                     return float(sum(v) / len(v)) if v else None
             return None
 
-        if yaw:
+        if yaw and not (col.fused and col._one_launch):
             us = timed(lambda: eng.step(act))
             roofline = hbm("fpv::yaw_step_kernel<float,true>", us, 458)   # 44 words r+w, 4 B action, 48 B obs, 4 B reward, 2 B flags
         else:
             us_plain = timed(lambda: eng.step(act))
-            roofline_env_plain = hbm("fpv::step_kernel<float,true,false>", us_plain, ALG_BYTES_PER_STEP)
+            env_bytes = 458 if yaw else ALG_BYTES_PER_STEP
+            roofline_env_plain = hbm("fpv::yaw_step_kernel<float,true>" if yaw else "fpv::step_kernel<float,true,false>", us_plain, env_bytes)
+            pol_flop = 2 * (2 * (12 * 128 + 128 * 128) + 128 * 1 + 128) if yaw else POLICY_FLOP_PER_ROW
+            env_flop = 0 if yaw else ENV_FLOP_PER_STEP      # (the yaw env step's operations have not been counted: left out)
             if col.fused and col._one_launch:
                 # ---- the rollout-step kernel (policy + env step in one launch)
                 ev_fused = timed(lambda: eng.step_fused(col.clipped, done=col._starts[1], ret=col.rew_norm.ret,
@@ -363,14 +366,14 @@ def main() -> None:
                 phases = kernel_phases() if world == 1 else None      # (extra captures + collects: kept off the multi-rank runs)
                 # the kernel's algorithmic work: the policy's matrix flops AND the env step's vector flops — fp32 both, and the
                 # fp32-input MFMA peak is the vector fp32 peak (MI355X_MICROARCH.md), so one roofline prices both
-                flop = (POLICY_FLOP_PER_ROW + ENV_FLOP_PER_STEP) * n
+                flop = (pol_flop + env_flop) * n
                 tf = flop / us_one / 1e6
-                roofline = {"bound": "mfma", "kernel": "fpv::rollout_step_kernel", "achieved": round(tf, 1),
+                roofline = {"bound": "mfma", "kernel": "fpv::rollout_step_kernel<%d>" % (1 if yaw else 0), "achieved": round(tf, 1),
                             "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
-                            "traffic": traffic_of("fpv::rollout_step_kernel"), "us_per_launch": round(us_one, 2),
+                            "traffic": None if yaw else traffic_of("fpv::rollout_step_kernel"), "us_per_launch": round(us_one, 2),
                             "launches": L, "algorithmic_flop_per_launch": flop,
-                            "algorithmic_flop_per_drone": {"policy (MFMA)": POLICY_FLOP_PER_ROW, "env step (VALU, counted)": ENV_FLOP_PER_STEP},
-                            "frac_policy_flops_only": round(POLICY_FLOP_PER_ROW * n / us_one / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "dtype": "f32",
+                            "algorithmic_flop_per_drone": {"policy (MFMA)": pol_flop, "env step (VALU, counted)": env_flop or None},
+                            "frac_policy_flops_only": round(pol_flop * n / us_one / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "dtype": "f32",
                             "measured": how, "us_per_launch_hip_events_back_to_back": round(ev_one, 2),
                             "us_per_launch_traced": round(us_traced, 2), "us_per_step_timed_region": round(cadence, 2)}
                 roofline["note"] = ("one kernel per rollout step: actor-critic forward (the matrix work priced here) AND the env step of "
@@ -383,13 +386,13 @@ def main() -> None:
                     roofline["phases_us"] = phases
                     pol = phases.get("policy (normalise, pi, V, sample)")
                     if pol:
-                        roofline["frac_of_peak_within_policy_phase"] = round(POLICY_FLOP_PER_ROW * n / pol / 1e6 / MFMA_F32_PEAK_TFLOPS, 4)
+                        roofline["frac_of_peak_within_policy_phase"] = round(pol_flop * n / pol / 1e6 / MFMA_F32_PEAK_TFLOPS, 4)
                     envp = phases.get("env step + bookkeeping")
                     if envp:
-                        roofline_env = hbm("env-step phase of fpv::rollout_step_kernel", envp, ALG_BYTES_PER_STEP)
+                        roofline_env = hbm("env-step phase of fpv::rollout_step_kernel", envp, env_bytes)
                         roofline_env.update(traffic=None, measured="in-kernel s_memrealtime stamps, median over workgroups "
                                             "(the drone state is requested under the matrix work; this is the exposed part)")
-                roofline_env_fused = hbm("fpv::step_kernel<float,true,true>", ev_fused, ALG_BYTES_PER_STEP)
+                roofline_env_fused = hbm("fpv::yaw_step_kernel<float,true,true>" if yaw else "fpv::step_kernel<float,true,true>", ev_fused, env_bytes)
                 roofline_env_fused.update(measured="HIP events around back-to-back launches (the stand-alone fpv_step_fused kernel; "
                                                    "not launched by the default rollout)")
             elif col.fused:
