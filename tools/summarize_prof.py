@@ -4,13 +4,14 @@ import collections
 import csv
 import glob
 import json
+import os
 import shutil
 import sys
 
 
 def main():
     tag, stats_dir = sys.argv[1], sys.argv[2]
-    src = glob.glob(f"{stats_dir}/**/*kernel_stats.csv", recursive=True)[0]
+    src = max(glob.glob(f"{stats_dir}/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)   # the newest run in the directory
     shutil.copy(src, f"profiles/{tag}_kernel_stats.csv")
     out = {"tag": tag, "kernel_stats_csv": f"profiles/{tag}_kernel_stats.csv"}
     rows = list(csv.DictReader(open(src)))
@@ -19,7 +20,7 @@ def main():
     if len(sys.argv) >= 5:
         pmc = {}
         for name, d in (("FETCH_SIZE", sys.argv[3]), ("WRITE_SIZE", sys.argv[4])):
-            f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0]
+            f = max(glob.glob(f"{d}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
             acc = collections.defaultdict(list)
             for r in csv.DictReader(open(f)):
                 if r["Counter_Name"] == name:
