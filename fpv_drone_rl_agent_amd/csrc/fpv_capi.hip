@@ -69,7 +69,10 @@ static int scratch_for_current_device(double** out) {
     FPV_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return fail(FPV_ERR_ARG, "device ordinal %d out of range", dev);
     std::lock_guard<std::mutex> lk(g_scratch_mu);
-    if (!g_scratch[dev]) FPV_HIP(hipMalloc(&g_scratch[dev], sizeof(double) * kScratchDoubles));
+    if (!g_scratch[dev]) {
+        FPV_HIP(hipMalloc(&g_scratch[dev], sizeof(double) * kScratchDoubles));
+        FPV_HIP(hipMemset(g_scratch[dev], 0, sizeof(double) * kScratchDoubles));   // holds the tickets of in-launch reductions
+    }
     *out = g_scratch[dev];
     return FPV_OK;
 }

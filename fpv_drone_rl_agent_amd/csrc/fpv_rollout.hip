@@ -40,8 +40,9 @@ __global__ __launch_bounds__(kRedBlock) void gae_kernel(int64_t T, int64_t n, co
                                                         const float* __restrict__ last_values,
                                                         const uint8_t* __restrict__ last_dones, float gamma, float lam,
                                                         float* __restrict__ adv, float* __restrict__ returns,
-                                                        double* __restrict__ partial) {
-    __shared__ double lds[2 * (kRedBlock / 64)];
+                                                        double* __restrict__ partial, double* __restrict__ stats, double count,
+                                                        uint32_t* __restrict__ ticket) {
+    __shared__ double lds[2 * (kRedBlock / 64) + 130];
     double s1 = 0.0, s2 = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float next_v = last_values[i];
@@ -86,23 +87,36 @@ __global__ __launch_bounds__(kRedBlock) void gae_kernel(int64_t T, int64_t n, co
         }
     }
     if (partial) {
+        // The block sums leave write-through, the block takes a ticket, and the block that draws the last one adds all of them
+        // in a fixed order — 64 strided sums, then those in turn: the same bits whichever block it is — so the reduction needs no
+        // launch of its own.
         block_sum2(s1, s2, lds);
-        if (threadIdx.x == 0) { partial[2 * blockIdx.x] = s1; partial[2 * blockIdx.x + 1] = s2; }
+        int* flag = reinterpret_cast<int*>(lds + 2 * (kRedBlock / 64));
+        if (threadIdx.x == 0) {
+            row_store_sc1(partial + 2 * blockIdx.x, s1);
+            row_store_sc1(partial + 2 * blockIdx.x + 1, s2);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = t == gridDim.x - 1u;
+        }
+        __syncthreads();
+        if (*flag == 0) return;                          // uniform
+        double* l1 = lds + 2 * (kRedBlock / 64) + 1, *l2 = l1 + 64;   // (word 0 of this area is the flag)
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            double a1 = 0.0, a2 = 0.0;
+            for (int b = threadIdx.x; b < (int)gridDim.x; b += 64) { a1 += row_load_sc1(partial + 2 * b); a2 += row_load_sc1(partial + 2 * b + 1); }
+            l1[threadIdx.x] = a1;
+            l2[threadIdx.x] = a2;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double a1 = 0.0, a2 = 0.0;
+            for (int w = 0; w < 64; ++w) { a1 += l1[w]; a2 += l2[w]; }
+            stats[0] = count; stats[1] = a1; stats[2] = a2;
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // for the next launch
+        }
     }
-}
-
-__global__ __launch_bounds__(64) void gae_stats_kernel(const double* __restrict__ partial, int blocks, double count,
-                                                       double* stats) {
-    __shared__ double l1[64], l2[64];
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = threadIdx.x; b < blocks; b += 64) { s1 += partial[2 * b]; s2 += partial[2 * b + 1]; }
-    l1[threadIdx.x] = s1;
-    l2[threadIdx.x] = s2;
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    s1 = 0.0; s2 = 0.0;
-    for (int w = 0; w < 64; ++w) { s1 += l1[w]; s2 += l2[w]; }
-    stats[0] = count; stats[1] = s1; stats[2] = s2;
 }
 
 // {count, sum A, sum A^2} per rank, added in rank order -> {mean, std} (population std, as SB3 normalises advantages)
@@ -127,11 +141,12 @@ hipError_t launch_gae(int64_t T, int64_t n, const float* rewards, const float* v
                       float* returns, double* stats, double* scratch, hipStream_t s) {
     int64_t blocks = (n + kRedBlock - 1) / kRedBlock;
     if (blocks > kMaxRedBlocks * 2) blocks = kMaxRedBlocks * 2;
+    // the ticket of the in-launch reduction: the last word of the device's reduction scratch (zeroed at allocation, reset by
+    // the block that finishes the reduction)
+    uint32_t* ticket = reinterpret_cast<uint32_t*>(scratch + kScratchDoubles - 1);
     hipLaunchKernelGGL(gae_kernel, dim3((unsigned)blocks), dim3(kRedBlock), 0, s, T, n, rewards, values,
-                       episode_starts, last_values, last_dones, gamma, lam, adv, returns, stats ? scratch : nullptr);
-    if (stats)
-        hipLaunchKernelGGL(gae_stats_kernel, dim3(1), dim3(64), 0, s, scratch, (int)blocks, (double)T * (double)n,
-                           stats);
+                       episode_starts, last_values, last_dones, gamma, lam, adv, returns, stats ? scratch : nullptr, stats,
+                       (double)T * (double)n, ticket);
     return hipGetLastError();
 }
 
