@@ -51,7 +51,7 @@ def synthetic_states(n: int, seed: int):
     return gen(n, seed=seed).astype("float32")
 
 
-def cpu_baseline(n: int, seed: int, budget_s: float = 9.0):
+def cpu_baseline(n: int, seed: int, budget_s: float = 9.0, detector: str = "pixel"):
     """The C oracle (kind "port") on this box's host cores: OpenMP over drones on ALL cores, and one thread.
     Bounded samples (~budget_s of wall time each on the all-cores leg, a 4 096-drone slice for the single thread)."""
     import numpy as np
@@ -73,7 +73,7 @@ def cpu_baseline(n: int, seed: int, budget_s: float = 9.0):
     def sample(m, threads, budget):
         st = orc.synthetic_states(m, seed=seed)
         act = np.random.Generator(np.random.Philox(seed + 1)).uniform(-1, 1, (m, 4))
-        cfg = orc.make_cfg(noise_ratio=0.02, seed=seed)
+        cfg = orc.make_cfg(noise_ratio=0.02, seed=seed, detector=detector)
         orc.step_batch(cfg, st, act, 0, nthreads=threads)       # warms the thread pool
         steps, t0 = 0, time.perf_counter()
         while True:
@@ -91,7 +91,7 @@ def cpu_baseline(n: int, seed: int, budget_s: float = 9.0):
     v_all, k_all, t_all = sample(n, cores, budget_s)
     v_one, k_one, t_one = sample(4096, 1, budget_s)
     return {"value": v_all, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/fpv_oracle.c env-step only (no policy), {n} drones x {k_all} steps, OpenMP {cores} threads "
+            "sample": f"oracle/fpv_oracle.c env-step only (no policy, detector={detector}), {n} drones x {k_all} steps, OpenMP {cores} threads "
                       f"(host reports {host} cores, {usable} usable; thread counts probed {probe}), {t_all:.1f} s",
             "single_thread": {"value": v_one, "unit": "env-steps/s", "cores": 1,
                               "sample": f"4096 drones x {k_one} steps, 1 thread, {t_one:.1f} s"}}
@@ -154,8 +154,9 @@ def main() -> None:
                     help="the K-step timed region is run this many times and the median is reported; default: 5, or as many as "
                          "it takes to time about 1 024 steps in all when K is small (a 20-step region is 1.4 ms: the first few "
                          "run on a chip that is still raising its clock)")
-    ap.add_argument("--detector", choices=["analytic", "pixel"], default="analytic",
-                    help="hover task camera features: continuous projection (SPEC §6) or the reference's 128x128 pixel rules (§6b)")
+    ap.add_argument("--detector", choices=["analytic", "pixel"], default="pixel",
+                    help="hover task camera features: the reference's 128x128 pixel rules (SPEC §6b, hover.py:157-222; the default and "
+                         "the headline) or the continuous projection (§6)")
     ap.add_argument("--two-launch", action="store_true",
                     help="policy forward and env step as two kernels per rollout step (the default is fpv_rollout_step: one)")
     args = ap.parse_args()
@@ -309,7 +310,7 @@ def main() -> None:
                 from fpv_drone_rl_agent_amd import _lib as LIB
                 import numpy as np
                 grid = n // 256
-                stamps = torch.zeros((grid, 8), dtype=torch.int64, device=dev)
+                stamps = torch.zeros((grid, 16), dtype=torch.int64, device=dev)
                 LIB.load().fpv_debug_rollout_stamps(C.c_void_p(stamps.data_ptr()))
                 col._graph = None                     # the stamp pointer is a kernel argument: capture again
                 col.collect()
@@ -473,7 +474,7 @@ def main() -> None:
             out["extra"]["value_f64_env_note"] = ("env-steps/s of fpv_step on an FPV_F64 handle (env step only, no policy, HIP events over "
                                                   f"{args.kernel_launches} launches): the reference's arithmetic type")
         if world == 1 and not args.no_cpu_baseline and not yaw:
-            out["cpu_baseline"] = cpu_baseline(n, seed=0)
+            out["cpu_baseline"] = cpu_baseline(n, seed=0, detector=args.detector)
         print(json.dumps(out), flush=True)
     barrier()
     eng.close()

@@ -12,7 +12,8 @@ from .build import LIB_PATH, build_extension
 
 FPV_F32, FPV_F64 = 0, 1
 TASK_HOVER, TASK_YAW = 0, 1
-DETECTOR_ANALYTIC, DETECTOR_PIXEL = 0, 1
+DETECTOR_PIXEL, DETECTOR_ANALYTIC = 0, 1   # fpv_detector: the reference's pixel rules are the default
+ABI_VERSION = 2                              # FPV_ABI_VERSION of include/fpv_env.h this binding was written against
 STATE_WORDS, OBS_WORDS, ACT_WORDS = 36, 20, 4
 INFO_TERMINATED, INFO_TRUNCATED, INFO_OUT_OF_BOUNDS, INFO_ON_FLOOR = 1, 2, 4, 8
 
@@ -139,6 +140,10 @@ def load(build_if_missing: bool = True):
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI and the header drift apart
         fn.restype, fn.argtypes = res, args
+    built = lib.fpv_version()
+    if built != ABI_VERSION:         # struct layouts / enum values differ between versions: refuse before the first real call
+        raise RuntimeError(f"{LIB_PATH} was built for FPV_ABI_VERSION {built}, this binding is version {ABI_VERSION}: "
+                           "rebuild it (fpv_drone_rl_agent_amd.build.build_extension(force=True))")
     _lib = lib
     return lib
 

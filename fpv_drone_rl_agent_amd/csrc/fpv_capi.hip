@@ -100,7 +100,7 @@ static int step_impl(fpv_env* e, const T* actions, T* obs, T* reward, uint8_t* t
     a.sigma = (T)e->cfg.noise_ratio;
     a.floor_check = e->cfg.floor_check;
     a.domain_rand = e->cfg.domain_rand;
-    a.detector = e->cfg.detector;
+    a.detector = e->cfg.detector == FPV_DETECTOR_PIXEL ? 1 : 0;   // kernel-side switch: non-zero = pixel rules
     a.done = ex ? ex->done : nullptr;
     a.ret = ex ? ex->ret : nullptr;
     a.partials = ex ? ex->partials : nullptr;
@@ -154,7 +154,7 @@ int fpv_noop(void* stream) {
 }
 
 const char* fpv_last_error(void) { return g_err; }
-int fpv_version(void) { return 1; }
+int fpv_version(void) { return FPV_ABI_VERSION; }
 
 int fpv_create(const fpv_config* cfg, fpv_env** out) {
     if (!cfg || !out) return fail(FPV_ERR_ARG, "fpv_create: null argument");
@@ -213,8 +213,8 @@ int fpv_create(const fpv_config* cfg, fpv_env** out) {
                       : launch_yaw_reset<float>(e->state, e->tick, nullptr, nullptr, cfg->num_envs, cfg->seed, cfg->id_offset,
                                                 cfg->domain_rand, 1, nullptr);
         else
-            err = cfg->precision == FPV_F64 ? launch_init<double>(e->state, e->tmpl, cfg->num_envs, cfg->detector, nullptr)
-                                            : launch_init<float>(e->state, e->tmpl, cfg->num_envs, cfg->detector, nullptr);
+            err = cfg->precision == FPV_F64 ? launch_init<double>(e->state, e->tmpl, cfg->num_envs, cfg->detector == FPV_DETECTOR_PIXEL, nullptr)
+                                            : launch_init<float>(e->state, e->tmpl, cfg->num_envs, cfg->detector == FPV_DETECTOR_PIXEL, nullptr);
     }
     if (err == hipSuccess) err = hipDeviceSynchronize();
     if (err != hipSuccess) {
@@ -622,7 +622,7 @@ int fpv_rollout_step(fpv_env* e, fpv_policy* p, const fpv_policy_io* io, float* 
     a.sigma = (float)e->cfg.noise_ratio;
     a.floor_check = e->cfg.floor_check;
     a.domain_rand = e->cfg.domain_rand;
-    a.detector = e->cfg.detector;
+    a.detector = e->cfg.detector == FPV_DETECTOR_PIXEL ? 1 : 0;   // kernel-side switch: non-zero = pixel rules
     a.done = ex ? ex->done : nullptr;
     a.ret = ex ? ex->ret : nullptr;
     a.partials = ex ? ex->partials : nullptr;
@@ -640,6 +640,9 @@ int fpv_rollout_steps(fpv_env* e, fpv_policy* p, const fpv_rollout_io* io, void*
         return fail(FPV_ERR_ARG, "fpv_rollout_steps: obs, value, reward, terminated, truncated and status are required");
     if (e->cfg.precision != FPV_F32 || e->cfg.task != FPV_TASK_HOVER || e->cfg.noise_ratio == 0.0)
         return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_steps: fp32 hover handles with motor noise only");
+    if (e->cfg.detector == FPV_DETECTOR_PIXEL)
+        // (the pixel detector's work-item exchange lives above the part of the weight image this kernel stages again per step)
+        return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_steps: the persistent launch serves FPV_DETECTOR_ANALYTIC handles only");
     if (e->cfg.num_envs % 256 != 0 || e->cfg.num_envs / 256 > p->cus)
         return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_steps: num_envs must be a multiple of 256 and at most 256 x %d (one workgroup per CU)", p->cus);
     if (p->in_dim != 20 || p->act_dim != 4 || p->gemm != 0)
@@ -668,7 +671,7 @@ int fpv_rollout_steps(fpv_env* e, fpv_policy* p, const fpv_rollout_io* io, void*
     a.sigma = (float)e->cfg.noise_ratio;
     a.floor_check = e->cfg.floor_check;
     a.domain_rand = e->cfg.domain_rand;
-    a.detector = e->cfg.detector;
+    a.detector = e->cfg.detector == FPV_DETECTOR_PIXEL ? 1 : 0;   // kernel-side switch: non-zero = pixel rules
     a.ret = io->ret;
     a.gamma = io->gamma;
     a.mg_count = (double)e->cfg.num_envs;

@@ -443,28 +443,57 @@ __device__ __forceinline__ bool camera_features(const Drone<T>& d, T& cx, T& cy,
 // corners, accepted when the two off the longer diagonal lie farther than 0.04 arcLength from it.  OpenCV's rules are
 // restated from their documentation (cv2 is not on disk): parity unpinned; pinned by hover.py:50-51's own constants
 // (reset pose: 20 / 13 = 1.538, 207 / 16384 = 0.0126) and compared with a full Douglas-Peucker restatement in
-// tests/test_detector_cpu.py.  The arithmetic and its order are those of SPEC §6b (the CPU checker follows the same text).
+// tests/test_detector_cpu.py.
+//
+// Shape of the computation (round 3).  Everything a row contributes is an exact small integer (or half-integer) in T, so
+// the pass is written as a RUN of consecutive rows reduced to thirteen numbers (PixelRun) that concatenate exactly
+// (pixel_merge): a wave may walk all rows of its drones, or two waves may each walk a part of them (fpv_rollstep.hip:
+// the physics wave and its helper) and merge — same integers either way, hence the same features bit for bit.
+//   crossings of row y = j + 0.5: edge k crosses iff (v_k <= y) != (v_{k+1} <= y) — the rule of SPEC §6b as it stands;
+//   the four compares feed scalar XORs, a non-crossing edge contributes a NaN that v_min3 / v_max3 ignore;
+//   contour area   = W - (w_first + w_last) / 2 - S / 2 + H / 2
+//   contour length = w_first + w_last + S + 2 (n - 1) - 2 H + sqrt(2) H
+// with W = sum of widths (b - a), S = sum of |a - a'| + |b - b'| over consecutive rows, H = number of span ends that
+// moved; both closed forms equal SPEC §6b item 5's per-pair sums for 8-connected rows (a blob that is not 8-connected is
+// invisible anyway) and are checked against the explicit contour in tests/test_detector_cpu.py.
 template <typename T>
-__device__ __forceinline__ bool row_span(const T (&u)[4], const T (&v)[4], const T (&slope)[4], int j, int& a, int& b) {
-    // branch-free: the four edge tests run for every lane of the wave alike (crossings come in pairs on a closed polygon,
-    // so "at least two" = "any")
-    const T y = T(j) + T(0.5);
-    T xl = T(1e30), xr = T(-1e30);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int m = (k + 1) & 3;
-        const bool cross = (v[k] <= y) != (v[m] <= y);
-        const T x = u[k] + (y - v[k]) * slope[k];
-        xl = cross ? min_(xl, x) : xl;
-        xr = cross ? max_(xr, x) : xr;
-    }
-    const T fa = max_(ceil_(xl - T(0.5)), T(0)), fb = min_(floor_(xr - T(0.5)), T(127));
-    a = (int)fa; b = (int)fb;
-    return xl <= xr && fa <= fb;
+struct PixelRun {
+    T n;          // non-empty rows
+    T j0, jn;     // first / last non-empty row
+    T a0, b0;     // span of the first non-empty row
+    T pa, pb;     // span of the last non-empty row
+    T W, S, H;    // see above
+    T viol;       // max over consecutive rows of (a - b'), (a' - b): > 1 means not 8-connected
+    T amin, bmax; // bounding box columns
+};
+
+// a / b to ~1 ulp without the IEEE division sequence (fp32); exact division in fp64
+__device__ __forceinline__ float div_(float a, float b) {
+    const float r = __builtin_amdgcn_rcpf(b);
+    const float q = a * r;
+    return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+}
+__device__ __forceinline__ double div_(double a, double b) { return a / b; }
+
+// span [fa, fb] (as exact integers in T) of the row of pixel centres y = j + 0.5; false when the row is empty
+template <typename T>
+__device__ __forceinline__ bool row_span(const T (&u)[4], const T (&v)[4], const T (&slope)[4], T y, T& fa, T& fb) {
+    const bool c0 = v[0] <= y, c1 = v[1] <= y, c2 = v[2] <= y, c3 = v[3] <= y;
+    const T nan = __builtin_nanf("");
+    const T x0 = (c0 != c1) ? u[0] + (y - v[0]) * slope[0] : nan;
+    const T x1 = (c1 != c2) ? u[1] + (y - v[1]) * slope[1] : nan;
+    const T x2 = (c2 != c3) ? u[2] + (y - v[2]) * slope[2] : nan;
+    const T x3 = (c3 != c0) ? u[3] + (y - v[3]) * slope[3] : nan;
+    const T xl = min_(min_(x0, x1), min_(x2, x3)), xr = max_(max_(x0, x1), max_(x2, x3));   // NaN operands are ignored
+    fa = max_(ceil_(xl - T(0.5)), T(0));
+    fb = min_(floor_(xr - T(0.5)), T(127));
+    return xl <= xr && fa <= fb;                      // (no crossing: xl = xr = NaN, the first test fails)
 }
 
+// projected corners, edge slopes and the rows [jlo, jhi] that can hold pixel centres; false: some corner is behind the
+// camera or the quadrilateral lies between two rows of centres (then jlo > jhi as well)
 template <typename T>
-__device__ __forceinline__ bool camera_features_pixel(const Drone<T>& d, T& cx, T& cy, T& area, T& ratio) {
+__device__ __forceinline__ bool pixel_setup(const Drone<T>& d, T (&u)[4], T (&v)[4], T (&slope)[4], T& jlo, T& jhi) {
     const T xx = d.qx * d.qx, yy = d.qy * d.qy, zz = d.qz * d.qz;
     const T xy = d.qx * d.qy, xz = d.qx * d.qz, yz = d.qy * d.qz;
     const T wx_ = d.qw * d.qx, wy_ = d.qw * d.qy, wz_ = d.qw * d.qz;
@@ -479,7 +508,6 @@ __device__ __forceinline__ bool camera_features_pixel(const Drone<T>& d, T& cx, 
     const T dep_c = c * bx + s * bz, up_c = c * bz - s * bx, rt_c = -by;
     const T dep_y = c * r10 + s * r12, up_y = c * r12 - s * r10, rt_y = -r11;
     const T dep_z = c * r20 + s * r22, up_z = c * r22 - s * r20, rt_z = -r21;
-    T u[4], v[4];
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -489,90 +517,227 @@ __device__ __forceinline__ bool camera_features_pixel(const Drone<T>& d, T& cx, 
         const T up = up_c + sy * up_y + sz * up_z;
         const T rt = rt_c + sy * rt_y + sz * rt_z;
         if (!(dep > T(0.1))) { ok = false; dep = T(1); }
-        const T k = T(64) / dep;
+        const T k = div_(T(64), dep);
         u[j] = T(64) + k * rt;
         v[j] = T(64) - k * up;
     }
-    cx = T(0); cy = T(0); area = T(0); ratio = T(0);
-    T slope[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int m = (j + 1) & 3;
-        slope[j] = v[m] != v[j] ? (u[m] - u[j]) / (v[m] - v[j]) : T(0);
+        const T dv = v[m] - v[j];
+        slope[j] = dv != T(0) ? div_(u[m] - u[j], dv) : T(0);
     }
     const T vmin = min_(min_(v[0], v[1]), min_(v[2], v[3])), vmax = max_(max_(v[0], v[1]), max_(v[2], v[3]));
-    const T flo = max_(ceil_(vmin - T(0.5)), T(0)), fhi = min_(floor_(vmax - T(0.5)), T(127));
-    if (!ok || !(flo <= fhi)) return false;
-    const int jlo = (int)flo, jhi = (int)fhi;
-    int j0 = -1, jn = -1, amin = 128, bmax = -1, pa = 0, pb = 0;
-    bool border = false, broken = false;
-    T apx = T(0), len = T(0);
-    // rows are counted from each lane's own first row, so a wave iterates max(blob height), not the union of row ranges
-    for (int t = 0; t <= jhi - jlo; ++t) {
-        const int j = jlo + t;
-        int a, b;
-        if (!row_span(u, v, slope, j, a, b)) continue;                  // (a sliver between two pixel centres)
-        if (j0 >= 0 && jn != j - 1) broken = true;                      // an empty row inside the blob
-        if (j0 < 0) { j0 = j; len += T(b - a); }
-        else {
-            if (a > pb + 1 || b < pa - 1) broken = true;                // not 8-connected to the row above
-            const T ml = T(a > pa ? a : pa) - (a != pa ? T(0.5) : T(0));
-            const T mr = T(b < pb ? b : pb) + (b != pb ? T(0.5) : T(0));
-            if (mr > ml) apx += mr - ml;
-            const int da = a > pa ? a - pa : pa - a, db = b > pb ? b - pb : pb - b;
-            len += (da == 0 ? T(1) : T(1.4142135623730951) + T(da - 1)) + (db == 0 ? T(1) : T(1.4142135623730951) + T(db - 1));
-        }
-        if (a == 0 || b == 127 || j == 0 || j == 127) border = true;    // hover.py:180-185
-        amin = a < amin ? a : amin;
-        bmax = b > bmax ? b : bmax;
-        jn = j; pa = a; pb = b;
+    jlo = max_(ceil_(vmin - T(0.5)), T(0));
+    jhi = min_(floor_(vmax - T(0.5)), T(127));
+    ok = ok && jlo <= jhi;
+    if (!ok) { jlo = T(1); jhi = T(0); }
+    return ok;
+}
+
+// Border rule ahead of the walk (hover.py:180-185: a red pixel on the image border makes the target invisible).  True when
+// one of six rows of the blob — its first and last row and the two rows next to its leftmost and to its rightmost vertex,
+// where a convex outline reaches its extreme columns — has a span that starts in column 0, ends in column 127 or lies in
+// row 0 / 127.  These are rows of the walk evaluated by the walk's own row_span, so "true" is exactly what the walk would
+// find (and a border contact on another row is still found by the walk): skipping the walk then changes no result.
+// Nearly half of the blobs that have rows at all touch the border (measured on the synthetic states of bench.py).
+template <typename T>
+__device__ __forceinline__ bool pixel_touches_border(const T (&u)[4], const T (&v)[4], const T (&slope)[4], T jlo, T jhi) {
+    T vl = v[0], ul = u[0], vr = v[0], ur = u[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+        if (u[k] < ul) { ul = u[k]; vl = v[k]; }
+        if (u[k] > ur) { ur = u[k]; vr = v[k]; }
     }
-    if (j0 < 0 || broken || border) return false;
-    len += T(pb - pa);
-    int vx[4], vy[4];
+    const T rl = clip_(floor_(vl - T(0.5)), jlo, jhi), rr = clip_(floor_(vr - T(0.5)), jlo, jhi);
+    const T rows[6] = {jlo, jhi, rl, min_(rl + T(1), jhi), rr, min_(rr + T(1), jhi)};
+    bool touch = false;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        T a, b;
+        const bool ne = row_span(u, v, slope, rows[q] + T(0.5), a, b);
+        touch = touch || (ne && (a == T(0) || b == T(127) || rows[q] == T(0) || rows[q] == T(127)));
+    }
+    return touch && jlo <= jhi;
+}
+
+template <typename T>
+__device__ __forceinline__ void pixel_run_clear(PixelRun<T>& r) {
+    r.n = T(0); r.j0 = T(0); r.jn = T(-1); r.a0 = r.b0 = r.pa = r.pb = T(0);
+    r.W = r.S = r.H = T(0); r.viol = T(-1000); r.amin = T(128); r.bmax = T(-1);
+}
+
+// rows jfirst .. jlast (exact integers in T; none when jfirst > jlast) of this lane's quadrilateral
+// tab (may be null): span table, entry idx + (j - jfirst) <- a | b << 8 for the non-empty rows below cap (read back by the vertex
+// search of pixel_finish instead of evaluating those rows again).
+// linked: (pa0, pb0) is the span of row jfirst - 1, which belongs to the blob but to another run: when row jfirst is not empty its
+// pair with that row is counted here (S, H, viol), so that runs walked by different lanes need no merging beyond sums and
+// minima / maxima of their fields (fpv_rollstep.hip).
+template <typename T>
+__device__ __forceinline__ void pixel_walk(const T (&u)[4], const T (&v)[4], const T (&slope)[4], T jfirst, T jlast, PixelRun<T>& r,
+                                           uint16_t* tab = nullptr, int idx = 0, int cap = 0, bool linked = false, T pa0 = T(0),
+                                           T pb0 = T(0)) {
+    pixel_run_clear(r);
+    for (T j = jfirst; j <= jlast; j += T(1), ++idx) { // per-lane trip count: a wave iterates max(rows), not the union of ranges
+        T fa, fb;
+        if (!row_span(u, v, slope, j + T(0.5), fa, fb)) continue;   // (a sliver between two pixel centres)
+        if (tab && idx < cap) tab[idx] = (uint16_t)(int)(fb * T(256) + fa);
+        if (r.n == T(0)) {
+            const bool link = linked && j == jfirst;
+            r.j0 = j; r.a0 = fa; r.b0 = fb; r.pa = link ? pa0 : fa; r.pb = link ? pb0 : fb;
+        }
+        const T da = abs_(fa - r.pa), db = abs_(fb - r.pb);
+        r.viol = max_(r.viol, max_(fa - r.pb, r.pa - fb));
+        r.S += da; r.S += db;
+        r.H += min_(da, T(1)); r.H += min_(db, T(1));
+        r.W += fb - fa;
+        r.n += T(1);
+        r.amin = min_(r.amin, fa); r.bmax = max_(r.bmax, fb);
+        r.pa = fa; r.pb = fb; r.jn = j;
+    }
+}
+
+// The same for rows on which exactly the edges A and B cross (a run of rows between two vertex rows of a convex
+// quadrilateral): two edge evaluations per row instead of four tests.  The integers are those of pixel_walk — the
+// crossing rule picks these two edges on every row of the range (pixel_vertex_rows / pixel_active_pair below).
+template <typename T>
+__device__ __forceinline__ void pixel_walk2(T uA, T vA, T sA, T uB, T vB, T sB, T jfirst, T jlast, PixelRun<T>& r,
+                                            uint16_t* tab = nullptr, int idx = 0, int cap = 0, bool linked = false, T pa0 = T(0),
+                                            T pb0 = T(0)) {
+    pixel_run_clear(r);
+    for (T j = jfirst; j <= jlast; j += T(1), ++idx) {
+        const T y = j + T(0.5);
+        const T xa = uA + (y - vA) * sA, xb = uB + (y - vB) * sB;
+        const T fa = max_(ceil_(min_(xa, xb) - T(0.5)), T(0)), fb = min_(floor_(max_(xa, xb) - T(0.5)), T(127));
+        if (!(fa <= fb)) continue;
+        if (tab && idx < cap) tab[idx] = (uint16_t)(int)(fb * T(256) + fa);
+        if (r.n == T(0)) {
+            const bool link = linked && j == jfirst;
+            r.j0 = j; r.a0 = fa; r.b0 = fb; r.pa = link ? pa0 : fa; r.pb = link ? pb0 : fb;
+        }
+        const T da = abs_(fa - r.pa), db = abs_(fb - r.pb);
+        r.viol = max_(r.viol, max_(fa - r.pb, r.pa - fb));
+        r.S += da; r.S += db;
+        r.H += min_(da, T(1)); r.H += min_(db, T(1));
+        r.W += fb - fa;
+        r.n += T(1);
+        r.amin = min_(r.amin, fa); r.bmax = max_(r.bmax, fb);
+        r.pa = fa; r.pb = fb; r.jn = j;
+    }
+}
+
+// Row from which vertex i counts as "above the row of pixel centres": (v_i <= j + 0.5) <=> j >= c_i, c_i = ceil(v_i - 0.5)
+// (exact: v - 0.5 is exact for v >= 0.5, and a v below that gives a c of 0 either way), clamped to [0, 128].  Between two
+// consecutive values of the sorted c the set of crossing edges does not change.
+template <typename T>
+__device__ __forceinline__ void pixel_vertex_rows(const T (&v)[4], int (&c)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) c[i] = (int)clip_(ceil_(v[i] - T(0.5)), T(0), T(128));
+}
+
+// The edges crossing row j (constant over a range of rows that contains no c_i in its interior).  Returns how many cross
+// (2 for a convex quadrilateral, 4 for a self-intersecting one, 0 outside); A = the lowest-numbered, B = the
+// highest-numbered crossing edge.
+template <typename T>
+__device__ __forceinline__ T sel3_(bool f, bool g, T a, T b, T c) { return f ? a : (g ? b : c); }
+// (scalars on purpose: handed small arrays, hipcc turns the nested selects into an indexed load from scratch memory)
+template <typename T>
+__device__ __forceinline__ int pixel_active_pair(T u0, T u1, T u2, T u3, T v0, T v1, T v2, T v3, T s0, T s1, T s2, T s3,
+                                                 int c0, int c1, int c2, int c3, int j, T& uA, T& vA, T& sA, T& uB, T& vB, T& sB) {
+    const bool b0 = j >= c0, b1 = j >= c1, b2 = j >= c2, b3 = j >= c3;
+    const bool a0 = b0 != b1, a1 = b1 != b2, a2 = b2 != b3, a3 = b3 != b0;
+    uA = sel3_(a0, a1, u0, u1, u2); vA = sel3_(a0, a1, v0, v1, v2); sA = sel3_(a0, a1, s0, s1, s2);
+    uB = sel3_(a3, a2, u3, u2, u1); vB = sel3_(a3, a2, v3, v2, v1); sB = sel3_(a3, a2, s3, s2, s1);
+    return (int)a0 + (int)a1 + (int)a2 + (int)a3;
+}
+
+// p <- p followed by h (h's rows lie below p's)
+template <typename T>
+__device__ __forceinline__ void pixel_merge(PixelRun<T>& p, const PixelRun<T>& h) {
+    const bool hp = p.n > T(0), hh = h.n > T(0), both = hp && hh;
+    const T da = abs_(h.a0 - p.pa), db = abs_(h.b0 - p.pb);
+    const T link = max_(h.a0 - p.pb, p.pa - h.b0);
+    PixelRun<T> o;
+    o.n = p.n + h.n;                                  // a gap between the runs shows as jn - j0 + 1 != n
+    o.j0 = hp ? p.j0 : h.j0; o.a0 = hp ? p.a0 : h.a0; o.b0 = hp ? p.b0 : h.b0;
+    o.jn = hh ? h.jn : p.jn; o.pa = hh ? h.pa : p.pa; o.pb = hh ? h.pb : p.pb;
+    o.W = p.W + h.W;
+    o.S = p.S + h.S + (both ? da + db : T(0));
+    o.H = p.H + h.H + (both ? min_(da, T(1)) + min_(db, T(1)) : T(0));
+    o.viol = max_(max_(p.viol, h.viol), both ? link : T(-1000));
+    o.amin = min_(p.amin, h.amin); o.bmax = max_(p.bmax, h.bmax);
+    p = o;
+}
+
+// the gates and features of SPEC §6b items 3-7 from the blob's run; span(j, a, b) yields the span of a row j0 <= j <= jn
+// (it is also called for j0 - 1 and jn + 1, whose result is not used)
+template <typename T, typename SpanFn>
+__device__ __forceinline__ bool pixel_finish(const PixelRun<T>& r, const T (&u)[4], const T (&v)[4], SpanFn span,
+                                             T& cx, T& cy, T& area, T& ratio) {
+    cx = T(0); cy = T(0); area = T(0); ratio = T(0);
+    const T h = r.jn - r.j0 + T(1);
+    if (!(r.n > T(0)) || h != r.n || r.viol > T(1)) return false;             // empty, an empty row inside, not 8-connected
+    if (r.amin == T(0) || r.bmax == T(127) || r.j0 == T(0) || r.jn == T(127)) return false;   // hover.py:180-185
+    const T w0 = r.b0 - r.a0, wn = r.pb - r.pa;
+    const T apx = r.W - T(0.5) * (w0 + wn) - T(0.5) * r.S + T(0.5) * r.H;
+    const T straight = w0 + wn + r.S + T(2) * (r.n - T(1)) - T(2) * r.H;
+    const T diag = T(1.4142135623730951) * r.H;
+    const T len = straight + diag;
+    T vx[4], vy[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const T fr = floor_(v[k]);
-        const int jc = (int)(fr < T(j0) ? T(j0) : (fr > T(jn) ? T(jn) : fr));
+        const T jc = fr < r.j0 ? r.j0 : (fr > r.jn ? r.jn : fr);
+        const T fx = floor_(u[k]);
         T best = T(1e30);
-        vx[k] = 0; vy[k] = 0;
+        vx[k] = T(0); vy[k] = T(0);
 #pragma unroll
         for (int dj = -1; dj <= 1; ++dj) {
-            const int j = jc + dj;
-            int a = 0, b = 0;
-            if (j < j0 || j > jn) continue;
-            row_span(u, v, slope, j, a, b);
-            const T fx = floor_(u[k]);
-            const int x = (int)(fx < T(a) ? T(a) : (fx > T(b) ? T(b) : fx));
-            const T ex = T(x) + T(0.5) - u[k], ey = T(j) + T(0.5) - v[k], d2 = ex * ex + ey * ey;
-            if (d2 < best) { best = d2; vx[k] = x; vy[k] = j; }
+            const T j = jc + T(dj);
+            T a, b;
+            span(j, a, b);
+            const T x = fx < a ? a : (fx > b ? b : fx);
+            const T ex = x + T(0.5) - u[k], ey = j + T(0.5) - v[k], d2 = ex * ex + ey * ey;
+            if (j >= r.j0 && j <= r.jn && d2 < best) { best = d2; vx[k] = x; vy[k] = j; }
         }
     }
     const T eps = T(0.04) * len;
     {
-        const T d02 = T((vx[2] - vx[0]) * (vx[2] - vx[0]) + (vy[2] - vy[0]) * (vy[2] - vy[0]));
-        const T d13 = T((vx[3] - vx[1]) * (vx[3] - vx[1]) + (vy[3] - vy[1]) * (vy[3] - vy[1]));
-        const int p = d02 >= d13 ? 0 : 1, q = p + 2;
-        const T ex = T(vx[q] - vx[p]), ey = T(vy[q] - vy[p]), el = sqrt_(ex * ex + ey * ey);
+        const T e02x = vx[2] - vx[0], e02y = vy[2] - vy[0], e13x = vx[3] - vx[1], e13y = vy[3] - vy[1];
+        const T d02 = e02x * e02x + e02y * e02y, d13 = e13x * e13x + e13y * e13y;
+        const bool first = d02 >= d13;                                         // the longer diagonal's ends p, q = p + 2
+        const T px = first ? vx[0] : vx[1], py = first ? vy[0] : vy[1];
+        const T ex = first ? e02x : e13x, ey = first ? e02y : e13y, el = sqrt_(first ? d02 : d13);
         if (!(el > T(0))) return false;
-#pragma unroll
-        for (int k = 1; k < 4; k += 2) {
-            const int m = (p + k) & 3;
-            const T dist = abs_(ex * T(vy[m] - vy[p]) - ey * T(vx[m] - vx[p])) / el;
-            if (!(dist > eps)) return false;
-        }
+        const T m1x = first ? vx[1] : vx[2], m1y = first ? vy[1] : vy[2];      // vertices p + 1 and p + 3
+        const T m3x = first ? vx[3] : vx[0], m3y = first ? vy[3] : vy[0];
+        // distance from the chord > eps, as |cross product| > eps * |chord| (SPEC §6b item 6)
+        const T lim = eps * el;
+        const T cr1 = abs_(ex * (m1y - py) - ey * (m1x - px)), cr3 = abs_(ex * (m3y - py) - ey * (m3x - px));
+        if (!(cr1 > lim) || !(cr3 > lim)) return false;
     }
-    cx = T(0.25) * T(vx[0] + vx[1] + vx[2] + vx[3]) / T(64) - T(1);     // hover.py:197-203
-    cy = T(0.25) * T(vy[0] + vy[1] + vy[2] + vy[3]) / T(64) - T(1);
-    area = apx / T(16384);                                              // :206
-    ratio = T(bmax - amin + 1) / T(jn - j0 + 1);                        // :209-213
+    cx = ((vx[0] + vx[1]) + (vx[2] + vx[3])) * T(1.0 / 256.0) - T(1);          // hover.py:197-203: mean / 64 - 1 (exact scalings)
+    cy = ((vy[0] + vy[1]) + (vy[2] + vy[3])) * T(1.0 / 256.0) - T(1);
+    area = apx * T(1.0 / 16384.0);                                             // :206
+    ratio = div_(r.bmax - r.amin + T(1), h);                                   // :209-213
     return true;
 }
 
-// Observation of hover.py:237-272 into o[20]; updates the feature memory.  Returns visible.
 template <typename T>
-__device__ __forceinline__ bool observe(Drone<T>& d, T roll, T pitch, T yaw, T a0, T a1, T a2, T a3,
-                                        T (&o)[kObsWords], int detector = 0) {
+__device__ __forceinline__ bool camera_features_pixel(const Drone<T>& d, T& cx, T& cy, T& area, T& ratio) {
+    T u[4], v[4], slope[4], jlo, jhi;
+    bool ok = pixel_setup(d, u, v, slope, jlo, jhi);
+    if (pixel_touches_border(u, v, slope, jlo, jhi)) { ok = false; jlo = T(1); jhi = T(0); }    // invisible either way: no walk
+    PixelRun<T> r;
+    pixel_walk(u, v, slope, jlo, jhi, r);
+    const bool vis = pixel_finish(r, u, v, [&](T j, T& a, T& b) { row_span(u, v, slope, j + T(0.5), a, b); }, cx, cy, area, ratio);
+    return ok && vis;
+}
+
+// Observation of hover.py:237-272 into o[20] from the camera features of the caller; updates the feature memory.
+template <typename T>
+__device__ __forceinline__ void observe_with(Drone<T>& d, T roll, T pitch, T yaw, T a0, T a1, T a2, T a3, T (&o)[kObsWords],
+                                             bool vis, T cx, T cyy, T area, T ratio) {
     o[0] = wrap_angle(roll - d.er) * C<T>::inv_agent_dt;   // hover.py:228-230
     o[1] = wrap_angle(pitch - d.ep) * C<T>::inv_agent_dt;
     o[2] = wrap_angle(yaw - d.eyaw) * C<T>::inv_agent_dt;
@@ -584,8 +749,6 @@ __device__ __forceinline__ bool observe(Drone<T>& d, T roll, T pitch, T yaw, T a
     o[4] = cr * sp * cy + sr * cp * sy;
     o[5] = cr * cp * sy - sr * sp * cy;
     o[6] = cr * cp * cy + sr * sp * sy;
-    T cx, cyy, area, ratio;
-    const bool vis = detector ? camera_features_pixel(d, cx, cyy, area, ratio) : camera_features(d, cx, cyy, area, ratio);
     o[7] = cx; o[8] = cyy;                                 // hover.py:253-267
     o[9] = d.prev_cx; o[10] = d.prev_cy;
     o[11] = area; o[12] = d.prev_area;
@@ -593,6 +756,15 @@ __device__ __forceinline__ bool observe(Drone<T>& d, T roll, T pitch, T yaw, T a
     o[14] = ratio; o[15] = d.prev_ratio;
     o[16] = a0; o[17] = a1; o[18] = a2; o[19] = a3;
     d.prev_cx = cx; d.prev_cy = cyy; d.prev_area = area; d.prev_ratio = ratio;  // hover.py:270-272
+}
+
+// The same with the camera features computed here by the handle's detector.  Returns visible.
+template <typename T>
+__device__ __forceinline__ bool observe(Drone<T>& d, T roll, T pitch, T yaw, T a0, T a1, T a2, T a3,
+                                        T (&o)[kObsWords], int detector = 0) {
+    T cx, cyy, area, ratio;
+    const bool vis = detector ? camera_features_pixel(d, cx, cyy, area, ratio) : camera_features(d, cx, cyy, area, ratio);
+    observe_with(d, roll, pitch, yaw, a0, a1, a2, a3, o, vis, cx, cyy, area, ratio);
     return vis;
 }
 

@@ -41,7 +41,7 @@ struct RollStepArgs {
     MergeArgs mg;            // mg.rows != null: fold the previous launch's rows into rms first
     // ---- env side: st.obs holds obs_t on entry and obs_{t+1} on exit; st.actions is not used
     StepArgs<float> st;
-    uint64_t* stamps;        // diagnostic (fpv_debug_rollout_stamps): [grid][8] s_memrealtime values, or null
+    uint64_t* stamps;        // diagnostic (fpv_debug_rollout_stamps): [grid][16] s_memrealtime values, or null
 };
 
 // LDS map of phase 2, in floats from the start of the (dead) weight image
@@ -53,6 +53,19 @@ constexpr int kRsXch = kRsTile + 4 * kRsTileFloats;         // per tile: 128 dou
 constexpr int kRsSum = kRsXch + 4 * 256;                    // 4 x kPartialWords doubles
 static_assert((kRsXch * 4) % 8 == 0 && (kRsSum * 4) % 8 == 0, "fp64 areas must be 8-byte aligned");
 static_assert(kRsSum + 2 * 4 * kPartialWords <= 2 * kNetFloats, "phase-2 exchange must fit in the weight image's space");
+// Pixel detector (hover.py:157-222, SPEC §6b): the blob's rows as work items of the tile's two waves.  Per tile, above the rest
+// of the phase-2 map: the corner block [5][64] f32x4 (u, v, edge slopes, vertex rows, {first span-table entry, jlo, jhi} of
+// every drone), the drones' integer accumulators, the item list (kPixItems packed words + the item count) and the span table.
+constexpr int kPixItems = 256;                              // >= rows / chunk + 3 segments x 64 drones for every chunk size chosen
+constexpr int kPixAcc = 5 * kTile * 4;                      // floats from the tile's base: behind the corner block [5][64] f32x4
+constexpr int kPixSlots = kPixAcc + 3 * kTile * 4;          // per-drone accumulators [3][64] int4, then the item list
+constexpr int kPixTab = kPixSlots + kPixItems + 4;          // item list: kPixItems packed items, then the item count; then the span table
+constexpr int kPixSpanCap = kTile * 128;                    // u16 entries: a | b << 8 per row, the tile's drones one after the other (every
+                                                            // drone could have all 128 rows)
+constexpr int kPixTileFloats = kPixTab + kPixSpanCap / 2;
+constexpr int kRsPix = kRsSum + 2 * 4 * kPartialWords;
+static_assert((kRsPix * 4) % 16 == 0 && (kPixAcc * 4) % 16 == 0 && (kPixTileFloats * 4) % 16 == 0, "16-byte areas must be 16-byte aligned");
+static_assert(kRsPix + 4 * kPixTileFloats <= 2 * kNetFloats, "the pixel detector's exchange must fit in the weight image's space");
 
 // Workgroup barrier that publishes LDS only: waits for this wave's LDS operations, not for its global stores.  __syncthreads()
 // drains vmcnt too, and in these kernels every barrier would then wait out the ~1-2 us of the rollout-buffer / ledger / flag
@@ -243,7 +256,10 @@ struct TailOut {
     double* partials;        // this step's row table (one row per workgroup) or null
     bool store_obs;          // write the row-major observation tile to st.obs
     bool row_write_through;  // publish the row with sc1 stores + drain (read by other workgroups inside this launch)
-    uint64_t* stamps;        // diagnostic: 4 s_memrealtime values of the tile-0 physics wave (pairs done, observed, barrier 6, 7) or null
+    bool store_state;        // the physics wave stores its tile's state and tick itself, ahead of barrier 6 (one-step kernel)
+    uint64_t* stamps;        // diagnostic: s_memrealtime values of tile 0's waves, or null: [0..3] physics wave: pairs done, observed,
+                             // barrier 6, 7; pixel detector: [4] corners published, [5] own rows walked, [6] barrier Q passed, [7] features done;
+                             // [8] helper: barrier P passed, [9] helper: its rows walked
 };
 
 // Physics-wave registers that live across steps in the persistent kernel; the one-step kernel loads / stores them around
@@ -255,7 +271,88 @@ struct TileRegs {
     float tmpl_lane;
 };
 
-// Called by all 512 threads after the clipped actions are in LDS (kRsAct) and a workgroup barrier.  Contains eight
+// Inclusive sum over the 64 lanes on the VALU (DPP row shifts, then the row broadcasts gfx9 keeps): lane 63 holds the total.
+__device__ __forceinline__ int wave_scan_inclusive(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);    // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);    // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);    // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);    // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);    // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
+// Helper wave, one lane per drone: cut the drone's rows [jlo, jhi] at the rows where a vertex passes (between two cuts the same
+// two edges cross every row) and into chunks of at most 2^sh rows — eight, or more in a tile with so many rows that the list
+// would overflow — and append the items (drone | first row << 8 |
+// last row << 16) at this lane's place in the list.  Leaves the vertex rows and {first entry of the drone in the span table, jlo,
+// jhi} in the corner block.  A lane without rows (jlo > jhi) appends nothing.
+__device__ __forceinline__ void pixel_post_items(float* pix, int lane) {
+    f32x4* cb = reinterpret_cast<f32x4*>(pix);
+    const f32x4 qv = cb[kTile + lane], qr = cb[4 * kTile + lane];
+    const float v[4] = {qv.x, qv.y, qv.z, qv.w};
+    const int ilo = (int)qr.x, ihi = (int)qr.y;
+    int c[4];
+    pixel_vertex_rows(v, c);
+    const int lo1 = min(c[0], c[1]), hi1 = max(c[0], c[1]), lo2 = min(c[2], c[3]), hi2 = max(c[2], c[3]);
+    const int ma = max(lo1, lo2), mb = min(hi1, hi2), m1 = min(ma, mb), m2 = max(ma, mb);     // the two middle vertex rows
+    const int sa0 = ilo, sa1 = max(m1, ilo), sa2 = max(m2, ilo), sb0 = min(m1 - 1, ihi), sb1 = min(m2 - 1, ihi), sb2 = ihi;
+    const int l0 = max(sb0 - sa0 + 1, 0), l1 = max(sb1 - sa1 + 1, 0), l2 = max(sb2 - sa2 + 1, 0);
+    const int rows = max(ihi - ilo + 1, 0);
+    const int rows_incl = wave_scan_inclusive(rows);
+    const int tile_rows = __builtin_amdgcn_readlane(rows_incl, 63);
+    int sh = 3;                                                // chunks of 8 rows at least
+    while ((64 << sh) < tile_rows) ++sh;                       // items <= rows / 2^sh + 3 x 64 <= kPixItems
+    const int ch1 = (1 << sh) - 1;
+    const int n0 = (l0 + ch1) >> sh, n1 = (l1 + ch1) >> sh, n2 = (l2 + ch1) >> sh, items = n0 + n1 + n2;
+    const int incl = wave_scan_inclusive(items);
+    const int ch = 1 << sh, first = incl - items;
+    uint32_t* slots = reinterpret_cast<uint32_t*>(pix + kPixSlots);
+    int pos = first;
+    for (int i = 0, jf = sa0; i < n0; ++i, jf += ch) slots[pos++] = (uint32_t)lane | (uint32_t)jf << 8 | (uint32_t)min(jf + ch - 1, sb0) << 16;
+    for (int i = 0, jf = sa1; i < n1; ++i, jf += ch) slots[pos++] = (uint32_t)lane | (uint32_t)jf << 8 | (uint32_t)min(jf + ch - 1, sb1) << 16;
+    for (int i = 0, jf = sa2; i < n2; ++i, jf += ch) slots[pos++] = (uint32_t)lane | (uint32_t)jf << 8 | (uint32_t)min(jf + ch - 1, sb2) << 16;
+    if (lane == kTile - 1) slots[kPixItems] = (uint32_t)incl;
+    cb[3 * kTile + lane] = f32x4{(float)c[0], (float)c[1], (float)c[2], (float)c[3]};
+    cb[4 * kTile + lane] = f32x4{(float)(rows_incl - rows), (float)ilo, (float)ihi, 0.f};
+}
+
+// Both waves of the tile (worker 0 .. 127): walk the rows of items worker, worker + 128, ... and add each item's run to its
+// drone's accumulators.  An item whose first row is not the drone's first also evaluates the row above it and counts the pair
+// of the two rows (pixel_walk*'s `linked`), so every pair of consecutive rows is counted by exactly one item and the
+// accumulators need sums, minima and maxima only — integer LDS atomics on exact integers: the order does not matter.
+__device__ __forceinline__ void pixel_work_items(float* pix, int worker) {
+    const uint32_t* slots = reinterpret_cast<const uint32_t*>(pix + kPixSlots);
+    const f32x4* cb = reinterpret_cast<const f32x4*>(pix);
+    int* acc = reinterpret_cast<int*>(pix + kPixAcc);
+    uint16_t* tab = reinterpret_cast<uint16_t*>(pix + kPixTab);
+    const int total = (int)slots[kPixItems];
+    for (int item = worker; item < total; item += 2 * kTile) {
+        const uint32_t rec = slots[item];
+        const int d = (int)(rec & 63u), jf = (int)((rec >> 8) & 255u), jl = (int)(rec >> 16);
+        const f32x4 qu = cb[d], qv = cb[kTile + d], qs = cb[2 * kTile + d], qc = cb[3 * kTile + d], qr = cb[4 * kTile + d];
+        const float u[4] = {qu.x, qu.y, qu.z, qu.w}, v[4] = {qv.x, qv.y, qv.z, qv.w}, sl[4] = {qs.x, qs.y, qs.z, qs.w};
+        float uA, vA, sA, uB, vB, sB;
+        const int crossing = pixel_active_pair(qu.x, qu.y, qu.z, qu.w, qv.x, qv.y, qv.z, qv.w, qs.x, qs.y, qs.z, qs.w, (int)qc.x, (int)qc.y,
+                                               (int)qc.z, (int)qc.w, jf, uA, vA, sA, uB, vB, sB);
+        const int ilo = (int)qr.y, idx = (int)qr.x + jf - ilo;   // this item's first entry in the span table
+        float pa = 0.f, pb = 0.f;
+        const bool linked = jf > ilo && row_span(u, v, sl, (float)jf - 0.5f, pa, pb);       // the row above, if the blob has it
+        PixelRun<float> r;
+        if (crossing == 2) pixel_walk2(uA, vA, sA, uB, vB, sB, (float)jf, (float)jl, r, tab, idx, kPixSpanCap, linked, pa, pb);
+        else pixel_walk(u, v, sl, (float)jf, (float)jl, r, tab, idx, kPixSpanCap, linked, pa, pb);   // (a quadrilateral that rounding has
+                                                                                                      // folded over: the four-edge rule)
+        if (r.n > 0.f) {
+            int* a = acc + 4 * d;
+            atomicAdd(a, (int)r.n); atomicAdd(a + 1, (int)r.W); atomicAdd(a + 2, (int)r.S); atomicAdd(a + 3, (int)r.H);
+            a += 4 * kTile;
+            atomicMax(a, (int)r.viol); atomicMin(a + 1, (int)r.amin); atomicMax(a + 2, (int)r.bmax); atomicMin(a + 3, (int)r.j0);
+            atomicMax(a + 4 * kTile, (int)r.jn);
+        }
+    }
+}
+
+// Called by all 512 threads after the clipped actions are in LDS (kRsAct) and a workgroup barrier.  Contains eight (eleven with the pixel detector)
 // workgroup barriers on every path.  On return the four observation tiles (+ returns) are still in LDS (kRsTile).
 __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, TileRegs& tr, const TailOut& o_) {
     using T = float;
@@ -269,6 +366,7 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
     T(*nz)[8][kTile] = reinterpret_cast<T(*)[8][kTile]>(lds + kRsNoise + tl * (2 * 8 * kTile));
     Vec4<T>* tl_lds = reinterpret_cast<Vec4<T>*>(lds + kRsTile + tl * kRsTileFloats);
     double* bsum = reinterpret_cast<double*>(lds + kRsSum);
+    float* pix = lds + kRsPix + tl * kPixTileFloats;   // pixel detector: this tile's corner block, item list and runs
 
     if (helper) {
         // ---- noise producer: pair k is published before barrier k (fpv_step.hip, step_kernel_pair)
@@ -280,6 +378,15 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
             slot[0][lane] = ga[0]; slot[1][lane] = ga[1]; slot[2][lane] = ga[2]; slot[3][lane] = ga[3];
             slot[4][lane] = gb[0]; slot[5][lane] = gb[1]; slot[6][lane] = gb[2]; slot[7][lane] = gb[3];
             lds_barrier();
+        }
+        if (s.detector) {                                  // uniform: the pixel detector's rows are work items of both waves
+            lds_barrier();                                 // barrier P0: the physics wave has projected the corners
+            pixel_post_items(pix, lane);                   // ... and computes the Euler angles while this wave builds the item list
+            lds_barrier();                                 // barrier P: corner block and item list of this tile are in LDS
+            if (o_.stamps && threadIdx.x == 256) o_.stamps[8] = __builtin_amdgcn_s_memrealtime();
+            pixel_work_items(pix, kTile + lane);
+            if (o_.stamps && threadIdx.x == 256) o_.stamps[9] = __builtin_amdgcn_s_memrealtime();
+            lds_barrier();                                 // barrier Q: every item's run is in LDS
         }
         lds_barrier();   // barrier 6: the physics wave has staged the observation tile (and the returns)
         const int64_t rows_left = s.n - tile * kTile;
@@ -332,9 +439,60 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
     }
     if (o_.stamps && threadIdx.x == 0) o_.stamps[0] = __builtin_amdgcn_s_memrealtime();
     T roll, pitch, yaw;
-    euler_from_quat(d.qx, d.qy, d.qz, d.qw, roll, pitch, yaw);
     T o[kObsWords];
-    const bool vis = observe(d, roll, pitch, yaw, act.x, act.y, act.z, act.w, o, s.detector);
+    bool vis;
+    T cam_x, cam_y, cam_area, cam_ratio;
+    if (s.detector) {
+        // Pixel detector (hover.py:157-222, SPEC §6b).  A drone's blob is 0 .. ~45 image rows and a third of the drones see the
+        // panel at all: one lane walking its own drone's rows keeps the wave busy for the tallest blob while most lanes idle
+        // (measured: 35 rows per tile against 7.8 per drone), and the helper wave has nothing to do until barrier 6.  So the rows
+        // become work items of BOTH waves: this wave projects the corners; the helper cuts every drone's rows where a vertex
+        // passes and into chunks, and posts the items (this wave converts the attitude meanwhile); the 128 lanes each walk an
+        // item — with the two edges that cross its rows, not four edge tests per row — leaving a PixelRun and the rows' spans;
+        // this wave concatenates its drones' runs in row order (pixel_merge: exact integers, the same features as one walk over
+        // all rows), searches the four vertices in the span table and applies the gates.
+        T u[4], v[4], sl[4], jlo, jhi;
+        bool ok = pixel_setup(d, u, v, sl, jlo, jhi);
+        if (pixel_touches_border(u, v, sl, jlo, jhi)) { ok = false; jlo = T(1); jhi = T(0); }     // invisible: no rows to walk
+        f32x4* cb = reinterpret_cast<f32x4*>(pix);
+        cb[lane] = f32x4{u[0], u[1], u[2], u[3]};
+        cb[kTile + lane] = f32x4{v[0], v[1], v[2], v[3]};
+        cb[2 * kTile + lane] = f32x4{sl[0], sl[1], sl[2], sl[3]};
+        cb[4 * kTile + lane] = f32x4{jlo, jhi, 0.f, 0.f};
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        i32x4* acc = reinterpret_cast<i32x4*>(pix + kPixAcc);
+        acc[lane] = i32x4{0, 0, 0, 0};                     // n, W, S, H
+        acc[kTile + lane] = i32x4{-1000, 128, -1, 128};    // viol, amin, bmax, j0
+        acc[2 * kTile + lane] = i32x4{-1, 0, 0, 0};        // jn
+        lds_barrier();                                     // barrier P0
+        euler_from_quat(d.qx, d.qy, d.qz, d.qw, roll, pitch, yaw);
+        if (o_.stamps && threadIdx.x == 0) o_.stamps[4] = __builtin_amdgcn_s_memrealtime();
+        lds_barrier();                                     // barrier P
+        pixel_work_items(pix, lane);
+        if (o_.stamps && threadIdx.x == 0) o_.stamps[5] = __builtin_amdgcn_s_memrealtime();
+        lds_barrier();                                     // barrier Q
+        if (o_.stamps && threadIdx.x == 0) o_.stamps[6] = __builtin_amdgcn_s_memrealtime();
+        const i32x4 a0 = acc[lane], a1 = acc[kTile + lane], a2 = acc[2 * kTile + lane];
+        const int rowbase = (int)cb[4 * kTile + lane].x, ilo = (int)jlo;
+        const uint16_t* tab = reinterpret_cast<const uint16_t*>(pix + kPixTab);
+        auto span = [&](T j, T& a, T& b) {                 // (j0 - 1 / jn + 1 may be asked for: never below entry 0, result unused)
+            const int idx = rowbase + (int)j - ilo;
+            const uint32_t ab = tab[idx < 0 ? 0 : idx];
+            a = (T)(ab & 255u); b = (T)(ab >> 8);
+        };
+        PixelRun<T> r;
+        r.n = (T)a0.x; r.W = (T)a0.y; r.S = (T)a0.z; r.H = (T)a0.w;
+        r.viol = (T)a1.x; r.amin = (T)a1.y; r.bmax = (T)a1.z; r.j0 = (T)a1.w; r.jn = (T)a2.x;
+        span(r.j0, r.a0, r.b0);                            // first and last row of the blob (unused when the blob is empty)
+        span(r.jn, r.pa, r.pb);
+        const bool seen = pixel_finish(r, u, v, span, cam_x, cam_y, cam_area, cam_ratio);
+        vis = ok && seen;
+        if (o_.stamps && threadIdx.x == 0) o_.stamps[7] = __builtin_amdgcn_s_memrealtime();
+    } else {
+        euler_from_quat(d.qx, d.qy, d.qz, d.qw, roll, pitch, yaw);
+        vis = camera_features(d, cam_x, cam_y, cam_area, cam_ratio);
+    }
+    observe_with(d, roll, pitch, yaw, act.x, act.y, act.z, act.w, o, vis, cam_x, cam_y, cam_area, cam_ratio);
     uint32_t bits;
     const T reward = reward_and_flags(d, roll, pitch, vis, o, act.x, act.y, act.z, act.w, s.floor_check != 0, bits);
     d.er = roll; d.ep = pitch; d.eyaw = yaw;
@@ -382,14 +540,20 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
         reinterpret_cast<T*>(tl_lds)[kTile * kObsWords + lane] = ret;
         if (live && o_.done) o_.done[i] = done ? 1 : 0;
     }
-    lds_barrier();   // barrier 6
+    lds_barrier();   // barrier 6 (publishes LDS only: the global stores around it stay in flight)
     if (o_.stamps && threadIdx.x == 0) o_.stamps[2] = __builtin_amdgcn_s_memrealtime();
+    // Everything this wave still owes to memory leaves now, under the helper's tile store and moment sums, instead of after
+    // barrier 7 at the very end of the kernel: the state's nine 1-KiB stores, the tick, reward and flags.
+    tr.agent_tick += 1ull;
+    if (o_.store_state) {
+        store_drone(d, s.state, tile, lane);
+        if (lane == 0) s.tick[tile] = tr.agent_tick;
+    }
     if (live) {
         o_.reward[i] = reward;
         o_.terminated[i] = (bits & kInfoTerm) ? 1 : 0;
         o_.truncated[i] = (bits & kInfoTrunc) ? 1 : 0;
     }
-    tr.agent_tick += 1ull;
     lds_barrier();   // barrier 7
     if (o_.stamps && threadIdx.x == 0) o_.stamps[3] = __builtin_amdgcn_s_memrealtime();
 }
@@ -414,12 +578,6 @@ __device__ __forceinline__ void rs_store_state(const StepArgs<float>& s, const T
     const int lane = threadIdx.x & (kTile - 1), wave = threadIdx.x >> 6;
     if (wave < 4) store_drone(tr.d, s.state, (int64_t)blockIdx.x * 4 + (wave & 3), lane);
 }
-__device__ __forceinline__ void rs_store_tile(const StepArgs<float>& s, const TileRegs& tr) {
-    const int lane = threadIdx.x & (kTile - 1), wave = threadIdx.x >> 6;
-    rs_store_state(s, tr);
-    if (wave < 4 && lane == 0) s.tick[(int64_t)blockIdx.x * 4 + (wave & 3)] = tr.agent_tick;
-}
-
 // ---------------------------------------------------------------- phase 2 of the yaw task (fpv_yaw.hip's step body)
 // One aviary step = one control tick + two sub-steps per agent step (yaw.py:126-127): the physics wave draws its own eight
 // normals, so there is no noise hand-off; waves 4..7 only take the observation tile (row-major store, moment sums).
@@ -564,7 +722,7 @@ template <int TASK>
 __global__ __launch_bounds__(512) void rollout_step_kernel(RollStepArgs p) {
     constexpr int IN = TASK == 0 ? kIn : kYawObsWords, ACT = TASK == 0 ? kAct : 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-#define RS1_STAMP(k) do { if (p.stamps && threadIdx.x == 0) p.stamps[(int64_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define RS1_STAMP(k) do { if (p.stamps && threadIdx.x == 0) p.stamps[(int64_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     RS1_STAMP(0);
     f32x2 xpre[IN / 4];
     rollstep_prologue<IN>(p, lds, xpre);
@@ -588,11 +746,10 @@ __global__ __launch_bounds__(512) void rollout_step_kernel(RollStepArgs p) {
     RS1_STAMP(2);
     if (lane < 32) reinterpret_cast<f32x4*>(lds + kRsAct)[wave * 32 + lane] = cl;
     lds_barrier();
-    const TailOut to{p.st.reward, p.st.terminated, p.st.truncated, p.st.done, p.st.partials, true, false,
-                     p.stamps ? p.stamps + (int64_t)blockIdx.x * 8 + 4 : nullptr};
+    const TailOut to{p.st.reward, p.st.terminated, p.st.truncated, p.st.done, p.st.partials, true, false, true,
+                     p.stamps ? p.stamps + (int64_t)blockIdx.x * 16 + 4 : nullptr};
     if constexpr (TASK == 0) {
-        rs_tail(p.st, lds, tr, to);
-        rs_store_tile(p.st, tr);
+        rs_tail(p.st, lds, tr, to);              // (stores the state itself: TailOut.store_state)
     } else {
         rs_tail_yaw(p.st, lds, ytr, to);
     }
@@ -801,7 +958,7 @@ __global__ __launch_bounds__(512) void rollout_persistent_kernel(RollPersistArgs
         if (lane < 32) reinterpret_cast<f32x4*>(lds + kRsAct)[wave * 32 + lane] = cl;
         lds_barrier();
         const bool last = t == p.T - 1;
-        const TailOut to{p.reward + off, s.terminated, s.truncated, p.done ? p.done + off : nullptr, p.rows[t & 1], last, !last, nullptr};
+        const TailOut to{p.reward + off, s.terminated, s.truncated, p.done ? p.done + off : nullptr, p.rows[t & 1], last, !last, false, nullptr};
         rs_tail(s, lds, tr, to);
         rs_store_state(s, tr);
         RS_STAMP(2);

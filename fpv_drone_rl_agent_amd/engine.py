@@ -26,7 +26,7 @@ class FpvEngine:
 
     def __init__(self, num_envs: int, device: int | str | torch.device = 0, *, render: bool = False,
                  noise_ratio: float = 0.02, seed: int = 0, id_offset: int = 0, precision: str = "f32",
-                 ledger_capacity: int = 0, task: str = "hover", domain_rand: bool = False, detector: str = "analytic"):
+                 ledger_capacity: int = 0, task: str = "hover", domain_rand: bool = False, detector: str | None = None):
         if not torch.cuda.is_available():
             raise RuntimeError("FpvEngine needs a HIP device: the MI355X extension has no CPU fallback")
         self.lib = L.load()
@@ -41,8 +41,11 @@ class FpvEngine:
         if task not in ("hover", "yaw"):
             raise ValueError("task must be 'hover' (simulation/hover.py) or 'yaw' (simulation/yaw.py)")
         self.task = task
+        if detector is None:         # hover: the reference's own pixel rules (hover.py:157-222); the yaw task has no pixel detector
+            detector = "pixel" if task == "hover" else "analytic"
         if detector not in ("analytic", "pixel"):
-            raise ValueError("detector must be 'analytic' (docs/SPEC.md §6) or 'pixel' (the 128 x 128 rules of hover.py:157-222, §6b)")
+            raise ValueError("detector must be 'pixel' (the 128 x 128 rules of hover.py:157-222, docs/SPEC.md §6b; the default) "
+                             "or 'analytic' (the continuous projection of SPEC §6)")
         self.detector = detector
         self.noise_ratio = float(noise_ratio)
         cfg = L.FpvConfig(self.num_envs, dev.index or 0, L.FPV_F64 if self._f64 else L.FPV_F32,

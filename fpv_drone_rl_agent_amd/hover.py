@@ -3,8 +3,8 @@ N = 1 view of the batched MI355X engine.
 
 Same constructor keywords, spaces, return arity / types / info keys.  Differences that follow from
 the engine (docs/SPEC.md): physics is the build's written spec (PyFlyt parity unpinned), camera
-features come from the projected panel (`detector="analytic"`) or from the reference's pixel rules
-restated without a renderer (`detector="pixel"`), and `reset()` is a constant-state overwrite instead of rebuilding a
+features come from the reference's pixel rules restated without a renderer (`detector="pixel"`, the default) or from the
+continuous projection of the panel (`detector="analytic"`), and `reset()` is a constant-state overwrite instead of rebuilding a
 simulator (the reference spends ~0.5 s there).
 """
 from __future__ import annotations
@@ -26,7 +26,7 @@ class QuadXHoverEnv(_EnvBase):
     metadata = {"render_modes": []}
 
     def __init__(self, flight_mode: int = 0, agent_hz: int = 40, render: bool = False, *, device=0,
-                 noise_ratio: float = 0.02, seed: int = 0, detector: str = "analytic"):
+                 noise_ratio: float = 0.02, seed: int = 0, detector: str = "pixel"):
         if _EnvBase is not object:
             super().__init__()
         if flight_mode != 0:

@@ -142,9 +142,10 @@ class RolloutCollector:
             # persistent: the WHOLE rollout of n_steps as one launch (fpv_rollout_steps): weights stay in LDS, drone state in
             # registers, a grid-wide barrier + statistics merge between steps.  Same bits again.  Needs every workgroup resident:
             # at most one per CU, i.e. num_envs <= 256 x CUs.
-            can_p = can and N // 256 <= cus and engine.task == "hover"
+            can_p = can and N // 256 <= cus and engine.task == "hover" and engine.detector == "analytic"
             if persistent and not can_p:
-                raise ValueError("persistent needs what one_launch needs and num_envs <= 256 x the device's CU count")
+                raise ValueError("persistent needs what one_launch needs, num_envs <= 256 x the device's CU count and "
+                                 "detector='analytic'")
             self._persistent = self._persistent_ok = False if persistent is None else bool(persistent)
             if self._one_launch or self._persistent:    # step t's rows are read while step t + 1's are written: two tables
                 self._rs_partials = torch.zeros((2, N // 256, 2 * O + 4), dtype=torch.float64, device=dev)
@@ -397,6 +398,11 @@ class RolloutCollector:
         self._started = True
 
     def _capture(self) -> None:
+        """Warm up once, then capture BOTH slots' graphs (the slots differ only in which post-rollout words the tail writes).
+        Capturing the second slot lazily — at the start of rollout 1 — would put its eager warm-up step into the middle of
+        training: an env step whose transitions are never returned, whose episode ends the next rollout_begin wipes from the
+        ledger, and which lands inside a timed region of bench.py.  Here every discarded step happens before the first
+        rollout."""
         side = torch.cuda.Stream(self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):       # warm-up outside capture: lazy allocations, rocBLAS handles
@@ -410,10 +416,14 @@ class RolloutCollector:
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         self._tick0 += self.T if self._persistent else 1
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._all_steps()
-        self._graph = g
+        keep = self._slot
+        for slot in (0, 1):
+            self._slot = slot
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._all_steps()
+            self._graphs[slot] = g
+        self._slot = keep
 
     def set_policy_gemm(self, gemm: str) -> None:
         """'f32' (exact fp32 MFMA) or 'bf16x6' (fp32-faithful 6-term bf16 split); drops the captured graph."""

@@ -25,6 +25,12 @@
 extern "C" {
 #endif
 
+/* Layout version of the structs and enums below.  fpv_version() returns the value the library was built with: a host
+ * compares the two before its first call (fpv_step_extras grew and fpv_detector was renumbered between 1 and 2, so a host
+ * built against another header would pass structs of another size).  History: 1 = rounds 1-2; 2 = round 3
+ * (FPV_DETECTOR_PIXEL = 0 is the default, debug hooks moved to fpv_env_debug.h). */
+#define FPV_ABI_VERSION 2
+
 #define FPV_STATE_WORDS 36 /* docs/SPEC.md §2 canonical order */
 #define FPV_OBS_WORDS 20   /* simulation/hover.py:63-70 */
 #define FPV_ACT_WORDS 4    /* simulation/hover.py:59-61 */
@@ -72,13 +78,14 @@ typedef struct {
 } fpv_config;
 
 /* The reference renders a 128 x 128 image and runs OpenCV's contour calls on it (hover.py:157-222).  Neither a renderer
- * nor OpenCV is part of this path: FPV_DETECTOR_ANALYTIC projects the panel's corners and takes centre / area /
- * bounding-box ratio of the continuous quadrilateral (docs/SPEC.md §6); FPV_DETECTOR_PIXEL applies the reference's rules
- * on the pixel grid — coverage by pixel centres, border rule, integer boundingRect, contourArea of the pixel contour,
- * the four approxPolyDP vertices (SPEC §6b; from the reset pose it reproduces hover.py:50-51's target_area = 0.013 and
- * target_ratio = 1.53).  The yaw task's target_center stays analytic (its sphere detector is missing from the
- * reference). */
-typedef enum { FPV_DETECTOR_ANALYTIC = 0, FPV_DETECTOR_PIXEL = 1 } fpv_detector;
+ * nor OpenCV is part of this path.  FPV_DETECTOR_PIXEL (the default: a zero-initialised config selects it) applies the
+ * reference's rules on the pixel grid — coverage by pixel centres, border rule, integer boundingRect, contourArea of the
+ * pixel contour, the four approxPolyDP vertices (docs/SPEC.md §6b); from the reset pose it reproduces hover.py:50-51's
+ * target_area = 0.013 and target_ratio = 1.53.  FPV_DETECTOR_ANALYTIC projects the panel's corners and takes centre /
+ * area / bounding-box ratio of the continuous quadrilateral (SPEC §6): cheaper, but per-cent level differences in
+ * obs[7,8,11,14] and the reward's target term.  The yaw task's target_center is analytic either way (its sphere
+ * detector is missing from the reference). */
+typedef enum { FPV_DETECTOR_PIXEL = 0, FPV_DETECTOR_ANALYTIC = 1 } fpv_detector;
 
 /* Device-side view of the done ledger (SB3 VecEnv `infos[i]["terminal_observation"]`,
  * `["TimeLimit.truncated"]`, Monitor `["episode"] = {r, l}` — SURVEY.md §8a A11).

@@ -247,20 +247,23 @@ static int camera_pixel(const double pos[3], const double quat[4], double center
     if (dbg) for (int i = 0; i < 256; ++i) dbg[i] = -1.0;
     /* pass over the rows: bounding box, contour area and length, border rule, 8-connectivity */
     int j0 = -1, jn = -1, amin = 128, bmax = -1, pa = 0, pb = 0, border = 0, broken = 0;
-    double apx = 0.0, len = 0.0;
+    int straight = 0, diag = 0;                                /* unit and diagonal steps of the outer contour */
+    double apx = 0.0;
     for (int j = jlo; j <= jhi; ++j) {
         int a, b;
         if (!row_span(u, v, slope, j, &a, &b)) continue;               /* (a sliver between two pixel centres) */
         if (dbg) { dbg[2 * j] = a; dbg[2 * j + 1] = b; }
         if (j0 >= 0 && jn != j - 1) broken = 1;                 /* an empty row inside the blob */
-        if (j0 < 0) { j0 = j; len += (double)(b - a); }
+        if (j0 < 0) { j0 = j; straight += b - a; }               /* the top row's run */
         else {
             if (a > pb + 1 || b < pa - 1) broken = 1;           /* not 8-connected to the row above */
             double ml = (a > pa ? a : pa) - (a != pa ? 0.5 : 0.0);
             double mr = (b < pb ? b : pb) + (b != pb ? 0.5 : 0.0);
             if (mr > ml) apx += mr - ml;
             int da = a > pa ? a - pa : pa - a, db = b > pb ? b - pb : pb - b;
-            len += (da == 0 ? 1.0 : 1.4142135623730951 + (double)(da - 1)) + (db == 0 ? 1.0 : 1.4142135623730951 + (double)(db - 1));
+            /* per side: one straight step down if the end stays, else one diagonal step and |delta| - 1 along the row */
+            if (da == 0) straight += 1; else { diag += 1; straight += da - 1; }
+            if (db == 0) straight += 1; else { diag += 1; straight += db - 1; }
         }
         if (a == 0 || b == 127 || j == 0 || j == 127) border = 1;      /* hover.py:180-185 */
         if (a < amin) amin = a;
@@ -268,7 +271,9 @@ static int camera_pixel(const double pos[3], const double quat[4], double center
         jn = j; pa = a; pb = b;
     }
     if (j0 < 0 || broken || border) return 0;
-    len += (double)(pb - pa);                                           /* the bottom row's run */
+    straight += pb - pa;                                                /* the bottom row's run */
+    double diag_len = 1.4142135623730951 * (double)diag;
+    double len = (double)straight + diag_len;                           /* cv2.arcLength of the 8-connected contour */
     /* the four vertices: covered pixel nearest to each projected corner (rows within one of the corner's own) */
     int vx[4], vy[4];
     for (int k = 0; k < 4; ++k) {
@@ -298,10 +303,11 @@ static int camera_pixel(const double pos[3], const double quat[4], double center
         int p = d02 >= d13 ? 0 : 1, q = p + 2;                           /* the longer diagonal's ends */
         double ex = vx[q] - vx[p], ey = vy[q] - vy[p], el = sqrt(ex * ex + ey * ey);
         if (!(el > 0.0)) return 0;
+        double lim = eps * el;                                           /* distance > eps as |cross product| > eps |chord| */
         for (int k = p + 1; k < p + 4; k += 2) {
             int m = k & 3;
-            double dist = fabs(ex * (vy[m] - vy[p]) - ey * (vx[m] - vx[p])) / el;
-            if (!(dist > eps)) return 0;
+            double cr = fabs(ex * (vy[m] - vy[p]) - ey * (vx[m] - vx[p]));
+            if (!(cr > lim)) return 0;
         }
     }
     center[0] = 0.25 * (double)(vx[0] + vx[1] + vx[2] + vx[3]) / 64.0 - 1.0;      /* hover.py:197-203 */

@@ -73,8 +73,9 @@ def _f64(a):
 DETECTORS = {"analytic": 0, "pixel": 1}
 
 
-def make_cfg(floor_check=True, noise_ratio=0.02, seed=0, id_offset=0, domain_rand=False, detector="analytic"):
-    """detector: "analytic" (SPEC §6) or "pixel" (the 128 x 128 rules of hover.py:157-222, SPEC §6b)."""
+def make_cfg(floor_check=True, noise_ratio=0.02, seed=0, id_offset=0, domain_rand=False, detector="pixel"):
+    """detector: "pixel" (the 128 x 128 rules of hover.py:157-222, SPEC §6b; the default, as in the product) or "analytic"
+    (the continuous projection of SPEC §6)."""
     return _Cfg(int(bool(floor_check)), int(bool(domain_rand)), float(noise_ratio), int(seed), int(id_offset),
                 DETECTORS[detector] if isinstance(detector, str) else int(detector), 0)
 
@@ -119,7 +120,7 @@ def scale_action(a):
     return sp
 
 
-def camera(pos, quat, detector="analytic"):
+def camera(pos, quat, detector="pixel"):
     pos, quat = _f64(pos), _f64(quat)
     c = np.zeros(2)
     area, ratio = C.c_double(), C.c_double()
@@ -151,7 +152,7 @@ def reward(pos, euler, omega_z, center, area, ratio, visible, action, prev_actio
 
 
 # ---------------------------------------------------------------- state / batch
-def reset_states(n, detector="analytic"):
+def reset_states(n, detector="pixel"):
     """n freshly reset drones.  Returns (state [n,36], obs [n,20])."""
     st = np.zeros((n, STATE_WORDS))
     obs = np.zeros((n, OBS_WORDS))
@@ -159,7 +160,7 @@ def reset_states(n, detector="analytic"):
     return st, obs
 
 
-def reset_masked(state, obs, mask, detector="analytic"):
+def reset_masked(state, obs, mask, detector="pixel"):
     m = np.ascontiguousarray(mask, dtype=np.uint8)
     lib().fpv_oracle_reset_batch_d(C.c_int64(state.shape[0]), _dp(state), _dp(obs),
                                    m.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int(DETECTORS.get(detector, detector)))

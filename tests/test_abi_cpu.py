@@ -23,7 +23,10 @@ def test_header_symbols_all_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/fpv_env.h but not exported"
     assert sorted(_lib.SIGNATURES) == declared, "ctypes binding and header drifted apart"
-    assert lib.fpv_version() == 1
+    # the version handshake (a host built against another header would pass structs of another size): header macro ==
+    # library == binding; _lib.load() refuses a stale library
+    macro = int(re.search(r"#define FPV_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "fpv_env.h")).read()).group(1))
+    assert lib.fpv_version() == macro == _lib.ABI_VERSION
 
 
 def test_config_struct_layout_matches_header():

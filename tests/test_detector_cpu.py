@@ -162,7 +162,7 @@ def test_step_uses_the_selected_detector(oracle):
     st = oracle.synthetic_states(256, seed=9)
     act = np.zeros((256, 4))
     a = st.copy(); b = st.copy()
-    obs_a, rew_a, *_ = oracle.step_batch(oracle.make_cfg(noise_ratio=0.0), a, act, 0)
+    obs_a, rew_a, *_ = oracle.step_batch(oracle.make_cfg(noise_ratio=0.0, detector="analytic"), a, act, 0)
     obs_b, rew_b, *_ = oracle.step_batch(oracle.make_cfg(noise_ratio=0.0, detector="pixel"), b, act, 0)
     both = (obs_a[:, 13] == 1) & (obs_b[:, 13] == 1)
     assert both.sum() > 10
@@ -173,3 +173,63 @@ def test_step_uses_the_selected_detector(oracle):
     t_a = -np.hypot(*obs_a[i, 7:9]) - abs(obs_a[i, 11] - 0.013) - abs(obs_a[i, 14] - 1.53)
     t_b = -np.hypot(*obs_b[i, 7:9]) - abs(obs_b[i, 11] - 0.013) - abs(obs_b[i, 14] - 1.53)
     assert abs((rew_b[i] - rew_a[i]) - (t_b - t_a)) < 1e-12
+
+
+def _run(rows):
+    """PixelRun of fpv_dynamics.h in integers: what a walk over `rows` [(j, a, b), ...] leaves."""
+    r = dict(n=0, j0=0, jn=-1, a0=0, b0=0, pa=0, pb=0, W=0, S=0, H=0, viol=-1000, amin=128, bmax=-1)
+    for j, a, b in rows:
+        if r["n"] == 0:
+            r.update(j0=j, a0=a, b0=b, pa=a, pb=b)
+        da, db = abs(a - r["pa"]), abs(b - r["pb"])
+        r["viol"] = max(r["viol"], a - r["pb"], r["pa"] - b)
+        r["S"] += da + db
+        r["H"] += min(da, 1) + min(db, 1)
+        r["W"] += b - a
+        r["n"] += 1
+        r["amin"], r["bmax"] = min(r["amin"], a), max(r["bmax"], b)
+        r.update(pa=a, pb=b, jn=j)
+    return r
+
+
+def _merge(p, h):
+    if h["n"] == 0:
+        return dict(p)
+    if p["n"] == 0:
+        return dict(h)
+    da, db = abs(h["a0"] - p["pa"]), abs(h["b0"] - p["pb"])
+    return dict(n=p["n"] + h["n"], j0=p["j0"], a0=p["a0"], b0=p["b0"], jn=h["jn"], pa=h["pa"], pb=h["pb"], W=p["W"] + h["W"],
+                S=p["S"] + h["S"] + da + db, H=p["H"] + h["H"] + min(da, 1) + min(db, 1),
+                viol=max(p["viol"], h["viol"], h["a0"] - p["pb"], p["pa"] - h["b0"]), amin=min(p["amin"], h["amin"]),
+                bmax=max(p["bmax"], h["bmax"]))
+
+
+def test_run_closed_forms_equal_the_per_pair_sums_and_concatenate(oracle):
+    """The HIP kernels reduce the blob's rows to a PixelRun (fpv_dynamics.h) and take contour area / arcLength from closed
+    forms; two waves may each walk a part of the rows and concatenate.  Checked here in integers against the oracle's
+    per-pair sums (SPEC §6b item 5) on random poses, for every split point of every blob."""
+    st = oracle.synthetic_states(6000, seed=8)
+    blobs = 0
+    for i in range(st.shape[0]):
+        vis, c, area, ratio, spans, verts, length, apx = oracle.camera_pixel_debug(st[i, 0:3], st[i, 3:7])
+        if not spans or length < 0:
+            continue
+        rows = [(j, spans[j][0], spans[j][1]) for j in sorted(spans)]
+        r = _run(rows)
+        gap = r["jn"] - r["j0"] + 1 != r["n"]
+        if gap or r["viol"] > 1:
+            assert vis == 0
+            continue
+        blobs += 1
+        w0, wn = r["b0"] - r["a0"], r["pb"] - r["pa"]
+        assert r["W"] - 0.5 * (w0 + wn) - 0.5 * r["S"] + 0.5 * r["H"] == apx
+        straight = w0 + wn + r["S"] + 2 * (r["n"] - 1) - 2 * r["H"]
+        assert straight + 1.4142135623730951 * r["H"] == length
+        if vis:
+            assert ratio == (r["bmax"] - r["amin"] + 1) / (r["jn"] - r["j0"] + 1)
+        for cut in range(len(rows) + 1):
+            m = _merge(_run(rows[:cut]), _run(rows[cut:]))
+            # (viol carries each run's first row against itself, -(b - a) <= 0: only its comparison with 1 is used)
+            assert {k: v for k, v in m.items() if k != "viol"} == {k: v for k, v in r.items() if k != "viol"}
+            assert (m["viol"] > 1) == (r["viol"] > 1)
+    assert blobs > 800

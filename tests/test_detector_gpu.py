@@ -82,6 +82,19 @@ def test_fp32_step_features_match_oracle_up_to_one_pixel_flips(oracle):
     bad = (diff > 1e-5).any(axis=1) & ~done
     assert (obs_r[:, 13] == 1).sum() > n // 4
     frac = bad.mean()
+    # the measured rate goes on record (gpurun_out/ is scratch; the copy under profiles/ is the committed one)
+    import json, os
+    seen = (obs_r[:, 13] == 1) & ~done
+    rec = {"drones": n, "see_the_panel": int(seen.sum()), "rows_with_a_feature_difference": int(bad.sum()),
+           "fraction_of_all_drones": float(frac), "fraction_of_drones_that_see_the_panel": float(bad.sum() / max(1, seen.sum())),
+           "visibility_flips": int((bad & (obs[:, 13] != obs_r[:, 13])).sum()),
+           "what": "fp32 HIP env step (detector=pixel) vs the fp64 oracle from identical fp32 states, one step, motor noise on; a row "
+                   "counts when any of obs[7,8,11,13,14] differs by more than 1e-5"}
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "pixel_flip_rate.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    print("pixel detector fp32 flip rate:", rec)
     assert frac < 0.01, frac                                       # one-pixel rasterisation flips: rare
     # ... and small: a visibility flip, or one pixel of w / h, a few px^2 of contour, one pixel of one vertex
     same_vis = bad & (obs[:, 13] == obs_r[:, 13])

@@ -4,6 +4,8 @@ state invariants, reset idempotence — plus a seeded sample of drones replayed 
 import numpy as np
 import pytest
 
+from tests import parity
+
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
@@ -76,12 +78,17 @@ def test_fullsize_shard_independence_and_oracle_sample(oracle):
     one.step(acts[0])
     got = one.get_state().cpu().numpy()[pick]
     a0 = acts[0].cpu().numpy().astype(np.float64)
+    flipped = 0
     for k, i in enumerate(pick):
         row = st0[i].astype(np.float64).copy()
         _, _, bits = oracle.step_one(cfg, row, a0[i], int(i), 0)
         if bits & 3:
             continue                                             # auto-reset rows are covered by the parity tests
-        assert (np.abs(got[k] - row) <= 1e-5 * np.maximum(1, np.abs(row))).all(), i
+        ok = np.abs(got[k] - row) <= 1e-5 * np.maximum(1, np.abs(row))
+        if not ok.all():                                         # a one-pixel flip of the pixel detector (tests/parity.py):
+            assert set(np.where(~ok)[0]) <= set(parity.FEATURE_STATE), i      # only the feature memory / ep_return may differ
+            flipped += 1
+    assert flipped <= 2
     eng.close(); one.close()
 
 
@@ -146,30 +153,37 @@ def test_benchmarked_kernel_matches_oracle_sample_including_auto_reset(oracle, l
     cfg = oracle.make_cfg(noise_ratio=0.02, seed=seed)
     a_np, r_in = act.cpu().numpy().astype(np.float64), ret_in.cpu().numpy().astype(np.float64)
     tol = lambda a, b, t=1e-5: (np.abs(a - b) <= t * np.maximum(1.0, np.abs(b))).all()
-    ended = 0
+    ended = flipped = 0
+    feat, other = parity.FEATURE_OBS, [c for c in range(3, 20) if c not in parity.FEATURE_OBS]
+    st_other = [c for c in range(36) if c not in parity.FEATURE_STATE]
     for i in pick:
         row = st0[i].astype(np.float64).copy()
         obs_r, rew_r, bits = oracle.step_one(cfg, row, a_np[i], int(i), 9)
-        assert tol(got_rew[i], rew_r, 2e-5), i
         assert got_done[i] == (1 if bits & 3 else 0)
+        # the observation this step produced: in the ledger for a finished episode, else the returned one
+        seen = led["obs"][led_row[int(i)]].astype(np.float64) if bits & 3 else got_obs[i].astype(np.float64)
+        # pixel detector (the default): a one-pixel rasterisation flip between fp32 and the fp64 oracle (tests/parity.py) is
+        # allowed on at most two drones of the sample; everything that does not derive from the camera features still holds
+        flip = bool((np.abs(seen[feat] - obs_r[feat]) > 1e-5).any())
+        flipped += flip
+        assert flip or tol(got_rew[i], rew_r, 2e-5), i
         r_acc = r_in[i] * gamma + rew_r
+        assert tol(seen[other], obs_r[other]) and tol(seen[0:3] * 0.025, obs_r[0:3] * 0.025), i
+        assert flip or tol(seen[feat], obs_r[feat]), i
         if bits & 3:
             ended += 1
             j = led_row[int(i)]
             assert led["info"][j] & 0xFF == bits and led["info"][j] >> 8 == int(row[34])
-            t_obs = led["obs"][j].astype(np.float64)
-            assert tol(t_obs[3:], obs_r[3:]) and tol(t_obs[0:3] * 0.025, obs_r[0:3] * 0.025), i      # terminal observation
-            assert tol(led["ep_return"][j], row[35], 2e-5)
+            assert flip or tol(led["ep_return"][j], row[35], 2e-5)
             keep = row[30:34].copy()                               # prev_action survives reset (hover.py:101 vs :357)
             rs, ro = oracle.reset_states(1)
             rs[0, 30:34] = keep
             assert tol(got_st[i], rs[0]) and tol(got_obs[i], ro[0]), i
             assert got_ret[i] == 0.0
         else:
-            assert tol(got_st[i], row), i
-            assert tol(got_obs[i, 3:], obs_r[3:]) and tol(got_obs[i, 0:3] * 0.025, obs_r[0:3] * 0.025), i
-            assert tol(got_ret[i], r_acc, 2e-5)
-    assert ended >= 3 * k - 2
+            assert tol(got_st[i][st_other], row[st_other]), i
+            assert flip or (tol(got_st[i], row) and tol(got_ret[i], r_acc, 2e-5)), i
+    assert ended >= 3 * k - 2 and flipped <= 2
     eng.close()
 
 

@@ -103,19 +103,19 @@ def test_floor_check_window_and_render(oracle):
 def test_camera_level_drone_kat(oracle):
     # SURVEY §8a A7 [DERIVED]: level drone at (0,0,1): centre (0,-0.359), area 0.0173, ratio 1.415;
     # at (0,0,0.5): area 0.0157, ratio 1.458 (front face at x=4.98 shifts these in the 3rd digit)
-    vis, c, area, ratio = oracle.camera((0, 0, 1), (0, 0, 0, 1))
+    vis, c, area, ratio = oracle.camera((0, 0, 1), (0, 0, 0, 1), "analytic")
     assert vis == 1 and abs(c[0]) < 1e-12
     assert abs(c[1] + 0.359) < 5e-3 and abs(area - 0.0173) < 3e-4 and abs(ratio - 1.415) < 1e-2
-    vis, c, area, ratio = oracle.camera((0, 0, 0.5), (0, 0, 0, 1))
+    vis, c, area, ratio = oracle.camera((0, 0, 0.5), (0, 0, 0, 1), "analytic")
     assert vis == 1 and abs(area - 0.0157) < 3e-4 and abs(ratio - 1.458) < 1e-2
 
 
 def test_camera_invisible_cases(oracle):
     # facing away (yaw pi): panel behind the camera
-    assert oracle.camera((0, 0, 1), oracle.quat_from_euler((0, 0, math.pi)))[0] == 0
+    assert oracle.camera((0, 0, 1), oracle.quat_from_euler((0, 0, math.pi)), "analytic")[0] == 0
     # pitched nose-down 60 deg: panel leaves the top of the frame
-    assert oracle.camera((0, 0, 1), oracle.quat_from_euler((0, 1.05, 0)))[0] == 0
-    vis, c, area, ratio = oracle.camera((0, 0, 1), oracle.quat_from_euler((0, 1.05, 0)))
+    assert oracle.camera((0, 0, 1), oracle.quat_from_euler((0, 1.05, 0)), "analytic")[0] == 0
+    vis, c, area, ratio = oracle.camera((0, 0, 1), oracle.quat_from_euler((0, 1.05, 0)), "analytic")
     assert (c == 0).all() and area == 0 and ratio == 0
 
 

@@ -156,7 +156,7 @@ def test_persistent_rollout_equals_step_by_step(oracle, n, T):
     try:
         cols = []
         for pers in (True, False):
-            eng = FpvEngine(n, 0, seed=2)
+            eng = FpvEngine(n, 0, seed=2, detector="analytic")   # (the persistent launch serves the analytic detector only)
             # eager launches: graph capture runs a warm-up outside the capture (one step, or one whole rollout in the persistent
             # shape), which would leave the two collectors a different number of steps into their episodes
             cols.append(RolloutCollector(eng, _policy(4), n_steps=T, policy_seed=9, persistent=pers, one_launch=True, use_graph=False))
@@ -184,7 +184,9 @@ def test_persistent_refuses_more_workgroups_than_cus():
     from fpv_drone_rl_agent_amd.rollout import RolloutCollector
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     with pytest.raises(ValueError, match="persistent"):
-        RolloutCollector(FpvEngine(256 * (cus + 1), 0), _policy(), n_steps=4, persistent=True)
+        RolloutCollector(FpvEngine(256 * (cus + 1), 0, detector="analytic"), _policy(), n_steps=4, persistent=True)
+    with pytest.raises(ValueError, match="persistent"):        # ... and the analytic detector only
+        RolloutCollector(FpvEngine(1024, 0), _policy(), n_steps=4, persistent=True)
 
 
 def test_persistent_rollout_replays_from_a_graph(oracle):
@@ -193,7 +195,7 @@ def test_persistent_rollout_replays_from_a_graph(oracle):
     from fpv_drone_rl_agent_amd.engine import FpvEngine
     from fpv_drone_rl_agent_amd.rollout import RolloutCollector
     n, T = 65536, 8
-    eng = FpvEngine(n, 0, seed=1)
+    eng = FpvEngine(n, 0, seed=1, detector="analytic")
     col = RolloutCollector(eng, _policy(2), n_steps=T, persistent=True)
     col.start()
     _synthetic(eng, oracle, 7)
@@ -207,8 +209,9 @@ def test_persistent_rollout_replays_from_a_graph(oracle):
             assert not torch.equal(prev, b["values"])
         prev = b["values"].clone()
     assert col._graph is not None
-    assert eng.get_tick() == t0 + 5 * T          # two captures (the collector alternates between two graphs), each with a
-                                                 # warm-up rollout, + three replays
+    assert col._graphs[0] is not None and col._graphs[1] is not None
+    assert eng.get_tick() == t0 + 4 * T          # ONE warm-up rollout before both of the collector's alternating graphs are
+                                                 # captured (no discarded step after the first rollout), + three replays
     assert col.episodes["count"] > 0             # reading the episode numbers checks the status words (timeout flag clear)
 
 
@@ -223,7 +226,7 @@ def test_persistent_rollout_gives_up_cleanly_when_a_grid_wait_times_out(oracle):
     n, T = 65536, 6
     try:
         lib.fpv_debug_rollout_timeout(1)
-        col = RolloutCollector(FpvEngine(n, 0, seed=4), _policy(3), n_steps=T, persistent=True, use_graph=False)
+        col = RolloutCollector(FpvEngine(n, 0, seed=4, detector="analytic"), _policy(3), n_steps=T, persistent=True, use_graph=False)
         col.start()
         col.collect()
         torch.cuda.synchronize()                 # returns: the launch ended although its barrier never completed
@@ -231,7 +234,7 @@ def test_persistent_rollout_gives_up_cleanly_when_a_grid_wait_times_out(oracle):
             _ = col.episodes
     finally:
         lib.fpv_debug_rollout_timeout(0)
-    col = RolloutCollector(FpvEngine(n, 0, seed=4), _policy(3), n_steps=T, persistent=True, use_graph=False)
+    col = RolloutCollector(FpvEngine(n, 0, seed=4, detector="analytic"), _policy(3), n_steps=T, persistent=True, use_graph=False)
     col.start()
     _synthetic(col.engine, oracle, 6)
     col.collect()
@@ -341,3 +344,31 @@ def test_rollout_begin_clears_the_ledger_and_carries_the_episode_starts():
         eng.rollout_begin()
         assert int(eng.led_count.abs().sum()) == 0 and torch.equal(dst, src)
         eng.close()
+
+
+def test_both_graphs_are_captured_before_the_first_rollout(oracle):
+    """The collector alternates between two captured graphs.  Both are captured — behind ONE eager warm-up step — when the first
+    rollout is requested, so no env step is discarded after training has started: from then on the tick advances by exactly
+    n_steps per collect(), the statistics count grows by exactly n_steps x num_envs, and rollout r + 1 starts from the
+    observation rollout r ended with."""
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.rollout import RolloutCollector
+    n, T = 4096, 6
+    eng = FpvEngine(n, 0, seed=3)
+    col = RolloutCollector(eng, _policy(1), n_steps=T)
+    col.start()
+    _synthetic(eng, oracle, 2)
+    t0 = eng.get_tick()
+    col.collect()
+    torch.cuda.synchronize()
+    assert col._graphs[0] is not None and col._graphs[1] is not None
+    assert eng.get_tick() == t0 + 1 + T                       # the one warm-up step + the first rollout
+    count1 = float(col.obs_norm.rms[40])
+    last_obs = col.cur_obs.clone()
+    for r in range(3):
+        b = col.collect()
+        torch.cuda.synchronize()
+        assert torch.equal(b["obs"][0], last_obs)              # nothing happened to the env between two rollouts
+        last_obs = col.cur_obs.clone()
+    assert eng.get_tick() == t0 + 1 + 4 * T
+    assert float(col.obs_norm.rms[40]) == count1 + 3 * T * n

@@ -10,6 +10,8 @@ to 1e-10 and carries the trajectory-level checks.  PyFlyt parity itself is unpin
 import numpy as np
 import pytest
 
+from tests import parity
+
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
@@ -71,22 +73,27 @@ def test_fp32_single_step_matches_oracle(oracle, noise):
     # integer masks: bit-exact
     assert (term == term_r).all() and (trunc == trunc_r).all()
     assert 0 < int(term.sum() + trunc.sum()) < n  # the synthetic batch exercises both outcomes
+    # The default detector is the reference's pixel rules (SPEC §6b): rows whose rasterisation differs by one pixel between
+    # fp32 and the fp64 oracle are found, bounded in number and size (tests/parity.py) and excluded from the feature words
+    # below; everything else is held to 1e-5.  Rows that auto-reset return the reset observation: no flip there.
+    flips = parity.pixel_flips(obs, obs_r)
     # float state within 1e-5
-    ok = _close(st, st_ref, 1e-5)
+    ok = parity.state_close_except_flips(st, st_ref, flips)
     assert ok.all(), f"state mismatch at words {np.unique(np.where(~ok)[1])}, max {np.abs(st - st_ref).max()}"
     # obs[0:3] = wrap(d euler) / agent_dt (hover.py:230): compared as the angle difference itself, at the same 1e-5 bar
     tol = np.full(20, 1e-5)
     scale = np.ones(20); scale[0:3] = 0.025
-    assert _close(obs * scale, obs_r * scale, tol).all(), np.abs(obs * scale - obs_r * scale).max(axis=0)
-    assert _close(rew, rew_r, 2e-5).all()
+    assert parity.obs_close_except_flips(obs, obs_r, flips, tol, scale).all(), np.abs(obs * scale - obs_r * scale).max(axis=0)
+    assert _close(rew[~flips], rew_r[~flips], 2e-5).all()
     # done ledger: same rows (order free), terminal observation and Monitor episode stats
     got = eng.ledger_read()
     idx_r, info_r, ret_r, tobs_r = led.rows()
     assert got["count"] == len(idx_r)
     assert (got["idx"] == idx_r).all() and (got["info"] == info_r).all()
     assert (got["tag"] == tick).all()
-    assert _close(got["ep_return"], ret_r, 2e-5).all()
-    assert _close(got["obs"] * scale, tobs_r * scale, tol).all()
+    lflips = parity.pixel_flips(got["obs"], tobs_r)          # terminal observations carry camera features too
+    assert _close(got["ep_return"][~lflips], ret_r[~lflips], 2e-5).all()
+    assert parity.obs_close_except_flips(got["obs"], tobs_r, lflips, tol, scale).all()
     eng.close()
 
 

@@ -18,7 +18,7 @@ from fpv_drone_rl_agent_amd.rollout import RolloutCollector  # noqa: E402
 
 n, T = int(os.environ.get("DRONES", 65536)), int(os.environ.get("NSTEPS", 32))
 torch.manual_seed(0)
-eng = FpvEngine(n, 0, noise_ratio=0.02, seed=0, ledger_capacity=n * max(2, T // 8))
+eng = FpvEngine(n, 0, noise_ratio=0.02, seed=0, ledger_capacity=n * max(2, T // 8), detector=os.environ.get("DETECTOR", "pixel"))
 persistent = os.environ.get("SHAPE", "step") == "rollout"
 col = RolloutCollector(eng, ActorCritic().cuda(), n_steps=T, persistent=persistent, one_launch=True)
 col.start()
@@ -26,7 +26,7 @@ eng.set_state(torch.from_numpy(synthetic_states(n, seed=0)))
 for _ in range(4):
     col.collect()
 grid = n // 256
-stamps = torch.zeros((grid, T, 8), dtype=torch.int64, device="cuda")
+stamps = torch.zeros((grid, T, 8) if persistent else (grid, 16), dtype=torch.int64, device="cuda")
 L.load().fpv_debug_rollout_stamps(C.c_void_p(stamps.data_ptr()))
 col._graph = None            # the stamp pointer is a kernel argument: capture again
 col.collect()
@@ -46,7 +46,7 @@ if persistent:
     arrive = s[:, :T - 1, 3]
     out["arrival_skew_us"] = round(float(np.median(arrive.max(axis=0) - arrive.min(axis=0))), 2)
 else:
-    s = s.reshape(-1, 8)[:grid]                                # the last launch of the last rollout
+    # (the last launch of the last rollout)
     names = ["staging + statistics merge", "policy (normalise, pi, V, sample)", "env step + bookkeeping"]
     for k, nm in enumerate(names):
         dt = s[:, k + 1] - s[:, k]
@@ -57,6 +57,14 @@ else:
           "helper: tile store + moment sums -> barrier 7"]
     edges = [s[:, 2], s[:, 4], s[:, 5], s[:, 6], s[:, 7]]
     out["env step, physics wave"] = {nm: round(float(np.median(edges[k + 1] - edges[k])), 2) for k, nm in enumerate(tn)}
+    if eng.detector == "pixel":
+        # pixel detector: [8] corners published (before barrier P), [9] own rows walked, [10] barrier Q passed, [11] features done;
+        # helper wave of tile 0: [12] barrier P passed, [13] its rows walked
+        med = lambda a, b: round(float(np.median(s[:, b] - s[:, a])), 2)
+        out["pixel detector, physics wave"] = {"corner projection, barrier P0, euler (the helper posts the items meanwhile)": med(4, 8), "its work items": med(8, 9),
+                                               "wait for the workgroup (barrier Q)": med(9, 10), "merge + vertices + gates": med(10, 11),
+                                               "observation + reward": med(11, 5)}
+        out["pixel detector, helper wave"] = {"its work items": med(12, 13), "p90": round(float(np.percentile(s[:, 13] - s[:, 12], 90)), 2)}
     out["workgroup"] = {"median_us": round(float(np.median(s[:, 3] - s[:, 0])), 2)}
     out["launch_first_start_to_last_end_us"] = round(float(s[:, 3].max() - s[:, 0].min()), 2)
     out["start_skew_us"] = round(float(s[:, 0].max() - s[:, 0].min()), 2)
