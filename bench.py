@@ -86,15 +86,54 @@ def cpu_baseline(n: int, seed: int, budget_s: float = 9.0, detector: str = "pixe
     # "all cores": every usable core; where the box shares its cores (more threads than this container is really given)
     # fewer threads can be faster, so 64 and 16 are tried too and the best count is the one reported and stated
     tries = sorted({usable, min(usable, 64), min(usable, 16)}, reverse=True)
-    probe = {c: sample(n, c, 1.5)[0] for c in tries} if len(tries) > 1 else {usable: 0.0}
-    cores = max(probe, key=probe.get)
+    probe = {c: round(sample(n, c, 1.5)[0]) for c in tries} if len(tries) > 1 else None
+    cores = max(probe, key=probe.get) if probe else usable
     v_all, k_all, t_all = sample(n, cores, budget_s)
     v_one, k_one, t_one = sample(4096, 1, budget_s)
     return {"value": v_all, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"oracle/fpv_oracle.c env-step only (no policy, detector={detector}), {n} drones x {k_all} steps, OpenMP {cores} threads "
-                      f"(host reports {host} cores, {usable} usable; thread counts probed {probe}), {t_all:.1f} s",
+                      f"(host reports {host} cores, {usable} usable" + (f"; thread counts probed {probe}" if probe else "") + f"), {t_all:.1f} s",
             "single_thread": {"value": v_one, "unit": "env-steps/s", "cores": 1,
                               "sample": f"4096 drones x {k_one} steps, 1 thread, {t_one:.1f} s"}}
+
+
+def host_mode_rate(n: int = 4096, steps: int = 200):
+    """BASELINE configs[1]: 4 096 hover drones, HIP dynamics kernel, policy on the CPU — FpvVecEnv's host (numpy) mode under
+    VecNormalize, the way stock SB3 would drive it (simulation/train_hover.py:42-43): per step one torch-CPU forward of
+    MlpPolicy [128, 128] on the normalised observations, one H2D of the actions, the env-step kernel, one D2H of observations /
+    rewards / flags (+ the finished episodes' ledger rows).  PCIe-inclusive by construction: not the headline."""
+    import numpy as np
+    import torch
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    from fpv_drone_rl_agent_amd.vec_env import FpvVecEnv, VecNormalize
+    env = VecNormalize(FpvVecEnv(n, noise_ratio=0.02, seed=0))
+    torch.manual_seed(0)
+    pol = ActorCritic()                                          # on the CPU
+    obs = env.reset()
+    t_pol = 0.0
+
+    def one(obs):
+        nonlocal t_pol
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            o = torch.from_numpy(np.ascontiguousarray(obs, dtype=np.float32))
+            a, _, _ = pol.act(o, torch.randn(n, 4))
+        act = a.clamp(-1.0, 1.0).numpy()
+        t_pol += time.perf_counter() - t0
+        return env.step(act)[0]
+
+    for _ in range(20):
+        obs = one(obs)
+    t_pol = 0.0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        obs = one(obs)
+    dt = time.perf_counter() - t0
+    env.close()
+    return {"value": n * steps / dt, "unit": "env-steps/s", "drones": n, "us_per_step": round(dt / steps * 1e6, 1),
+            "us_per_step_policy_on_cpu": round(t_pol / steps * 1e6, 1), "cpu_threads_torch": torch.get_num_threads(),
+            "workload": "BASELINE.json configs[1]: 4 096 hover drones, HIP env-step kernel, torch-CPU MlpPolicy, numpy in / out through "
+                        "FpvVecEnv + VecNormalize (PCIe-inclusive)"}
 
 
 def plumbing_only(args) -> None:
@@ -146,6 +185,7 @@ def main() -> None:
                     help="yaw = BASELINE configs[4] (yaw-setpoint task with domain randomisation); not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split-extra", action="store_true", help="skip the extra bf16x6-policy measurement")
+    ap.add_argument("--no-host-mode", action="store_true", help="skip the extra BASELINE configs[1] (host numpy mode) measurement")
     ap.add_argument("--kernel-launches", type=int, default=200)
     ap.add_argument("--plumbing-only", action="store_true",
                     help="no GPU work: rendezvous, argument / rank checks, the barrier + MAX-over-ranks timing and the one "
@@ -247,7 +287,7 @@ def main() -> None:
     # node inside the replayed graph).  `roofline` is the kernel that dominates the timed region by time (the fused
     # actor-critic forward, MFMA-bound); `roofline_env_step` is the HBM-bound dynamics kernel BASELINE's "% HBM
     # roofline" refers to, as it runs in the rollout (with the VecNormalize bookkeeping fused in) and stand-alone.
-    roofline = roofline_env = roofline_env_plain = roofline_env_fused = None
+    roofline = roofline_env = roofline_env_plain = roofline_env_fused = out_hbm_whole = None
     if True:   # every rank runs the same passes (collect() contains the collective); only rank 0 reports them
         L = args.kernel_launches
         act = torch.rand((n, eng.act_words), device=dev) * 2 - 1
@@ -359,30 +399,41 @@ def main() -> None:
                     in_graph, us_one = {}, ev_one                        # tracer output implausible: trust the events
                 how = "device timestamps of the launches inside the replayed rollout graph" if in_graph else \
                       "HIP events around back-to-back launches"
-                # One launch per step on one stream: a launch cannot last longer than the step cadence of the timed region
-                # (the activity tracer's own per-kernel overhead stretches the traced replay; rocprofv3 reads 62 us).
-                us_traced, cadence = us_one, elapsed / K * 1e6
-                if us_one > cadence:
-                    us_one, how = cadence, how + ", capped at the timed region's own time per step"
+                # us_per_launch is what was MEASURED for the kernel (nothing is capped or substituted); the timed region's own
+                # time per step stands beside it (one launch per step on one stream: the kernel cannot really be longer than
+                # that — the activity tracer stretches the replay it traces — and `frac_upper_bound_from_step_cadence` is the
+                # fraction that figure would give, published separately and named for what it is)
+                cadence = elapsed / K * 1e6
                 phases = kernel_phases() if world == 1 else None      # (extra captures + collects: kept off the multi-rank runs)
-                # the kernel's algorithmic work: the policy's matrix flops AND the env step's vector flops — fp32 both, and the
-                # fp32-input MFMA peak is the vector fp32 peak (MI355X_MICROARCH.md), so one roofline prices both
-                flop = (pol_flop + env_flop) * n
-                tf = flop / us_one / 1e6
+                tf = pol_flop * n / us_one / 1e6                         # MFMA work only: what `bound: mfma` prices
+                tf_all = (pol_flop + env_flop) * n / us_one / 1e6
                 roofline = {"bound": "mfma", "kernel": "fpv::rollout_step_kernel<%d>" % (1 if yaw else 0), "achieved": round(tf, 1),
                             "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
                             "traffic": None if yaw else traffic_of("fpv::rollout_step_kernel"), "us_per_launch": round(us_one, 2),
-                            "launches": L, "algorithmic_flop_per_launch": flop,
-                            "algorithmic_flop_per_drone": {"policy (MFMA)": pol_flop, "env step (VALU, counted)": env_flop or None},
-                            "frac_policy_flops_only": round(pol_flop * n / us_one / 1e6 / MFMA_F32_PEAK_TFLOPS, 4), "dtype": "f32",
+                            "launches": L, "algorithmic_flop_per_launch": pol_flop * n,
+                            "algorithmic_flop_per_drone": {"policy (MFMA)": pol_flop, "env step (VALU, counted, not in frac)": env_flop or None},
+                            "frac_fp32_pipe_incl_env_step_valu_flops": round(tf_all / MFMA_F32_PEAK_TFLOPS, 4), "dtype": "f32",
                             "measured": how, "us_per_launch_hip_events_back_to_back": round(ev_one, 2),
-                            "us_per_launch_traced": round(us_traced, 2), "us_per_step_timed_region": round(cadence, 2)}
-                roofline["note"] = ("one kernel per rollout step: actor-critic forward (the matrix work priced here) AND the env step of "
-                                    "the same drones (vector work, `phases`); peak = dense fp32-input MFMA rate (155 TF measured with "
-                                    "resident operands at a 2.38 GHz in-kernel clock, profiles/r02_mfma_peak.txt); vector instructions do "
-                                    "not co-execute with fp32-input MFMA (profiles/r02_mfma_valu_mix.txt), so tanh / heads / sampling "
-                                    "add to the product time (profiles/r02_policy_phase_stamps.md)")
+                            "us_per_step_timed_region": round(cadence, 2),
+                            "frac_upper_bound_from_step_cadence": round(pol_flop * n / min(us_one, cadence) / 1e6 / MFMA_F32_PEAK_TFLOPS, 4)}
+                roofline["note"] = ("one kernel per rollout step: actor-critic forward (the matrix work `frac` prices: MFMA flops only over the "
+                                    "WHOLE kernel's measured duration) AND the env step of the same drones (vector work on the same fp32 pipe; "
+                                    "`frac_fp32_pipe_incl_env_step_valu_flops` adds its counted flops); peak = dense fp32-input MFMA rate (155 TF "
+                                    "measured with resident operands at a 2.38 GHz in-kernel clock, profiles/r02_mfma_peak.txt); vector "
+                                    "instructions do not co-execute with fp32-input MFMA (profiles/r02_mfma_valu_mix.txt), so tanh / heads / "
+                                    "sampling add to the product time (profiles/r02_policy_phase_stamps.md)")
                 roofline["traffic_source"] = "profiles/kernel_traffic.json (rocprofv3 --pmc passes of this command; not collectable in-process)"
+                # the same kernel on the HBM roofline: every byte it must move (SURVEY §8d full-rollout figure minus the GAE pass that
+                # runs once per rollout: 20-word observation in, rollout-buffer row out, state r + w, next observation, reward,
+                # flags, return accumulator) over the whole kernel's measured duration
+                k0_bytes = 563 if not yaw else None
+                if k0_bytes:
+                    out_hbm_whole = hbm("fpv::rollout_step_kernel<0> (whole kernel)", us_one, k0_bytes)
+                    out_hbm_whole.update(traffic=traffic_of("fpv::rollout_step_kernel"), measured=how,
+                                         note="563 B per drone and step over the WHOLE kernel's duration: the kernel is bound by the fp32 "
+                                              "pipe (policy products), not by HBM; this is the honest HBM figure of the rollout step")
+                else:
+                    out_hbm_whole = None
                 if phases:
                     roofline["phases_us"] = phases
                     pol = phases.get("policy (normalise, pi, V, sample)")
@@ -390,9 +441,13 @@ def main() -> None:
                         roofline["frac_of_peak_within_policy_phase"] = round(pol_flop * n / pol / 1e6 / MFMA_F32_PEAK_TFLOPS, 4)
                     envp = phases.get("env step + bookkeeping")
                     if envp:
-                        roofline_env = hbm("env-step phase of fpv::rollout_step_kernel", envp, env_bytes)
-                        roofline_env.update(traffic=None, measured="in-kernel s_memrealtime stamps, median over workgroups "
-                                            "(the drone state is requested under the matrix work; this is the exposed part)")
+                        # NOT a bandwidth measurement: the drone state was requested ~45 us earlier, under the matrix work, so the
+                        # phase's bytes are not moved inside the phase — reported as a duration only
+                        roofline_env = {"kernel": "env-step phase of fpv::rollout_step_kernel", "exposed_phase_us": envp,
+                                        "measured": "in-kernel s_memrealtime stamps, median over workgroups",
+                                        "note": "duration of the phase only; no bandwidth fraction is claimed for it (its state loads were "
+                                                "issued under the policy phase) — see roofline_hbm_whole_kernel and "
+                                                "roofline_env_step_unfused for HBM figures"}
                 roofline_env_fused = hbm("fpv::yaw_step_kernel<float,true,true>" if yaw else "fpv::step_kernel<float,true,true>", ev_fused, env_bytes)
                 roofline_env_fused.update(measured="HIP events around back-to-back launches (the stand-alone fpv_step_fused kernel; "
                                                    "not launched by the default rollout)")
@@ -461,8 +516,10 @@ def main() -> None:
             "roofline": roofline,
         }
         if roofline_env is not None:
-            out["roofline_env_step"] = roofline_env
+            out["env_step_phase" if "exposed_phase_us" in roofline_env else "roofline_env_step"] = roofline_env
             out["roofline_env_step_unfused"] = roofline_env_plain
+        if out_hbm_whole is not None:
+            out["roofline_hbm_whole_kernel"] = out_hbm_whole
         if roofline_env_fused is not None:
             out["roofline_env_step_standalone_fused"] = roofline_env_fused
         if split_value is not None:
@@ -473,6 +530,8 @@ def main() -> None:
             out.setdefault("extra", {})["value_f64_env"] = f64_value
             out["extra"]["value_f64_env_note"] = ("env-steps/s of fpv_step on an FPV_F64 handle (env step only, no policy, HIP events over "
                                                   f"{args.kernel_launches} launches): the reference's arithmetic type")
+        if world == 1 and not yaw and not args.no_host_mode:
+            out.setdefault("extra", {})["cfg1_host_mode"] = host_mode_rate()
         if world == 1 and not args.no_cpu_baseline and not yaw:
             out["cpu_baseline"] = cpu_baseline(n, seed=0, detector=args.detector)
         print(json.dumps(out), flush=True)

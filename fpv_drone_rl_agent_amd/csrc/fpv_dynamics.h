@@ -734,13 +734,12 @@ __device__ __forceinline__ bool camera_features_pixel(const Drone<T>& d, T& cx, 
     return ok && vis;
 }
 
-// Observation of hover.py:237-272 into o[20] from the camera features of the caller; updates the feature memory.
+// obs[0:7] of hover.py:224-235: finite-difference Euler rates over agent_dt and the quaternion of the Euler angles
 template <typename T>
-__device__ __forceinline__ void observe_with(Drone<T>& d, T roll, T pitch, T yaw, T a0, T a1, T a2, T a3, T (&o)[kObsWords],
-                                             bool vis, T cx, T cyy, T area, T ratio) {
-    o[0] = wrap_angle(roll - d.er) * C<T>::inv_agent_dt;   // hover.py:228-230
-    o[1] = wrap_angle(pitch - d.ep) * C<T>::inv_agent_dt;
-    o[2] = wrap_angle(yaw - d.eyaw) * C<T>::inv_agent_dt;
+__device__ __forceinline__ void observe_attitude(T er, T ep, T eyaw, T roll, T pitch, T yaw, T (&o)[7]) {
+    o[0] = wrap_angle(roll - er) * C<T>::inv_agent_dt;     // hover.py:228-230
+    o[1] = wrap_angle(pitch - ep) * C<T>::inv_agent_dt;
+    o[2] = wrap_angle(yaw - eyaw) * C<T>::inv_agent_dt;
     T sr, cr, sp, cp, sy, cy;                              // hover.py:233
     sincos_half_(T(0.5) * roll, &sr, &cr);
     sincos_half_(T(0.5) * pitch, &sp, &cp);
@@ -749,13 +748,30 @@ __device__ __forceinline__ void observe_with(Drone<T>& d, T roll, T pitch, T yaw
     o[4] = cr * sp * cy + sr * cp * sy;
     o[5] = cr * cp * sy - sr * sp * cy;
     o[6] = cr * cp * cy + sr * sp * sy;
-    o[7] = cx; o[8] = cyy;                                 // hover.py:253-267
+}
+
+// obs[7:20] of hover.py:253-267 from the camera features of the caller and the raw action; updates the feature memory.
+template <typename T>
+__device__ __forceinline__ void observe_features(Drone<T>& d, T a0, T a1, T a2, T a3, T (&o)[kObsWords], bool vis, T cx, T cyy, T area,
+                                                 T ratio) {
+    o[7] = cx; o[8] = cyy;
     o[9] = d.prev_cx; o[10] = d.prev_cy;
     o[11] = area; o[12] = d.prev_area;
     o[13] = vis ? T(1) : T(0);
     o[14] = ratio; o[15] = d.prev_ratio;
     o[16] = a0; o[17] = a1; o[18] = a2; o[19] = a3;
     d.prev_cx = cx; d.prev_cy = cyy; d.prev_area = area; d.prev_ratio = ratio;  // hover.py:270-272
+}
+
+// Observation of hover.py:237-272 into o[20] from the camera features of the caller; updates the feature memory.
+template <typename T>
+__device__ __forceinline__ void observe_with(Drone<T>& d, T roll, T pitch, T yaw, T a0, T a1, T a2, T a3, T (&o)[kObsWords],
+                                             bool vis, T cx, T cyy, T area, T ratio) {
+    T att[7];
+    observe_attitude(d.er, d.ep, d.eyaw, roll, pitch, yaw, att);
+#pragma unroll
+    for (int j = 0; j < 7; ++j) o[j] = att[j];
+    observe_features(d, a0, a1, a2, a3, o, vis, cx, cyy, area, ratio);
 }
 
 // The same with the camera features computed here by the handle's detector.  Returns visible.

@@ -56,7 +56,8 @@ static_assert(kRsSum + 2 * 4 * kPartialWords <= 2 * kNetFloats, "phase-2 exchang
 // Pixel detector (hover.py:157-222, SPEC §6b): the blob's rows as work items of the tile's two waves.  Per tile, above the rest
 // of the phase-2 map: the corner block [5][64] f32x4 (u, v, edge slopes, vertex rows, {first span-table entry, jlo, jhi} of
 // every drone), the drones' integer accumulators, the item list (kPixItems packed words + the item count) and the span table.
-constexpr int kPixItems = 256;                              // >= rows / chunk + 3 segments x 64 drones for every chunk size chosen
+constexpr int kPixItems = 512;                              // >= rows / chunk + 3 segments x 64 drones for every chunk size chosen
+constexpr int kPixChunkShift = 2;                           // rows per item: 2^shift, more in a tile whose items would not fit the list
 constexpr int kPixAcc = 5 * kTile * 4;                      // floats from the tile's base: behind the corner block [5][64] f32x4
 constexpr int kPixSlots = kPixAcc + 3 * kTile * 4;          // per-drone accumulators [3][64] int4, then the item list
 constexpr int kPixTab = kPixSlots + kPixItems + 4;          // item list: kPixItems packed items, then the item count; then the span table
@@ -258,8 +259,9 @@ struct TailOut {
     bool row_write_through;  // publish the row with sc1 stores + drain (read by other workgroups inside this launch)
     bool store_state;        // the physics wave stores its tile's state and tick itself, ahead of barrier 6 (one-step kernel)
     uint64_t* stamps;        // diagnostic: s_memrealtime values of tile 0's waves, or null: [0..3] physics wave: pairs done, observed,
-                             // barrier 6, 7; pixel detector: [4] corners published, [5] own rows walked, [6] barrier Q passed, [7] features done;
-                             // [8] helper: barrier P passed, [9] helper: its rows walked
+                             // barrier 6, 7; pixel detector: [4] corners projected, border pre-check done, [5] item list posted (before
+                             // barrier P), [6] P passed, [7] own items done, [8] barrier Q passed, [9] features done; helper wave:
+                             // [10] attitude converted (before barrier P), [11] its items done
 };
 
 // Physics-wave registers that live across steps in the persistent kernel; the one-step kernel loads / stores them around
@@ -282,16 +284,13 @@ __device__ __forceinline__ int wave_scan_inclusive(int x) {
     return x;
 }
 
-// Helper wave, one lane per drone: cut the drone's rows [jlo, jhi] at the rows where a vertex passes (between two cuts the same
-// two edges cross every row) and into chunks of at most 2^sh rows — eight, or more in a tile with so many rows that the list
+// Physics wave, one lane per drone: cut the drone's rows [jlo, jhi] at the rows where a vertex passes (between two cuts the same
+// two edges cross every row) and into chunks of at most 2^sh rows — four, or more in a tile with so many rows that the list
 // would overflow — and append the items (drone | first row << 8 |
 // last row << 16) at this lane's place in the list.  Leaves the vertex rows and {first entry of the drone in the span table, jlo,
 // jhi} in the corner block.  A lane without rows (jlo > jhi) appends nothing.
-__device__ __forceinline__ void pixel_post_items(float* pix, int lane) {
+__device__ __forceinline__ void pixel_post_items(float* pix, int lane, const float (&v)[4], int ilo, int ihi) {
     f32x4* cb = reinterpret_cast<f32x4*>(pix);
-    const f32x4 qv = cb[kTile + lane], qr = cb[4 * kTile + lane];
-    const float v[4] = {qv.x, qv.y, qv.z, qv.w};
-    const int ilo = (int)qr.x, ihi = (int)qr.y;
     int c[4];
     pixel_vertex_rows(v, c);
     const int lo1 = min(c[0], c[1]), hi1 = max(c[0], c[1]), lo2 = min(c[2], c[3]), hi2 = max(c[2], c[3]);
@@ -301,8 +300,8 @@ __device__ __forceinline__ void pixel_post_items(float* pix, int lane) {
     const int rows = max(ihi - ilo + 1, 0);
     const int rows_incl = wave_scan_inclusive(rows);
     const int tile_rows = __builtin_amdgcn_readlane(rows_incl, 63);
-    int sh = 3;                                                // chunks of 8 rows at least
-    while ((64 << sh) < tile_rows) ++sh;                       // items <= rows / 2^sh + 3 x 64 <= kPixItems
+    int sh = kPixChunkShift;
+    while (((kPixItems - 3 * kTile) << sh) < tile_rows) ++sh;  // items <= rows / 2^sh + 3 x 64 <= kPixItems
     const int ch1 = (1 << sh) - 1;
     const int n0 = (l0 + ch1) >> sh, n1 = (l1 + ch1) >> sh, n2 = (l2 + ch1) >> sh, items = n0 + n1 + n2;
     const int incl = wave_scan_inclusive(items);
@@ -352,8 +351,11 @@ __device__ __forceinline__ void pixel_work_items(float* pix, int worker) {
     }
 }
 
-// Called by all 512 threads after the clipped actions are in LDS (kRsAct) and a workgroup barrier.  Contains eight (eleven with the pixel detector)
-// workgroup barriers on every path.  On return the four observation tiles (+ returns) are still in LDS (kRsTile).
+// Called by all 512 threads after the clipped actions are in LDS (kRsAct) and a workgroup barrier.  Contains eight (eleven with the
+// pixel detector) workgroup barriers on every path.  On return the four observation tiles (+ returns) are still in LDS (kRsTile).
+// (Measured and not kept: a two-party LDS arrival counter per tile in place of the workgroup barriers between a tile's two waves —
+// no waiting for the slowest of the four tiles at every hand-off, but each hand-off then costs an LDS poll: 68.45 vs 68.63 us per
+// step, the physics loop 5.9 -> 6.3 us.)
 __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, TileRegs& tr, const TailOut& o_) {
     using T = float;
     const int lane = threadIdx.x & (kTile - 1), wave = threadIdx.x >> 6;
@@ -380,12 +382,21 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
             lds_barrier();
         }
         if (s.detector) {                                  // uniform: the pixel detector's rows are work items of both waves
-            lds_barrier();                                 // barrier P0: the physics wave has projected the corners
-            pixel_post_items(pix, lane);                   // ... and computes the Euler angles while this wave builds the item list
+            lds_barrier();                                 // barrier P0: attitude and previous Euler angles of the tile's drones are in LDS
+            {   // This wave converts the attitude (Euler angles, obs[0:7]) while the physics wave prepares the detector's work items.
+                f32x4* att = reinterpret_cast<f32x4*>(nz);  // the noise slots are free once pair 5 has been read
+                const f32x4 q = att[lane], pe = att[kTile + lane];
+                T roll, pitch, yaw, o7[7];
+                euler_from_quat(q.x, q.y, q.z, q.w, roll, pitch, yaw);
+                observe_attitude(pe.x, pe.y, pe.z, roll, pitch, yaw, o7);
+                att[lane] = f32x4{roll, pitch, yaw, o7[0]};
+                att[kTile + lane] = f32x4{o7[1], o7[2], o7[3], o7[4]};
+                att[2 * kTile + lane] = f32x4{o7[5], o7[6], 0.f, 0.f};
+            }
+            if (o_.stamps && threadIdx.x == 256) o_.stamps[10] = __builtin_amdgcn_s_memrealtime();
             lds_barrier();                                 // barrier P: corner block and item list of this tile are in LDS
-            if (o_.stamps && threadIdx.x == 256) o_.stamps[8] = __builtin_amdgcn_s_memrealtime();
             pixel_work_items(pix, kTile + lane);
-            if (o_.stamps && threadIdx.x == 256) o_.stamps[9] = __builtin_amdgcn_s_memrealtime();
+            if (o_.stamps && threadIdx.x == 256) o_.stamps[11] = __builtin_amdgcn_s_memrealtime();
             lds_barrier();                                 // barrier Q: every item's run is in LDS
         }
         lds_barrier();   // barrier 6: the physics wave has staged the observation tile (and the returns)
@@ -446,11 +457,15 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
         // Pixel detector (hover.py:157-222, SPEC §6b).  A drone's blob is 0 .. ~45 image rows and a third of the drones see the
         // panel at all: one lane walking its own drone's rows keeps the wave busy for the tallest blob while most lanes idle
         // (measured: 35 rows per tile against 7.8 per drone), and the helper wave has nothing to do until barrier 6.  So the rows
-        // become work items of BOTH waves: this wave projects the corners; the helper cuts every drone's rows where a vertex
-        // passes and into chunks, and posts the items (this wave converts the attitude meanwhile); the 128 lanes each walk an
-        // item — with the two edges that cross its rows, not four edge tests per row — leaving a PixelRun and the rows' spans;
-        // this wave concatenates its drones' runs in row order (pixel_merge: exact integers, the same features as one walk over
-        // all rows), searches the four vertices in the span table and applies the gates.
+        // become work items of BOTH waves: this wave projects the corners, drops the blobs that touch the image border (exact
+        // pre-check), cuts every other drone's rows where a vertex passes and into chunks, and posts the items — the helper
+        // converts the attitude (Euler angles, obs[0:7]) meanwhile; the 128 lanes each walk an item — with the two edges that
+        // cross its rows, not four edge tests per row — adding its run to the drone's accumulators and leaving the rows' spans;
+        // this wave then searches the four vertices in the span table and applies the gates.
+        f32x4* att = reinterpret_cast<f32x4*>(nz);        // the noise slots are free once pair 5 has been read
+        att[lane] = f32x4{d.qx, d.qy, d.qz, d.qw};
+        att[kTile + lane] = f32x4{d.er, d.ep, d.eyaw, 0.f};
+        lds_barrier();                                     // barrier P0: the helper converts the attitude from here on
         T u[4], v[4], sl[4], jlo, jhi;
         bool ok = pixel_setup(d, u, v, sl, jlo, jhi);
         if (pixel_touches_border(u, v, sl, jlo, jhi)) { ok = false; jlo = T(1); jhi = T(0); }     // invisible: no rows to walk
@@ -458,20 +473,25 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
         cb[lane] = f32x4{u[0], u[1], u[2], u[3]};
         cb[kTile + lane] = f32x4{v[0], v[1], v[2], v[3]};
         cb[2 * kTile + lane] = f32x4{sl[0], sl[1], sl[2], sl[3]};
-        cb[4 * kTile + lane] = f32x4{jlo, jhi, 0.f, 0.f};
         typedef int i32x4 __attribute__((ext_vector_type(4)));
         i32x4* acc = reinterpret_cast<i32x4*>(pix + kPixAcc);
         acc[lane] = i32x4{0, 0, 0, 0};                     // n, W, S, H
         acc[kTile + lane] = i32x4{-1000, 128, -1, 128};    // viol, amin, bmax, j0
         acc[2 * kTile + lane] = i32x4{-1, 0, 0, 0};        // jn
-        lds_barrier();                                     // barrier P0
-        euler_from_quat(d.qx, d.qy, d.qz, d.qw, roll, pitch, yaw);
         if (o_.stamps && threadIdx.x == 0) o_.stamps[4] = __builtin_amdgcn_s_memrealtime();
-        lds_barrier();                                     // barrier P
-        pixel_work_items(pix, lane);
+        pixel_post_items(pix, lane, v, (int)jlo, (int)jhi);
         if (o_.stamps && threadIdx.x == 0) o_.stamps[5] = __builtin_amdgcn_s_memrealtime();
-        lds_barrier();                                     // barrier Q
+        lds_barrier();                                     // barrier P
         if (o_.stamps && threadIdx.x == 0) o_.stamps[6] = __builtin_amdgcn_s_memrealtime();
+        pixel_work_items(pix, lane);
+        if (o_.stamps && threadIdx.x == 0) o_.stamps[7] = __builtin_amdgcn_s_memrealtime();
+        lds_barrier();                                     // barrier Q
+        if (o_.stamps && threadIdx.x == 0) o_.stamps[8] = __builtin_amdgcn_s_memrealtime();
+        {
+            const f32x4 t0 = att[lane], t1 = att[kTile + lane], t2 = att[2 * kTile + lane];
+            roll = t0.x; pitch = t0.y; yaw = t0.z;
+            o[0] = t0.w; o[1] = t1.x; o[2] = t1.y; o[3] = t1.z; o[4] = t1.w; o[5] = t2.x; o[6] = t2.y;
+        }
         const i32x4 a0 = acc[lane], a1 = acc[kTile + lane], a2 = acc[2 * kTile + lane];
         const int rowbase = (int)cb[4 * kTile + lane].x, ilo = (int)jlo;
         const uint16_t* tab = reinterpret_cast<const uint16_t*>(pix + kPixTab);
@@ -487,12 +507,16 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
         span(r.jn, r.pa, r.pb);
         const bool seen = pixel_finish(r, u, v, span, cam_x, cam_y, cam_area, cam_ratio);
         vis = ok && seen;
-        if (o_.stamps && threadIdx.x == 0) o_.stamps[7] = __builtin_amdgcn_s_memrealtime();
+        if (o_.stamps && threadIdx.x == 0) o_.stamps[9] = __builtin_amdgcn_s_memrealtime();
     } else {
         euler_from_quat(d.qx, d.qy, d.qz, d.qw, roll, pitch, yaw);
+        T o7[7];
+        observe_attitude(d.er, d.ep, d.eyaw, roll, pitch, yaw, o7);
+#pragma unroll
+        for (int j = 0; j < 7; ++j) o[j] = o7[j];
         vis = camera_features(d, cam_x, cam_y, cam_area, cam_ratio);
     }
-    observe_with(d, roll, pitch, yaw, act.x, act.y, act.z, act.w, o, vis, cam_x, cam_y, cam_area, cam_ratio);
+    observe_features(d, act.x, act.y, act.z, act.w, o, vis, cam_x, cam_y, cam_area, cam_ratio);
     uint32_t bits;
     const T reward = reward_and_flags(d, roll, pitch, vis, o, act.x, act.y, act.z, act.w, s.floor_check != 0, bits);
     d.er = roll; d.ep = pitch; d.eyaw = yaw;
@@ -774,7 +798,7 @@ __global__ __launch_bounds__(512) void rollout_step_kernel(RollStepArgs p) {
 //   grid is at most one workgroup per CU (160 KB of LDS each) and the launch is a cooperative one, which checks that.
 // Per step the first kRsEnd floats of the image (the phase-2 exchange space) are staged again from L2 while the barrier is
 // awaited.
-constexpr int kRsEnd = kRsSum + 2 * 4 * kPartialWords;      // 11 872 floats = 47.5 KB
+constexpr int kRsEnd = kRsSum + 2 * 4 * kPartialWords;      // 11 872 floats = 47.5 KB (the analytic detector's phase-2 map)
 constexpr int kSyncStride = 32;                            // words: one 128-B line per counter
 constexpr int kSyncGroups = kPrologueMergeWays;            // 9 groups = the 9 ways of merge_prologue's summation order
 constexpr int kSyncTop = kSyncGroups, kSyncGen = kSyncGroups + 1, kSyncAbort = 2 * kSyncGroups + 1;

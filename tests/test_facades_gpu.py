@@ -37,9 +37,9 @@ def test_single_env_protocol(oracle):
     env.close()
 
 
-def test_vec_env_host_mode_matches_oracle(oracle):
+@pytest.mark.parametrize("n", [16, 4096])     # train_hover.py:41's n_envs; BASELINE.json configs[1]
+def test_vec_env_host_mode_matches_oracle(oracle, n):
     from fpv_drone_rl_agent_amd.vec_env import make_vec_env
-    n = 16  # train_hover.py:41
     env = make_vec_env(None, n_envs=n, noise_ratio=0.0)
     obs = env.reset()
     st, obs_ref = oracle.reset_states(n)

@@ -58,13 +58,14 @@ else:
     edges = [s[:, 2], s[:, 4], s[:, 5], s[:, 6], s[:, 7]]
     out["env step, physics wave"] = {nm: round(float(np.median(edges[k + 1] - edges[k])), 2) for k, nm in enumerate(tn)}
     if eng.detector == "pixel":
-        # pixel detector: [8] corners published (before barrier P), [9] own rows walked, [10] barrier Q passed, [11] features done;
-        # helper wave of tile 0: [12] barrier P passed, [13] its rows walked
+        # pixel detector, tile 0: physics wave [8] corners projected + border pre-check done, [9] item list posted (before barrier P),
+        # [10] P passed, [11] own items done, [12] barrier Q passed, [13] features done; helper wave [14] attitude converted, [15] items done
         med = lambda a, b: round(float(np.median(s[:, b] - s[:, a])), 2)
-        out["pixel detector, physics wave"] = {"corner projection, barrier P0, euler (the helper posts the items meanwhile)": med(4, 8), "its work items": med(8, 9),
-                                               "wait for the workgroup (barrier Q)": med(9, 10), "merge + vertices + gates": med(10, 11),
-                                               "observation + reward": med(11, 5)}
-        out["pixel detector, helper wave"] = {"its work items": med(12, 13), "p90": round(float(np.percentile(s[:, 13] - s[:, 12], 90)), 2)}
+        out["pixel detector, physics wave"] = {"barrier P0 + corner projection + border pre-check": med(4, 8), "item list": med(8, 9),
+                                               "barrier P": med(9, 10), "its work items": med(10, 11),
+                                               "wait for the workgroup (barrier Q)": med(11, 12), "accumulators + vertices + gates": med(12, 13),
+                                               "observation + reward": med(13, 5)}
+        out["pixel detector, helper wave"] = {"pairs done -> attitude converted": med(4, 14), "its work items (from P)": med(10, 15)}
     out["workgroup"] = {"median_us": round(float(np.median(s[:, 3] - s[:, 0])), 2)}
     out["launch_first_start_to_last_end_us"] = round(float(s[:, 3].max() - s[:, 0].min()), 2)
     out["start_skew_us"] = round(float(s[:, 0].max() - s[:, 0].min()), 2)
