@@ -597,60 +597,6 @@ __device__ __forceinline__ void pixel_walk(const T (&u)[4], const T (&v)[4], con
     }
 }
 
-// The same for rows on which exactly the edges A and B cross (a run of rows between two vertex rows of a convex
-// quadrilateral): two edge evaluations per row instead of four tests.  The integers are those of pixel_walk — the
-// crossing rule picks these two edges on every row of the range (pixel_vertex_rows / pixel_active_pair below).
-template <typename T>
-__device__ __forceinline__ void pixel_walk2(T uA, T vA, T sA, T uB, T vB, T sB, T jfirst, T jlast, PixelRun<T>& r,
-                                            uint16_t* tab = nullptr, int idx = 0, int cap = 0, bool linked = false, T pa0 = T(0),
-                                            T pb0 = T(0)) {
-    pixel_run_clear(r);
-    for (T j = jfirst; j <= jlast; j += T(1), ++idx) {
-        const T y = j + T(0.5);
-        const T xa = uA + (y - vA) * sA, xb = uB + (y - vB) * sB;
-        const T fa = max_(ceil_(min_(xa, xb) - T(0.5)), T(0)), fb = min_(floor_(max_(xa, xb) - T(0.5)), T(127));
-        if (!(fa <= fb)) continue;
-        if (tab && idx < cap) tab[idx] = (uint16_t)(int)(fb * T(256) + fa);
-        if (r.n == T(0)) {
-            const bool link = linked && j == jfirst;
-            r.j0 = j; r.a0 = fa; r.b0 = fb; r.pa = link ? pa0 : fa; r.pb = link ? pb0 : fb;
-        }
-        const T da = abs_(fa - r.pa), db = abs_(fb - r.pb);
-        r.viol = max_(r.viol, max_(fa - r.pb, r.pa - fb));
-        r.S += da; r.S += db;
-        r.H += min_(da, T(1)); r.H += min_(db, T(1));
-        r.W += fb - fa;
-        r.n += T(1);
-        r.amin = min_(r.amin, fa); r.bmax = max_(r.bmax, fb);
-        r.pa = fa; r.pb = fb; r.jn = j;
-    }
-}
-
-// Row from which vertex i counts as "above the row of pixel centres": (v_i <= j + 0.5) <=> j >= c_i, c_i = ceil(v_i - 0.5)
-// (exact: v - 0.5 is exact for v >= 0.5, and a v below that gives a c of 0 either way), clamped to [0, 128].  Between two
-// consecutive values of the sorted c the set of crossing edges does not change.
-template <typename T>
-__device__ __forceinline__ void pixel_vertex_rows(const T (&v)[4], int (&c)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) c[i] = (int)clip_(ceil_(v[i] - T(0.5)), T(0), T(128));
-}
-
-// The edges crossing row j (constant over a range of rows that contains no c_i in its interior).  Returns how many cross
-// (2 for a convex quadrilateral, 4 for a self-intersecting one, 0 outside); A = the lowest-numbered, B = the
-// highest-numbered crossing edge.
-template <typename T>
-__device__ __forceinline__ T sel3_(bool f, bool g, T a, T b, T c) { return f ? a : (g ? b : c); }
-// (scalars on purpose: handed small arrays, hipcc turns the nested selects into an indexed load from scratch memory)
-template <typename T>
-__device__ __forceinline__ int pixel_active_pair(T u0, T u1, T u2, T u3, T v0, T v1, T v2, T v3, T s0, T s1, T s2, T s3,
-                                                 int c0, int c1, int c2, int c3, int j, T& uA, T& vA, T& sA, T& uB, T& vB, T& sB) {
-    const bool b0 = j >= c0, b1 = j >= c1, b2 = j >= c2, b3 = j >= c3;
-    const bool a0 = b0 != b1, a1 = b1 != b2, a2 = b2 != b3, a3 = b3 != b0;
-    uA = sel3_(a0, a1, u0, u1, u2); vA = sel3_(a0, a1, v0, v1, v2); sA = sel3_(a0, a1, s0, s1, s2);
-    uB = sel3_(a3, a2, u3, u2, u1); vB = sel3_(a3, a2, v3, v2, v1); sB = sel3_(a3, a2, s3, s2, s1);
-    return (int)a0 + (int)a1 + (int)a2 + (int)a3;
-}
-
 // p <- p followed by h (h's rows lie below p's)
 template <typename T>
 __device__ __forceinline__ void pixel_merge(PixelRun<T>& p, const PixelRun<T>& h) {
@@ -669,10 +615,12 @@ __device__ __forceinline__ void pixel_merge(PixelRun<T>& p, const PixelRun<T>& h
     p = o;
 }
 
-// the gates and features of SPEC §6b items 3-7 from the blob's run; span(j, a, b) yields the span of a row j0 <= j <= jn
-// (it is also called for j0 - 1 and jn + 1, whose result is not used)
-template <typename T, typename SpanFn>
-__device__ __forceinline__ bool pixel_finish(const PixelRun<T>& r, const T (&u)[4], const T (&v)[4], SpanFn span,
+// the gates and features of SPEC §6b items 3-7 from the blob's run; span3(jc, a, b) yields the spans of rows jc - 1, jc, jc + 1
+// for a row j0 <= jc <= jn (what it returns for a row outside j0 .. jn is not used)
+__device__ __forceinline__ float med3_(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+__device__ __forceinline__ double med3_(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+template <typename T, typename Span3Fn>
+__device__ __forceinline__ bool pixel_finish(const PixelRun<T>& r, const T (&u)[4], const T (&v)[4], Span3Fn span3,
                                              T& cx, T& cy, T& area, T& ratio) {
     cx = T(0); cy = T(0); area = T(0); ratio = T(0);
     const T h = r.jn - r.j0 + T(1);
@@ -686,20 +634,19 @@ __device__ __forceinline__ bool pixel_finish(const PixelRun<T>& r, const T (&u)[
     T vx[4], vy[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const T fr = floor_(v[k]);
-        const T jc = fr < r.j0 ? r.j0 : (fr > r.jn ? r.jn : fr);
+        const T jc = med3_(floor_(v[k]), r.j0, r.jn);                          // the blob's row nearest to the corner's
         const T fx = floor_(u[k]);
-        T best = T(1e30);
-        vx[k] = T(0); vy[k] = T(0);
-#pragma unroll
-        for (int dj = -1; dj <= 1; ++dj) {
-            const T j = jc + T(dj);
-            T a, b;
-            span(j, a, b);
-            const T x = fx < a ? a : (fx > b ? b : fx);
-            const T ex = x + T(0.5) - u[k], ey = j + T(0.5) - v[k], d2 = ex * ex + ey * ey;
-            if (j >= r.j0 && j <= r.jn && d2 < best) { best = d2; vx[k] = x; vy[k] = j; }
-        }
+        T a[3], b[3];
+        span3(jc, a, b);
+        // candidates in the order jc - 1, jc, jc + 1, the first minimum wins (rows outside the blob do not take part)
+        const T ey0 = jc - T(0.5) - v[k], ey1 = jc + T(0.5) - v[k], ey2 = jc + T(1.5) - v[k];
+        const T x0 = med3_(fx, a[0], b[0]), x1 = med3_(fx, a[1], b[1]), x2 = med3_(fx, a[2], b[2]);
+        const T ex0 = x0 + T(0.5) - u[k], ex1 = x1 + T(0.5) - u[k], ex2 = x2 + T(0.5) - u[k];
+        const T d0 = jc > r.j0 ? ex0 * ex0 + ey0 * ey0 : T(1e30), d1 = ex1 * ex1 + ey1 * ey1;
+        const T d2 = jc < r.jn ? ex2 * ex2 + ey2 * ey2 : T(1e30);
+        T best = d0; vx[k] = x0; vy[k] = jc - T(1);
+        if (d1 < best) { best = d1; vx[k] = x1; vy[k] = jc; }
+        if (d2 < best) { best = d2; vx[k] = x2; vy[k] = jc + T(1); }
     }
     const T eps = T(0.04) * len;
     {
@@ -730,7 +677,10 @@ __device__ __forceinline__ bool camera_features_pixel(const Drone<T>& d, T& cx, 
     if (pixel_touches_border(u, v, slope, jlo, jhi)) { ok = false; jlo = T(1); jhi = T(0); }    // invisible either way: no walk
     PixelRun<T> r;
     pixel_walk(u, v, slope, jlo, jhi, r);
-    const bool vis = pixel_finish(r, u, v, [&](T j, T& a, T& b) { row_span(u, v, slope, j + T(0.5), a, b); }, cx, cy, area, ratio);
+    const bool vis = pixel_finish(r, u, v, [&](T jc, T (&a)[3], T (&b)[3]) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) row_span(u, v, slope, jc + T(q) - T(0.5), a[q], b[q]);
+    }, cx, cy, area, ratio);
     return ok && vis;
 }
 

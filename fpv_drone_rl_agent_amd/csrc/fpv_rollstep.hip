@@ -54,11 +54,11 @@ constexpr int kRsSum = kRsXch + 4 * 256;                    // 4 x kPartialWords
 static_assert((kRsXch * 4) % 8 == 0 && (kRsSum * 4) % 8 == 0, "fp64 areas must be 8-byte aligned");
 static_assert(kRsSum + 2 * 4 * kPartialWords <= 2 * kNetFloats, "phase-2 exchange must fit in the weight image's space");
 // Pixel detector (hover.py:157-222, SPEC §6b): the blob's rows as work items of the tile's two waves.  Per tile, above the rest
-// of the phase-2 map: the corner block [5][64] f32x4 (u, v, edge slopes, vertex rows, {first span-table entry, jlo, jhi} of
+// of the phase-2 map: the corner block [4][64] f32x4 (u, v, edge slopes, {first span-table entry, jlo, jhi, rows per item} of
 // every drone), the drones' integer accumulators, the item list (kPixItems packed words + the item count) and the span table.
-constexpr int kPixItems = 512;                              // >= rows / chunk + 3 segments x 64 drones for every chunk size chosen
+constexpr int kPixItems = 512;                              // >= rows / chunk + 64 drones for every chunk size chosen
 constexpr int kPixChunkShift = 2;                           // rows per item: 2^shift, more in a tile whose items would not fit the list
-constexpr int kPixAcc = 5 * kTile * 4;                      // floats from the tile's base: behind the corner block [5][64] f32x4
+constexpr int kPixAcc = 4 * kTile * 4;                      // floats from the tile's base: behind the corner block [4][64] f32x4
 constexpr int kPixSlots = kPixAcc + 3 * kTile * 4;          // per-drone accumulators [3][64] int4, then the item list
 constexpr int kPixTab = kPixSlots + kPixItems + 4;          // item list: kPixItems packed items, then the item count; then the span table
 constexpr int kPixSpanCap = kTile * 128;                    // u16 entries: a | b << 8 per row, the tile's drones one after the other (every
@@ -284,42 +284,30 @@ __device__ __forceinline__ int wave_scan_inclusive(int x) {
     return x;
 }
 
-// Physics wave, one lane per drone: cut the drone's rows [jlo, jhi] at the rows where a vertex passes (between two cuts the same
-// two edges cross every row) and into chunks of at most 2^sh rows — four, or more in a tile with so many rows that the list
-// would overflow — and append the items (drone | first row << 8 |
-// last row << 16) at this lane's place in the list.  Leaves the vertex rows and {first entry of the drone in the span table, jlo,
-// jhi} in the corner block.  A lane without rows (jlo > jhi) appends nothing.
-__device__ __forceinline__ void pixel_post_items(float* pix, int lane, const float (&v)[4], int ilo, int ihi) {
-    f32x4* cb = reinterpret_cast<f32x4*>(pix);
-    int c[4];
-    pixel_vertex_rows(v, c);
-    const int lo1 = min(c[0], c[1]), hi1 = max(c[0], c[1]), lo2 = min(c[2], c[3]), hi2 = max(c[2], c[3]);
-    const int ma = max(lo1, lo2), mb = min(hi1, hi2), m1 = min(ma, mb), m2 = max(ma, mb);     // the two middle vertex rows
-    const int sa0 = ilo, sa1 = max(m1, ilo), sa2 = max(m2, ilo), sb0 = min(m1 - 1, ihi), sb1 = min(m2 - 1, ihi), sb2 = ihi;
-    const int l0 = max(sb0 - sa0 + 1, 0), l1 = max(sb1 - sa1 + 1, 0), l2 = max(sb2 - sa2 + 1, 0);
+// Physics wave, one lane per drone: cut the drone's rows [jlo, jhi] into chunks of 2^sh rows — four, or more in a tile with so
+// many rows that the list would overflow — and append the items (drone | chunk << 8) at this lane's place in the list.  Leaves
+// {first entry of the drone in the span table, jlo, jhi, 2^sh} in the corner block.  A lane without rows (jlo > jhi) appends nothing.
+__device__ __forceinline__ void pixel_post_items(float* pix, int lane, int ilo, int ihi) {
     const int rows = max(ihi - ilo + 1, 0);
     const int rows_incl = wave_scan_inclusive(rows);
     const int tile_rows = __builtin_amdgcn_readlane(rows_incl, 63);
     int sh = kPixChunkShift;
-    while (((kPixItems - 3 * kTile) << sh) < tile_rows) ++sh;  // items <= rows / 2^sh + 3 x 64 <= kPixItems
-    const int ch1 = (1 << sh) - 1;
-    const int n0 = (l0 + ch1) >> sh, n1 = (l1 + ch1) >> sh, n2 = (l2 + ch1) >> sh, items = n0 + n1 + n2;
+    while (((kPixItems - kTile) << sh) < tile_rows) ++sh;      // items <= rows / 2^sh + 64 <= kPixItems
+    const int items = (rows + (1 << sh) - 1) >> sh;
     const int incl = wave_scan_inclusive(items);
-    const int ch = 1 << sh, first = incl - items;
     uint32_t* slots = reinterpret_cast<uint32_t*>(pix + kPixSlots);
-    int pos = first;
-    for (int i = 0, jf = sa0; i < n0; ++i, jf += ch) slots[pos++] = (uint32_t)lane | (uint32_t)jf << 8 | (uint32_t)min(jf + ch - 1, sb0) << 16;
-    for (int i = 0, jf = sa1; i < n1; ++i, jf += ch) slots[pos++] = (uint32_t)lane | (uint32_t)jf << 8 | (uint32_t)min(jf + ch - 1, sb1) << 16;
-    for (int i = 0, jf = sa2; i < n2; ++i, jf += ch) slots[pos++] = (uint32_t)lane | (uint32_t)jf << 8 | (uint32_t)min(jf + ch - 1, sb2) << 16;
+    for (int k = 0, pos = incl - items; k < items; ++k, ++pos) slots[pos] = (uint32_t)lane | (uint32_t)k << 8;
     if (lane == kTile - 1) slots[kPixItems] = (uint32_t)incl;
-    cb[3 * kTile + lane] = f32x4{(float)c[0], (float)c[1], (float)c[2], (float)c[3]};
-    cb[4 * kTile + lane] = f32x4{(float)(rows_incl - rows), (float)ilo, (float)ihi, 0.f};
+    reinterpret_cast<f32x4*>(pix)[3 * kTile + lane] = f32x4{(float)(rows_incl - rows), (float)ilo, (float)ihi, (float)(1 << sh)};
 }
 
 // Both waves of the tile (worker 0 .. 127): walk the rows of items worker, worker + 128, ... and add each item's run to its
-// drone's accumulators.  An item whose first row is not the drone's first also evaluates the row above it and counts the pair
-// of the two rows (pixel_walk*'s `linked`), so every pair of consecutive rows is counted by exactly one item and the
-// accumulators need sums, minima and maxima only — integer LDS atomics on exact integers: the order does not matter.
+// drone's accumulators.  An item that is not its drone's first also evaluates the row above it and counts the pair of the two
+// rows (pixel_walk's `linked`), so every pair of consecutive rows is counted by exactly one item and the accumulators need
+// sums, minima and maxima only — integer LDS atomics on exact integers: the order does not matter.
+// (Measured and not kept: items cut at the rows where a vertex passes, each walked with the two edges that cross it —
+// 12 instead of 28 instructions per row for the span, but three or more items per drone, vertex rows to sort and three
+// scatter loops on the posting wave, which is the serial part: 68.2 us per step against the plain chunks' figure in DESIGN §4.)
 __device__ __forceinline__ void pixel_work_items(float* pix, int worker) {
     const uint32_t* slots = reinterpret_cast<const uint32_t*>(pix + kPixSlots);
     const f32x4* cb = reinterpret_cast<const f32x4*>(pix);
@@ -328,19 +316,15 @@ __device__ __forceinline__ void pixel_work_items(float* pix, int worker) {
     const int total = (int)slots[kPixItems];
     for (int item = worker; item < total; item += 2 * kTile) {
         const uint32_t rec = slots[item];
-        const int d = (int)(rec & 63u), jf = (int)((rec >> 8) & 255u), jl = (int)(rec >> 16);
-        const f32x4 qu = cb[d], qv = cb[kTile + d], qs = cb[2 * kTile + d], qc = cb[3 * kTile + d], qr = cb[4 * kTile + d];
+        const int d = (int)(rec & 63u), k = (int)(rec >> 8);
+        const f32x4 qu = cb[d], qv = cb[kTile + d], qs = cb[2 * kTile + d], qr = cb[3 * kTile + d];
         const float u[4] = {qu.x, qu.y, qu.z, qu.w}, v[4] = {qv.x, qv.y, qv.z, qv.w}, sl[4] = {qs.x, qs.y, qs.z, qs.w};
-        float uA, vA, sA, uB, vB, sB;
-        const int crossing = pixel_active_pair(qu.x, qu.y, qu.z, qu.w, qv.x, qv.y, qv.z, qv.w, qs.x, qs.y, qs.z, qs.w, (int)qc.x, (int)qc.y,
-                                               (int)qc.z, (int)qc.w, jf, uA, vA, sA, uB, vB, sB);
-        const int ilo = (int)qr.y, idx = (int)qr.x + jf - ilo;   // this item's first entry in the span table
+        const float jf = qr.y + (float)k * qr.w, jl = fminf(jf + qr.w - 1.0f, qr.z);
+        const int idx = (int)qr.x + (int)(jf - qr.y);            // this item's first entry in the span table
         float pa = 0.f, pb = 0.f;
-        const bool linked = jf > ilo && row_span(u, v, sl, (float)jf - 0.5f, pa, pb);       // the row above, if the blob has it
+        const bool linked = k > 0 && row_span(u, v, sl, jf - 0.5f, pa, pb);        // the row above, if the blob has it
         PixelRun<float> r;
-        if (crossing == 2) pixel_walk2(uA, vA, sA, uB, vB, sB, (float)jf, (float)jl, r, tab, idx, kPixSpanCap, linked, pa, pb);
-        else pixel_walk(u, v, sl, (float)jf, (float)jl, r, tab, idx, kPixSpanCap, linked, pa, pb);   // (a quadrilateral that rounding has
-                                                                                                      // folded over: the four-edge rule)
+        pixel_walk(u, v, sl, jf, jl, r, tab, idx, kPixSpanCap, linked, pa, pb);
         if (r.n > 0.f) {
             int* a = acc + 4 * d;
             atomicAdd(a, (int)r.n); atomicAdd(a + 1, (int)r.W); atomicAdd(a + 2, (int)r.S); atomicAdd(a + 3, (int)r.H);
@@ -458,10 +442,9 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
         // panel at all: one lane walking its own drone's rows keeps the wave busy for the tallest blob while most lanes idle
         // (measured: 35 rows per tile against 7.8 per drone), and the helper wave has nothing to do until barrier 6.  So the rows
         // become work items of BOTH waves: this wave projects the corners, drops the blobs that touch the image border (exact
-        // pre-check), cuts every other drone's rows where a vertex passes and into chunks, and posts the items — the helper
-        // converts the attitude (Euler angles, obs[0:7]) meanwhile; the 128 lanes each walk an item — with the two edges that
-        // cross its rows, not four edge tests per row — adding its run to the drone's accumulators and leaving the rows' spans;
-        // this wave then searches the four vertices in the span table and applies the gates.
+        // pre-check), cuts every other drone's rows into chunks of four and posts the items — the helper converts the attitude
+        // (Euler angles, obs[0:7]) meanwhile; the 128 lanes each walk an item, adding its run to the drone's accumulators and
+        // leaving the rows' spans; this wave then searches the four vertices in the span table and applies the gates.
         f32x4* att = reinterpret_cast<f32x4*>(nz);        // the noise slots are free once pair 5 has been read
         att[lane] = f32x4{d.qx, d.qy, d.qz, d.qw};
         att[kTile + lane] = f32x4{d.er, d.ep, d.eyaw, 0.f};
@@ -479,7 +462,7 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
         acc[kTile + lane] = i32x4{-1000, 128, -1, 128};    // viol, amin, bmax, j0
         acc[2 * kTile + lane] = i32x4{-1, 0, 0, 0};        // jn
         if (o_.stamps && threadIdx.x == 0) o_.stamps[4] = __builtin_amdgcn_s_memrealtime();
-        pixel_post_items(pix, lane, v, (int)jlo, (int)jhi);
+        pixel_post_items(pix, lane, (int)jlo, (int)jhi);
         if (o_.stamps && threadIdx.x == 0) o_.stamps[5] = __builtin_amdgcn_s_memrealtime();
         lds_barrier();                                     // barrier P
         if (o_.stamps && threadIdx.x == 0) o_.stamps[6] = __builtin_amdgcn_s_memrealtime();
@@ -493,19 +476,22 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
             o[0] = t0.w; o[1] = t1.x; o[2] = t1.y; o[3] = t1.z; o[4] = t1.w; o[5] = t2.x; o[6] = t2.y;
         }
         const i32x4 a0 = acc[lane], a1 = acc[kTile + lane], a2 = acc[2 * kTile + lane];
-        const int rowbase = (int)cb[4 * kTile + lane].x, ilo = (int)jlo;
+        const int rowbase = (int)cb[3 * kTile + lane].x, ilo = (int)jlo;
         const uint16_t* tab = reinterpret_cast<const uint16_t*>(pix + kPixTab);
-        auto span = [&](T j, T& a, T& b) {                 // (j0 - 1 / jn + 1 may be asked for: never below entry 0, result unused)
-            const int idx = rowbase + (int)j - ilo;
-            const uint32_t ab = tab[idx < 0 ? 0 : idx];
+        auto entry = [&](int idx, T& a, T& b) {             // (rows outside the blob may be asked for — result unused —: kept inside the table)
+            const uint32_t ab = tab[min(max(idx, 0), kPixSpanCap - 1)];
             a = (T)(ab & 255u); b = (T)(ab >> 8);
         };
         PixelRun<T> r;
         r.n = (T)a0.x; r.W = (T)a0.y; r.S = (T)a0.z; r.H = (T)a0.w;
         r.viol = (T)a1.x; r.amin = (T)a1.y; r.bmax = (T)a1.z; r.j0 = (T)a1.w; r.jn = (T)a2.x;
-        span(r.j0, r.a0, r.b0);                            // first and last row of the blob (unused when the blob is empty)
-        span(r.jn, r.pa, r.pb);
-        const bool seen = pixel_finish(r, u, v, span, cam_x, cam_y, cam_area, cam_ratio);
+        entry(rowbase + a1.w - ilo, r.a0, r.b0);           // first and last row of the blob (unused when the blob is empty)
+        entry(rowbase + a2.x - ilo, r.pa, r.pb);
+        auto span3 = [&](T jc, T (&a)[3], T (&b)[3]) {
+            const int idx = rowbase + (int)jc - ilo;
+            entry(idx - 1, a[0], b[0]); entry(idx, a[1], b[1]); entry(idx + 1, a[2], b[2]);
+        };
+        const bool seen = pixel_finish(r, u, v, span3, cam_x, cam_y, cam_area, cam_ratio);
         vis = ok && seen;
         if (o_.stamps && threadIdx.x == 0) o_.stamps[9] = __builtin_amdgcn_s_memrealtime();
     } else {
