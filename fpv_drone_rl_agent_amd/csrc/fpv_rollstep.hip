@@ -56,8 +56,8 @@ static_assert(kRsSum + 2 * 4 * kPartialWords <= 2 * kNetFloats, "phase-2 exchang
 // Pixel detector (hover.py:157-222, SPEC §6b): the blob's rows as work items of the tile's two waves.  Per tile, above the rest
 // of the phase-2 map: the corner block [4][64] f32x4 (u, v, edge slopes, {first span-table entry, jlo, jhi, rows per item} of
 // every drone), the drones' integer accumulators, the item list (kPixItems packed words + the item count) and the span table.
-constexpr int kPixItems = 512;                              // >= rows / chunk + 64 drones for every chunk size chosen
-constexpr int kPixChunkShift = 2;                           // rows per item: 2^shift, more in a tile whose items would not fit the list
+constexpr int kPixItems = 2 * kTile;                        // one item per lane of the tile's two waves: the chunk size is chosen for that
+constexpr int kPixMinChunk = 2;                             // rows per item at least
 constexpr int kPixAcc = 4 * kTile * 4;                      // floats from the tile's base: behind the corner block [4][64] f32x4
 constexpr int kPixSlots = kPixAcc + 3 * kTile * 4;          // per-drone accumulators [3][64] int4, then the item list
 constexpr int kPixTab = kPixSlots + kPixItems + 4;          // item list: kPixItems packed items, then the item count; then the span table
@@ -284,21 +284,24 @@ __device__ __forceinline__ int wave_scan_inclusive(int x) {
     return x;
 }
 
-// Physics wave, one lane per drone: cut the drone's rows [jlo, jhi] into chunks of 2^sh rows — four, or more in a tile with so
-// many rows that the list would overflow — and append the items (drone | chunk << 8) at this lane's place in the list.  Leaves
-// {first entry of the drone in the span table, jlo, jhi, 2^sh} in the corner block.  A lane without rows (jlo > jhi) appends nothing.
+// Physics wave, one lane per drone: cut the drone's rows [jlo, jhi] into chunks of ch rows and append the items
+// (drone | chunk << 8) at this lane's place in the list.  Leaves {first entry of the drone in the span table, jlo, jhi, ch} in the
+// corner block.  A lane without rows (jlo > jhi) appends nothing.
 __device__ __forceinline__ void pixel_post_items(float* pix, int lane, int ilo, int ihi) {
     const int rows = max(ihi - ilo + 1, 0);
     const int rows_incl = wave_scan_inclusive(rows);
     const int tile_rows = __builtin_amdgcn_readlane(rows_incl, 63);
-    int sh = kPixChunkShift;
-    while (((kPixItems - kTile) << sh) < tile_rows) ++sh;      // items <= rows / 2^sh + 64 <= kPixItems
-    const int items = (rows + (1 << sh) - 1) >> sh;
+    // rows per item: the fewest that let the 128 lanes take all items in one round (items <= rows / ch + one per drone with rows)
+    const int with_rows = __popcll(__ballot(rows > 0));
+    const int ch = max(kPixMinChunk, (tile_rows + 2 * kTile - with_rows - 1) / (2 * kTile - with_rows));      // uniform
+    // ceil(rows / ch) for 0 <= rows <= 128 without an integer division: floor((rows + ch - 1/2) / ch), the half keeps the
+    // quotient away from the integers by 1 / (2 ch), far more than the rounding of the reciprocal
+    const int items = (int)(((float)(rows + ch) - 0.5f) * (1.0f / (float)ch));
     const int incl = wave_scan_inclusive(items);
     uint32_t* slots = reinterpret_cast<uint32_t*>(pix + kPixSlots);
     for (int k = 0, pos = incl - items; k < items; ++k, ++pos) slots[pos] = (uint32_t)lane | (uint32_t)k << 8;
     if (lane == kTile - 1) slots[kPixItems] = (uint32_t)incl;
-    reinterpret_cast<f32x4*>(pix)[3 * kTile + lane] = f32x4{(float)(rows_incl - rows), (float)ilo, (float)ihi, (float)(1 << sh)};
+    reinterpret_cast<f32x4*>(pix)[3 * kTile + lane] = f32x4{(float)(rows_incl - rows), (float)ilo, (float)ihi, (float)ch};
 }
 
 // Both waves of the tile (worker 0 .. 127): walk the rows of items worker, worker + 128, ... and add each item's run to its
