@@ -97,12 +97,12 @@ SIGNATURES = {
     "fpv_get_tick": (C.c_int, [_vp, C.POINTER(_u64), _vp]),
     "fpv_ledger_view": (C.c_int, [_vp, C.POINTER(FpvLedger)]),
     "fpv_ledger_clear": (C.c_int, [_vp, _vp]),
-    "fpv_rollout_begin": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "fpv_rollout_begin": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "fpv_ledger_bind": (C.c_int, [_vp, C.POINTER(FpvLedger)]),
     "fpv_advantage_stats": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
-    "fpv_ledger_scan": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "fpv_ledger_scan": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp]),
     "fpv_ledger_scatter": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _vp, _i64, _i64, _vp]),
-    "fpv_gae": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp]),
+    "fpv_gae": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "fpv_normalize": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _i32, _f32, _f32, _vp]),
     "fpv_normalize_reward": (C.c_int, [_i64, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _f32, _f32, _vp]),
     "fpv_policy_create": (C.c_int, [_i32, C.POINTER(_vp)]),

@@ -404,11 +404,15 @@ int fpv_ledger_clear(fpv_env* e, void* stream) {
     return FPV_OK;
 }
 
-int fpv_rollout_begin(fpv_env* e, uint8_t* starts_dst, const uint8_t* starts_src, void* stream) {
+int fpv_rollout_begin(fpv_env* e, uint8_t* starts_dst, const uint8_t* starts_src, int32_t* scan_counters, double* scan_sums,
+                      void* stream) {
     if (!e) return fail(FPV_ERR_ARG, "fpv_rollout_begin: null handle");
     if ((starts_dst == nullptr) != (starts_src == nullptr)) return fail(FPV_ERR_ARG, "fpv_rollout_begin: give both rows or neither");
+    if ((scan_counters == nullptr) != (scan_sums == nullptr))
+        return fail(FPV_ERR_ARG, "fpv_rollout_begin: give both scan_counters and scan_sums or neither");
     if (((uintptr_t)starts_dst | (uintptr_t)starts_src) & 15) return fail(FPV_ERR_ARG, "fpv_rollout_begin: rows must be 16-byte aligned");
-    FPV_HIP(launch_rollout_begin(e->led_count, e->tiles, starts_dst, starts_src, e->cfg.num_envs, (hipStream_t)stream));
+    FPV_HIP(launch_rollout_begin(e->led_count, e->tiles, starts_dst, starts_src, e->cfg.num_envs, scan_counters, scan_sums,
+                                 (hipStream_t)stream));
     return FPV_OK;
 }
 
@@ -419,14 +423,15 @@ int fpv_advantage_stats(const double* gathered, int32_t world, int32_t stride, d
 }
 
 int fpv_ledger_scan(fpv_env* e, const double* snapshots, int64_t snapshot_stride, int32_t T, float clip_obs, float eps_norm,
-                    float* tobs, int32_t* t_idx, int32_t* d_idx, int64_t cap, int32_t* counters, double* sums, void* stream) {
+                    float* tobs, int32_t* t_idx, int32_t* d_idx, int64_t cap, int32_t* counters, double* sums,
+                    int32_t counters_are_zero, void* stream) {
     if (!e || !tobs || !t_idx || !d_idx || !counters || !sums || cap <= 0 || T <= 0)
         return fail(FPV_ERR_ARG, "fpv_ledger_scan: null argument, cap <= 0 or T <= 0");
     if (e->cfg.precision != FPV_F32) return fail(FPV_ERR_UNSUPPORTED, "fpv_ledger_scan: fp32 handles");
     if (snapshots && snapshot_stride < 2 * e->obs_words) return fail(FPV_ERR_ARG, "fpv_ledger_scan: snapshot rows hold {mean[O], var[O], ...}");
     FPV_HIP(launch_ledger_scan(e->led_count, e->led_idx, e->led_info, e->led_tag, (const float*)e->led_ret, (const float*)e->led_obs,
                                e->tick, e->tiles, (int)e->led_rows, e->obs_words, snapshots, snapshot_stride, T, clip_obs, eps_norm,
-                               tobs, t_idx, d_idx, cap, counters, sums, (hipStream_t)stream));
+                               tobs, t_idx, d_idx, cap, counters, sums, counters_are_zero != 0, (hipStream_t)stream));
     return FPV_OK;
 }
 
@@ -440,14 +445,15 @@ int fpv_ledger_scatter(const int32_t* counters, const int32_t* t_idx, const int3
 
 int fpv_gae(int64_t T, int64_t n, const float* rewards, const float* values, const uint8_t* episode_starts,
             const float* last_values, const uint8_t* last_dones, float gamma, float lam, float* advantages,
-            float* returns, double* stats, void* stream) {
+            float* returns, double* stats, double* mean_std, void* stream) {
     if (T <= 0 || n <= 0) return fail(FPV_ERR_ARG, "fpv_gae: T and n must be positive");
+    if (mean_std && !stats) return fail(FPV_ERR_ARG, "fpv_gae: mean_std needs stats");
     if (!rewards || !values || !episode_starts || !last_values || !last_dones || !advantages || !returns)
         return fail(FPV_ERR_ARG, "fpv_gae: null buffer");
     double* scratch = nullptr;
     if (int rc = scratch_for_current_device(&scratch)) return rc;
     FPV_HIP(launch_gae(T, n, rewards, values, episode_starts, last_values, last_dones, gamma, lam, advantages,
-                       returns, stats, scratch, (hipStream_t)stream));
+                       returns, stats, mean_std, scratch, (hipStream_t)stream));
     return FPV_OK;
 }
 

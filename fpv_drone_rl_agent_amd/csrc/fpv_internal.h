@@ -167,7 +167,7 @@ hipError_t launch_tick_fill(uint64_t* tick, int64_t tiles, uint64_t v, hipStream
 // fpv_rollout.hip
 hipError_t launch_gae(int64_t T, int64_t n, const float* rewards, const float* values, const uint8_t* episode_starts,
                       const float* last_values, const uint8_t* last_dones, float gamma, float lam, float* adv,
-                      float* returns, double* stats, double* scratch, hipStream_t s);
+                      float* returns, double* stats, double* mean_std, double* scratch, hipStream_t s);
 hipError_t launch_normalize(int64_t n, int32_t d, const float* x, float* y, double* rms, int32_t update, float clip,
                             float eps, double* scratch, hipStream_t s);
 hipError_t launch_moments_merge_tiles(int64_t tiles, const double* partials, double batch_count, const double* obs_rms_in,
@@ -193,12 +193,13 @@ __device__ __forceinline__ float half_sum(float v) {
 
 hipError_t launch_advantage_stats(const double* gathered, int world, int stride, double* out, hipStream_t s);
 hipError_t launch_zero_words(uint32_t* a, int64_t n, hipStream_t s);
-hipError_t launch_rollout_begin(uint32_t* counts, int64_t tiles, uint8_t* dst, const uint8_t* src, int64_t n, hipStream_t s);
+hipError_t launch_rollout_begin(uint32_t* counts, int64_t tiles, uint8_t* dst, const uint8_t* src, int64_t n, int32_t* scan_counters,
+                                double* scan_sums, hipStream_t s);
 hipError_t launch_ledger_scan(const uint32_t* led_count, const int32_t* led_idx, const uint32_t* led_info, const uint32_t* led_tag,
                               const float* led_ret, const float* led_obs, const uint64_t* tick, int64_t tiles, int rows,
                               int obs_words, const double* snapshots, int64_t stride, int T, float clip_obs, float eps,
                               float* tobs, int32_t* t_idx, int32_t* d_idx, int64_t cap, int32_t* counters, double* sums,
-                              hipStream_t s);
+                              bool counters_are_zero, hipStream_t s);
 hipError_t launch_ledger_scatter(const int32_t* counters, const int32_t* t_idx, const int32_t* d_idx, const float* v, float gamma,
                                  float* rewards, int64_t n, int64_t cap, hipStream_t s);
 

@@ -40,8 +40,8 @@ __global__ __launch_bounds__(kRedBlock) void gae_kernel(int64_t T, int64_t n, co
                                                         const float* __restrict__ last_values,
                                                         const uint8_t* __restrict__ last_dones, float gamma, float lam,
                                                         float* __restrict__ adv, float* __restrict__ returns,
-                                                        double* __restrict__ partial, double* __restrict__ stats, double count,
-                                                        uint32_t* __restrict__ ticket) {
+                                                        double* __restrict__ partial, double* __restrict__ stats,
+                                                        double* __restrict__ mean_std, double count, uint32_t* __restrict__ ticket) {
     __shared__ double lds[2 * (kRedBlock / 64) + 130];
     double s1 = 0.0, s2 = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -114,6 +114,13 @@ __global__ __launch_bounds__(kRedBlock) void gae_kernel(int64_t T, int64_t n, co
             double a1 = 0.0, a2 = 0.0;
             for (int w = 0; w < 64; ++w) { a1 += l1[w]; a2 += l2[w]; }
             stats[0] = count; stats[1] = a1; stats[2] = a2;
+            if (mean_std) {                              // one rank: advantage_stats_kernel's arithmetic on this shard's sums
+                const double mean = a1 / count;
+                double var = a2 / count - mean * mean;
+                if (var < 0.0) var = 0.0;
+                mean_std[0] = mean;
+                mean_std[1] = sqrt(var);
+            }
             __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // for the next launch
         }
     }
@@ -138,7 +145,7 @@ hipError_t launch_advantage_stats(const double* gathered, int world, int stride,
 
 hipError_t launch_gae(int64_t T, int64_t n, const float* rewards, const float* values, const uint8_t* episode_starts,
                       const float* last_values, const uint8_t* last_dones, float gamma, float lam, float* adv,
-                      float* returns, double* stats, double* scratch, hipStream_t s) {
+                      float* returns, double* stats, double* mean_std, double* scratch, hipStream_t s) {
     int64_t blocks = (n + kRedBlock - 1) / kRedBlock;
     if (blocks > kMaxRedBlocks * 2) blocks = kMaxRedBlocks * 2;
     // the ticket of the in-launch reduction: the last word of the device's reduction scratch (zeroed at allocation, reset by
@@ -146,7 +153,7 @@ hipError_t launch_gae(int64_t T, int64_t n, const float* rewards, const float* v
     uint32_t* ticket = reinterpret_cast<uint32_t*>(scratch + kScratchDoubles - 1);
     hipLaunchKernelGGL(gae_kernel, dim3((unsigned)blocks), dim3(kRedBlock), 0, s, T, n, rewards, values,
                        episode_starts, last_values, last_dones, gamma, lam, adv, returns, stats ? scratch : nullptr, stats,
-                       (double)T * (double)n, ticket);
+                       stats ? mean_std : nullptr, (double)T * (double)n, ticket);
     return hipGetLastError();
 }
 
@@ -410,9 +417,12 @@ __global__ void zero_words_kernel(uint32_t* __restrict__ a, int64_t na, uint32_t
 // Start of a rollout in one launch: clear the done ledger's per-tile counts and carry the episode-start flags over
 // (dst[i] = src[i], n bytes; a memcpy node in a captured graph costs tens of microseconds of dispatch latency, a kernel node ~1.5).
 __global__ void rollout_begin_kernel(uint32_t* __restrict__ counts, int64_t tiles, uint8_t* __restrict__ dst,
-                                     const uint8_t* __restrict__ src, int64_t n) {
+                                     const uint8_t* __restrict__ src, int64_t n, int32_t* __restrict__ scan_counters,
+                                     double* __restrict__ scan_sums) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t k = i; k < tiles; k += stride) counts[k] = 0u;
+    if (scan_counters && i < 4) scan_counters[i] = 0;    // what this rollout's ledger scan accumulates into
+    if (scan_sums && i >= 4 && i < 6) scan_sums[i - 4] = 0.0;
     if (dst) {
         const int64_t words = n / 16;                  // both rows are 16-byte aligned (checked by the caller)
         for (int64_t k = i; k < words; k += stride) reinterpret_cast<uint4*>(dst)[k] = reinterpret_cast<const uint4*>(src)[k];
@@ -420,12 +430,13 @@ __global__ void rollout_begin_kernel(uint32_t* __restrict__ counts, int64_t tile
     }
 }
 
-hipError_t launch_rollout_begin(uint32_t* counts, int64_t tiles, uint8_t* dst, const uint8_t* src, int64_t n, hipStream_t s) {
+hipError_t launch_rollout_begin(uint32_t* counts, int64_t tiles, uint8_t* dst, const uint8_t* src, int64_t n, int32_t* scan_counters,
+                                double* scan_sums, hipStream_t s) {
     int64_t work = tiles > n / 16 ? tiles : n / 16;
     int64_t blocks = (work + 255) / 256;
     if (blocks > 256) blocks = 256;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(rollout_begin_kernel, dim3((unsigned)blocks), dim3(256), 0, s, counts, tiles, dst, src, n);
+    hipLaunchKernelGGL(rollout_begin_kernel, dim3((unsigned)blocks), dim3(256), 0, s, counts, tiles, dst, src, n, scan_counters, scan_sums);
     return hipGetLastError();
 }
 
@@ -575,10 +586,11 @@ hipError_t launch_ledger_scan(const uint32_t* led_count, const int32_t* led_idx,
                               const float* led_ret, const float* led_obs, const uint64_t* tick, int64_t tiles, int rows,
                               int obs_words, const double* snapshots, int64_t stride, int T, float clip_obs, float eps,
                               float* tobs, int32_t* t_idx, int32_t* d_idx, int64_t cap, int32_t* counters, double* sums,
-                              hipStream_t s) {
-    // zeroed by a kernel, not hipMemsetAsync: memset nodes captured into a HIP graph left these words holding garbage
-    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<uint32_t*>(counters), (int64_t)4,
-                       reinterpret_cast<uint32_t*>(sums), (int64_t)4);
+                              bool counters_are_zero, hipStream_t s) {
+    // zeroed by a kernel — this one, unless the rollout's fpv_rollout_begin has done it
+    if (!counters_are_zero)
+        hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<uint32_t*>(counters), (int64_t)4,
+                           reinterpret_cast<uint32_t*>(sums), (int64_t)4);
     LedgerScanArgs a{led_count, led_idx, led_info, led_tag, led_ret, led_obs, tick, snapshots, tiles, stride, cap,
                      rows, T, obs_words, 0, clip_obs, eps, tobs, t_idx, d_idx, counters, sums};
     const int64_t slots = tiles * rows, per_block = 256 * kScanPerThread;

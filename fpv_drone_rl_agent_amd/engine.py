@@ -185,10 +185,11 @@ class FpvEngine:
     def ledger_clear(self) -> None:
         L.check(self.lib.fpv_ledger_clear(self._h, _stream(self.device)), "fpv_ledger_clear")
 
-    def rollout_begin(self, starts_dst=None, starts_src=None) -> None:
-        """fpv_rollout_begin: ledger_clear() and the episode-start carry (starts_dst <- starts_src, uint8 [num_envs]) as one
-        kernel."""
-        L.check(self.lib.fpv_rollout_begin(self._h, _ptr(starts_dst), _ptr(starts_src), _stream(self.device)), "fpv_rollout_begin")
+    def rollout_begin(self, starts_dst=None, starts_src=None, scan_counters=None, scan_sums=None) -> None:
+        """fpv_rollout_begin: ledger_clear(), the episode-start carry (starts_dst <- starts_src, uint8 [num_envs]) and the zeroing
+        of the words this rollout's ledger scan will accumulate into (int32[4], float64[2]) as one kernel."""
+        L.check(self.lib.fpv_rollout_begin(self._h, _ptr(starts_dst), _ptr(starts_src), _ptr(scan_counters), _ptr(scan_sums),
+                                           _stream(self.device)), "fpv_rollout_begin")
 
     def ledger_rows(self):
         """Device-side compaction of the per-tile ledger: (total_appended, flat row indices [k]) — one

@@ -26,9 +26,10 @@ def _need(t, dtype, name):
 
 
 def gae(rewards, values, episode_starts, last_values, last_dones, gamma=0.99, lam=0.95,
-        advantages=None, returns=None, stats=None):
+        advantages=None, returns=None, stats=None, mean_std=None):
     """rewards/values [T,N] f32, episode_starts [T,N] u8, last_values [N] f32, last_dones [N] u8.
-    Returns (advantages, returns); stats (optional f64[3]) gets {count, sum A, sum A^2}."""
+    Returns (advantages, returns); stats (optional f64[3]) gets {count, sum A, sum A^2}, mean_std (optional f64[2], needs
+    stats) {mean, population std} of this shard's advantages in the same launch."""
     T, n = rewards.shape
     for t, dt, nm in ((rewards, torch.float32, "rewards"), (values, torch.float32, "values"),
                       (episode_starts, torch.uint8, "episode_starts"), (last_values, torch.float32, "last_values"),
@@ -40,10 +41,12 @@ def gae(rewards, values, episode_starts, last_values, last_dones, gamma=0.99, la
         returns = torch.empty_like(rewards)
     if stats is not None:
         _need(stats, torch.float64, "stats")
+    if mean_std is not None:
+        _need(mean_std, torch.float64, "mean_std")
     lib = L.load()
     L.check(lib.fpv_gae(T, n, _ptr(rewards), _ptr(values), _ptr(episode_starts), _ptr(last_values),
                         _ptr(last_dones), float(gamma), float(lam), _ptr(advantages), _ptr(returns), _ptr(stats),
-                        _stream(rewards.device)), "fpv_gae")
+                        _ptr(mean_std), _stream(rewards.device)), "fpv_gae")
     return advantages, returns
 
 
@@ -128,12 +131,13 @@ def advantage_stats(gathered, out):
                                          _stream(gathered.device)), "fpv_advantage_stats")
 
 
-def ledger_scan(engine, T, *, snapshots, clip_obs, eps, tobs, t_idx, d_idx, counters, sums):
+def ledger_scan(engine, T, *, snapshots, clip_obs, eps, tobs, t_idx, d_idx, counters, sums, prezeroed=False):
     """fpv_ledger_scan on the engine's done ledger: episode statistics + the dense list of truncated-not-terminated
-    episode ends of the last T agent steps (see include/fpv_env.h).  No host synchronisation."""
+    episode ends of the last T agent steps (see include/fpv_env.h).  No host synchronisation.
+    prezeroed: counters / sums were zeroed by this rollout's engine.rollout_begin(scan_counters=, scan_sums=)."""
     L.check(L.load().fpv_ledger_scan(engine._h, _ptr(snapshots), snapshots.shape[1] if snapshots is not None else 0, int(T),
                                      float(clip_obs), float(eps), _ptr(tobs), _ptr(t_idx), _ptr(d_idx), tobs.shape[0],
-                                     _ptr(counters), _ptr(sums), _stream(tobs.device)), "fpv_ledger_scan")
+                                     _ptr(counters), _ptr(sums), 1 if prezeroed else 0, _stream(tobs.device)), "fpv_ledger_scan")
 
 
 def ledger_scatter(counters, t_idx, d_idx, values, gamma, rewards):

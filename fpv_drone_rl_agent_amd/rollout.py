@@ -182,6 +182,7 @@ class RolloutCollector:
         self._rollouts = 0
         self._episodes_host = {"count": 0, "ep_len_mean": float("nan"), "ep_rew_mean": float("nan"), "truncated": 0}
         self._graphs = [None, None]
+        self._scan_prezeroed = False
         self._tick0 = 0
         self._started = False
 
@@ -328,8 +329,11 @@ class RolloutCollector:
         self._starts[t + 1].copy_(self.done)
 
     def _all_steps(self) -> None:
+        self._scan_prezeroed = False
         if self.fused_policy and self.N % 16 == 0:
-            self.engine.rollout_begin(self._starts[0], self._starts[self.T])     # ledger clear + episode-start carry: one kernel
+            # ledger clear + episode-start carry + zeroing of the words the tail's ledger scan accumulates into: one kernel
+            self.engine.rollout_begin(self._starts[0], self._starts[self.T], self._led_counters, self._led_sums)
+            self._scan_prezeroed = True
         else:
             if self.fused_policy:
                 self.engine.ledger_clear()
@@ -381,11 +385,13 @@ class RolloutCollector:
                 self.buf_rew.copy_(self.raw_rew)
         ops.ledger_scan(eng, self.T, snapshots=self.snap if self.norm_obs else None, clip_obs=self.obs_norm.clip,
                         eps=self.obs_norm.eps, tobs=self._tobs, t_idx=self._t_idx, d_idx=self._d_idx,
-                        counters=self._led_counters, sums=self._led_sums)
+                        counters=self._led_counters, sums=self._led_sums, prezeroed=self._scan_prezeroed)
         self.fp.forward(self._tobs, value=self._tv, deterministic=True, nets="v", n_dev=self._led_counters[0:1])
         ops.ledger_scatter(self._led_counters, self._t_idx, self._d_idx, self._tv, self.gamma, self.buf_rew)
+        # one rank: the advantage mean / std come out of the GAE launch itself (with several ranks: after the all-gather)
         ops.gae(self.buf_rew, self.buf_val, self.buf_start, self.last_val, self.episode_start, self.gamma,
-                self.lam, advantages=self.adv, returns=self.ret, stats=self.stats)
+                self.lam, advantages=self.adv, returns=self.ret, stats=self.stats,
+                mean_std=self._adv_ms[self._slot] if D.world_size() == 1 else None)
 
     # ------------------------------------------------------------------ public API
     def start(self) -> None:
@@ -412,6 +418,7 @@ class RolloutCollector:
                 self._step(0)
                 self._merge_tail(0)
                 if self.fused_policy:
+                    self._scan_prezeroed = False   # (no rollout_begin ahead of this warm-up tail)
                     self._tail()            # first-call allocations of the tail (reduction scratch) happen here
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
@@ -482,8 +489,9 @@ class RolloutCollector:
                 self._status_host[k].copy_(self._post[k][0:8], non_blocking=True)
                 self._status_event[k].record(post)
                 self._status_pending[k] = True
-            gathered = D.allgather_payload(self._stats_k[k])        # the one collective per update (a view at one rank)
-            ops.advantage_stats(gathered, self._adv_ms[k])
+            if not (self.fused_policy and D.world_size() == 1):     # (one rank, fused tail: fpv_gae has written mean / std already)
+                gathered = D.allgather_payload(self._stats_k[k])    # the one collective per update (a view at one rank)
+                ops.advantage_stats(gathered, self._adv_ms[k])
             self._stats_done[k].record(post)
         self._stats_last = k
         self._tick0 += self.T

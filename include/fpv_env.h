@@ -203,10 +203,13 @@ int fpv_get_tick(fpv_env* env, uint64_t* tick_host, void* stream);
 
 int fpv_ledger_view(fpv_env* env, fpv_ledger* out);
 int fpv_ledger_clear(fpv_env* env, void* stream);
-/* Start of a rollout in one launch: fpv_ledger_clear, and the episode-start flags carried over from the end of the previous
- * rollout (starts_dst[i] = starts_src[i] for the handle's num_envs drones; both NULL to skip; 16-byte aligned).  A kernel, so
- * that a captured rollout holds no memcpy node. */
-int fpv_rollout_begin(fpv_env* env, uint8_t* starts_dst, const uint8_t* starts_src, void* stream);
+/* Start of a rollout in one launch: fpv_ledger_clear, the episode-start flags carried over from the end of the previous
+ * rollout (starts_dst[i] = starts_src[i] for the handle's num_envs drones; both NULL to skip; 16-byte aligned), and — when
+ * given — the words fpv_ledger_scan will accumulate into at the end of this rollout set to zero (scan_counters[4],
+ * scan_sums[2]; both or neither; fpv_ledger_scan is then called with counters_are_zero = 1 and needs no launch of its own for
+ * that).  A kernel, so that a captured rollout holds no memcpy / memset node. */
+int fpv_rollout_begin(fpv_env* env, uint8_t* starts_dst, const uint8_t* starts_src, int32_t* scan_counters, double* scan_sums,
+                      void* stream);
 /* Replace the handle-owned ledger by caller-owned device buffers (same layout as fpv_ledger;
  * ep_return / obs in the handle's precision; count has ceil(num_envs / 64) entries and capacity
  * must equal that tile count times rows_per_tile).  The caller keeps them alive until
@@ -218,10 +221,14 @@ int fpv_ledger_bind(fpv_env* env, const fpv_ledger* buffers);
 /* SB3 RolloutBuffer.compute_returns_and_advantage: rewards / values / episode_starts are
  * [T][n] (time-major), last_values / last_dones [n]; writes advantages / returns [T][n].
  * stats (optional, device double[3]) receives {count, sum(A), sum(A^2)} of this shard —
- * the payload of the one all-gather per update. */
+ * the payload of the one all-gather per update.  mean_std (optional, device double[2]; needs stats)
+ * receives {mean, population std} of THIS shard's advantages in the same launch: what fpv_advantage_stats derives from the
+ * gathered payload when there is one rank only.
+ * The handle-less primitives (fpv_gae, fpv_normalize*, fpv_moments_merge*) share one reduction scratch per device: calls on
+ * different streams of one device must not overlap. */
 int fpv_gae(int64_t T, int64_t n, const float* rewards, const float* values,
             const uint8_t* episode_starts, const float* last_values, const uint8_t* last_dones,
-            float gamma, float lam, float* advantages, float* returns, double* stats,
+            float gamma, float lam, float* advantages, float* returns, double* stats, double* mean_std,
             void* stream);
 
 /* SB3 VecNormalize running moments (train_hover.py:43): merge the batch x [n][d] into
@@ -251,9 +258,11 @@ int fpv_advantage_stats(const double* gathered, int32_t world, int32_t stride, d
  * truncated-not-terminated entries as a dense list: t_idx[k] (step within the rollout), d_idx[k] (drone), tobs[k][O]
  * (terminal observation, normalised with snapshots[t_idx[k]] = {mean[O], var[O], ...} when snapshots != NULL).
  * The value net then runs over tobs with fpv_policy_io.n_dev = &counters[0], and fpv_ledger_scatter adds
- * gamma * values[k] to rewards[t_idx[k]][d_idx[k]] ([T][n]).  The list order is arbitrary, the result is not. */
+ * gamma * values[k] to rewards[t_idx[k]][d_idx[k]] ([T][n]).  The list order is arbitrary, the result is not.
+ * counters_are_zero != 0: counters / sums were zeroed by this rollout's fpv_rollout_begin (else a small launch zeroes them here). */
 int fpv_ledger_scan(fpv_env* env, const double* snapshots, int64_t snapshot_stride, int32_t T, float clip_obs, float eps_norm,
-                    float* tobs, int32_t* t_idx, int32_t* d_idx, int64_t cap, int32_t* counters, double* sums, void* stream);
+                    float* tobs, int32_t* t_idx, int32_t* d_idx, int64_t cap, int32_t* counters, double* sums,
+                    int32_t counters_are_zero, void* stream);
 int fpv_ledger_scatter(const int32_t* counters, const int32_t* t_idx, const int32_t* d_idx, const float* values, float gamma,
                        float* rewards, int64_t n, int64_t cap, void* stream);
 

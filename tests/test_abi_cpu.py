@@ -78,11 +78,11 @@ def test_argument_errors_reported_without_gpu():
     assert lib.fpv_create(None, None) == -1
     assert b"null" in lib.fpv_last_error()
     assert lib.fpv_step(None, None, None, None, None, None, None) == -1
-    assert lib.fpv_gae(0, 0, None, None, None, None, None, 0.99, 0.95, None, None, None, None) == -1
+    assert lib.fpv_gae(0, 0, None, None, None, None, None, 0.99, 0.95, None, None, None, None, None) == -1
     assert lib.fpv_destroy(None) == 0
     assert lib.fpv_rollout_step(None, None, None, None, None, None, None, None) == -1 and b"fpv_rollout_step" in lib.fpv_last_error()
     assert lib.fpv_rollout_steps(None, None, None, None) == -1 and b"fpv_rollout_steps" in lib.fpv_last_error()
-    assert lib.fpv_rollout_begin(None, None, None, None) == -1
+    assert lib.fpv_rollout_begin(None, None, None, None, None, None) == -1
     with pytest.raises(ValueError):
         _lib.check(-1, "x")
     with pytest.raises(RuntimeError):
