@@ -1,4 +1,4 @@
-"""ctypes binding of libfpv_env.so — exactly the symbols include/fpv_env.h declares.
+"""ctypes binding of libfpv_env.so — exactly the symbols include/fpv_env.h (and, apart, fpv_env_debug.h) declare.
 
 The library is the product's only compute path: if it is missing or fails to load this
 module raises; there is no CPU or PyTorch fallback.
@@ -100,6 +100,7 @@ SIGNATURES = {
     "fpv_rollout_begin": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "fpv_ledger_bind": (C.c_int, [_vp, C.POINTER(FpvLedger)]),
     "fpv_advantage_stats": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "fpv_rank_merge": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "fpv_ledger_scan": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp]),
     "fpv_ledger_scatter": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _vp, _i64, _i64, _vp]),
     "fpv_gae": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
@@ -116,12 +117,17 @@ SIGNATURES = {
     "fpv_ppo_workspace_bytes": (C.c_int, [_vp, _i64, C.POINTER(_i64)]),
     "fpv_ppo_grad": (C.c_int, [_vp, C.POINTER(FpvPpoIo), _vp]),
     "fpv_adam_clip_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp]),
-    "fpv_set_pair_threshold": (C.c_int, [_i64]),
-    "fpv_noop": (C.c_int, [_vp]),
-    "fpv_debug_rollout_stamps": (C.c_int, [_vp]),
-    "fpv_debug_rollout_timeout": (C.c_int, [_u64]),
     "fpv_last_error": (C.c_char_p, []),
     "fpv_version": (C.c_int, []),
+}
+# include/fpv_env_debug.h: diagnostic hooks (tools/, bench.py's phase report, tests) — not the product interface
+DEBUG_SIGNATURES = {
+    "fpv_set_pair_threshold": (C.c_int, [_i64]),
+    "fpv_noop": (C.c_int, [_vp]),
+    "fpv_debug_rollout_stamps": (C.c_int, [_vp, _vp]),
+    "fpv_debug_rollout_timeout": (C.c_int, [_vp, _u64]),
+    "fpv_debug_memset": (C.c_int, [_vp, _i32, _i64, _vp]),
+    "fpv_debug_atomic_inc": (C.c_int, [_vp, _i64, _vp]),
 }
 
 _lib = None
@@ -137,8 +143,8 @@ def load(build_if_missing: bool = True):
             raise RuntimeError(f"{LIB_PATH} is missing: build it with fpv_drone_rl_agent_amd.build.build_extension()")
         build_extension()
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError if the ABI and the header drift apart
+    for name, (res, args) in {**SIGNATURES, **DEBUG_SIGNATURES}.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and the headers drift apart
         fn.restype, fn.argtypes = res, args
     built = lib.fpv_version()
     if built != ABI_VERSION:         # struct layouts / enum values differ between versions: refuse before the first real call

@@ -88,6 +88,7 @@ def open_stats_archive(path: str):
 def save_normalizer(path: str, collector, format=None) -> None:
     """model.env.save(path) — the rollout collector's VecNormalize statistics, vec_env.VecNormalize.load-compatible."""
     check_stats_save_path(path, format)
+    collector.wait_stats()      # several ranks: the statistics over ALL ranks' drones are written behind the collective
     rms, rr = collector.obs_norm.rms.cpu().numpy(), collector.rew_norm.rms.cpu().numpy()
     d = collector.obs_norm.dim
     with open(path, "wb") as f:

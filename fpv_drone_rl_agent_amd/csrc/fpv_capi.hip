@@ -3,6 +3,7 @@
 // ledger and the tick; launches the kernels of fpv_step.hip / fpv_rollout.hip on the
 // caller's stream.  No allocation and no host synchronisation inside fpv_step.
 #include "../../include/fpv_env.h"
+#include "../../include/fpv_env_debug.h"
 #include "fpv_dynamics.h"
 #include "fpv_internal.h"
 
@@ -40,6 +41,8 @@ struct fpv_env {
     uint64_t* tick;      // device [tiles]
     uint32_t* merge_ticket;   // device counter of the in-launch statistics merge (zero between launches)
     uint32_t* rollout_sync;   // barrier words of fpv_rollout_steps (zeroed on the stream before every launch)
+    uint64_t* stamps;         // fpv_debug_rollout_stamps: diagnostic buffer of this handle's rollout kernels, or null
+    uint64_t timeout_ticks;   // fpv_debug_rollout_timeout: 0 = the default bound of fpv_rollout_steps' grid-wide waits
     uint32_t* led_count;
     int32_t* led_idx;
     uint32_t* led_info;
@@ -136,14 +139,33 @@ int fpv_set_pair_threshold(int64_t max_drones) {
     return FPV_OK;
 }
 
-int fpv_debug_rollout_stamps(uint64_t* device_buffer) {
-    fpv::g_rollout_stamps = device_buffer;
+int fpv_debug_rollout_stamps(fpv_env* e, uint64_t* device_buffer) {
+    if (!e) return fail(FPV_ERR_ARG, "fpv_debug_rollout_stamps: null handle");
+    e->stamps = device_buffer;
     return FPV_OK;
 }
 
-static uint64_t g_rollout_timeout_ticks = 0;     // 0: the default of fpv_rollout_steps
-int fpv_debug_rollout_timeout(uint64_t ticks) {
-    g_rollout_timeout_ticks = ticks;
+int fpv_debug_rollout_timeout(fpv_env* e, uint64_t ticks) {
+    if (!e) return fail(FPV_ERR_ARG, "fpv_debug_rollout_timeout: null handle");
+    e->timeout_ticks = ticks;
+    return FPV_OK;
+}
+
+__global__ void fpv_atomic_inc_kernel(uint32_t* w, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&w[i], 1u);
+}
+
+int fpv_debug_memset(void* dst, int32_t value, int64_t bytes, void* stream) {
+    if (!dst || bytes <= 0) return fail(FPV_ERR_ARG, "fpv_debug_memset: null destination or no bytes");
+    FPV_HIP(hipMemsetAsync(dst, value, (size_t)bytes, (hipStream_t)stream));
+    return FPV_OK;
+}
+
+int fpv_debug_atomic_inc(uint32_t* words, int64_t n, void* stream) {
+    if (!words || n <= 0) return fail(FPV_ERR_ARG, "fpv_debug_atomic_inc: null words or n <= 0");
+    hipLaunchKernelGGL(fpv_atomic_inc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, words, n);
+    FPV_HIP(hipGetLastError());
     return FPV_OK;
 }
 
@@ -422,6 +444,16 @@ int fpv_advantage_stats(const double* gathered, int32_t world, int32_t stride, d
     return FPV_OK;
 }
 
+int fpv_rank_merge(const double* gathered, int32_t world, int32_t stride, int32_t obs_words, const double* base_obs_rms,
+                   const double* base_ret_rms, double* obs_rms, double* ret_rms, void* stream) {
+    if (!gathered || world <= 0 || obs_words <= 0 || obs_words > 32) return fail(FPV_ERR_ARG, "fpv_rank_merge: bad arguments");
+    if (stride < 3 + 2 * obs_words + 1 + 3) return fail(FPV_ERR_ARG, "fpv_rank_merge: rows hold {adv[3], obs_rms[2 O + 1], ret_rms[3]}");
+    if ((base_obs_rms == nullptr) != (obs_rms == nullptr) || (base_ret_rms == nullptr) != (ret_rms == nullptr))
+        return fail(FPV_ERR_ARG, "fpv_rank_merge: give a statistics buffer together with its base, or neither");
+    FPV_HIP(launch_rank_merge(gathered, world, stride, obs_words, base_obs_rms, base_ret_rms, obs_rms, ret_rms, (hipStream_t)stream));
+    return FPV_OK;
+}
+
 int fpv_ledger_scan(fpv_env* e, const double* snapshots, int64_t snapshot_stride, int32_t T, float clip_obs, float eps_norm,
                     float* tobs, int32_t* t_idx, int32_t* d_idx, int64_t cap, int32_t* counters, double* sums,
                     int32_t counters_are_zero, void* stream) {
@@ -635,7 +667,7 @@ int fpv_rollout_step(fpv_env* e, fpv_policy* p, const fpv_policy_io* io, float* 
     a.gamma = ex ? ex->gamma : 0.0f;
     a.mg_count = (double)e->cfg.num_envs;
     FPV_HIP(launch_rollout_step(p->image, io->rms, io->obs_n, io->action, io->clipped, io->value, io->logp, io->seed, io->id_offset,
-                                io->clip_obs, io->eps_norm, mg, a, yaw ? 1 : 0, (hipStream_t)stream));
+                                io->clip_obs, io->eps_norm, mg, a, yaw ? 1 : 0, e->stamps, (hipStream_t)stream));
     return FPV_OK;
 }
 
@@ -692,7 +724,8 @@ int fpv_rollout_steps(fpv_env* e, fpv_policy* p, const fpv_rollout_io* io, void*
     h.rows[0] = io->partials[0]; h.rows[1] = io->partials[1];
     h.sync = e->rollout_sync; h.status = io->status;
     // 2 s of the 100 MHz counter: far beyond any step, short enough to end a stuck launch (fpv_debug_rollout_timeout overrides)
-    h.timeout_ticks = g_rollout_timeout_ticks ? g_rollout_timeout_ticks : 200000000ull;
+    h.timeout_ticks = e->timeout_ticks ? e->timeout_ticks : 200000000ull;
+    h.stamps = e->stamps;
     FPV_HIP(launch_rollout_persistent(h, a, (hipStream_t)stream));
     return FPV_OK;
 }

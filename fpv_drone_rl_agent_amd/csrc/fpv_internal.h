@@ -192,6 +192,8 @@ __device__ __forceinline__ float half_sum(float v) {
 }
 
 hipError_t launch_advantage_stats(const double* gathered, int world, int stride, double* out, hipStream_t s);
+hipError_t launch_rank_merge(const double* gathered, int world, int stride, int d, const double* base_obs, const double* base_ret,
+                             double* out_obs, double* out_ret, hipStream_t s);
 hipError_t launch_zero_words(uint32_t* a, int64_t n, hipStream_t s);
 hipError_t launch_rollout_begin(uint32_t* counts, int64_t tiles, uint8_t* dst, const uint8_t* src, int64_t n, int32_t* scan_counters,
                                 double* scan_sums, hipStream_t s);
@@ -322,7 +324,7 @@ int policy16_image_floats();
 // fpv_rollstep.hip
 hipError_t launch_rollout_step(const float* image, const double* rms, float* obs_n, float* action, float* clipped, float* value,
                                float* logp, uint64_t pol_seed, uint64_t pol_id_offset, float clip_obs, float eps_norm,
-                               const MergeArgs& merge, const StepArgs<float>& st, int yaw, hipStream_t s);
+                               const MergeArgs& merge, const StepArgs<float>& st, int yaw, uint64_t* stamps, hipStream_t s);
 struct RollPersistHost {     // host-side description of a T-step launch (fpv_rollout_steps); fields as RollPersistArgs, fpv_rollstep.hip
     const float* image;
     uint64_t pol_seed, pol_id_offset;
@@ -337,10 +339,10 @@ struct RollPersistHost {     // host-side description of a T-step launch (fpv_ro
     double* rows[2];
     uint32_t *sync, *status;
     uint64_t timeout_ticks;
+    uint64_t* stamps;        // diagnostic phase stamps (fpv_debug_rollout_stamps), or null
 };
 hipError_t launch_rollout_persistent(const RollPersistHost& h, const StepArgs<float>& st, hipStream_t s);
 int rollout_sync_words();
-extern uint64_t* g_rollout_stamps;   // diagnostic phase stamps of the persistent kernel (fpv_debug_rollout_stamps)
 // fpv_ppo.hip
 int64_t ppo_workspace_floats(int64_t rows, int cus);
 hipError_t launch_ppo_grad(const float* const* w, float* const* grads, const int64_t* index, const float* obs,

@@ -322,7 +322,10 @@ hipError_t launch_policy_forward(const float* image, const float* obs, const dou
                                  int in_dim, int act_dim, const MergeArgs& merge, const int32_t* n_dev, hipStream_t s) {
     // nets: 3 = pi + V (one launch), 1 = pi only (with the sampling epilogue), 2 = V only.
     // narrow: 256-thread workgroups (one wave per SIMD) so that other kernels can co-reside.
-    static bool attr_set = false;
+    static bool attr_tab[64] = {};                    // hipFuncSetAttribute holds for one device: one flag per ordinal
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    bool& attr_set = attr_tab[dev_ & 63];
     if (!attr_set) {
         const int full = (int)((2 * kNetFloats + (kImageFloats - kHeadBase) + 40) * sizeof(float)) + kMergeLdsBytes;
         hipError_t e = hipFuncSetAttribute((const void*)policy_forward_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, full);

@@ -324,7 +324,10 @@ hipError_t launch_policy_split_forward(const unsigned char* image, const float* 
                                        float* logp, float* eps_out, int64_t n, uint64_t seed, uint64_t id_offset,
                                        float clip_obs, float eps_norm, int deterministic, int max_blocks,
                                        const MergeArgs& merge, hipStream_t s) {
-    static bool attr_set = false;
+    static bool attr_tab[64] = {};                    // hipFuncSetAttribute holds for one device: one flag per ordinal
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    bool& attr_set = attr_tab[dev_ & 63];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)policy_split_forward_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLdsBytes);

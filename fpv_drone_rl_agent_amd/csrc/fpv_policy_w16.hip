@@ -404,7 +404,10 @@ hipError_t launch_policy16_forward(const float* image, const float* obs, const d
                                    float* action, float* clipped, float* value, float* logp, float* eps_out, int64_t n,
                                    uint64_t seed, uint64_t id_offset, float clip_obs, float eps_norm, int max_blocks, int in_dim,
                                    int act_dim, hipStream_t s) {
-    static bool attr_set = false;
+    static bool attr_tab[64] = {};                    // hipFuncSetAttribute holds for one device: one flag per ordinal
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    bool& attr_set = attr_tab[dev_ & 63];
     constexpr int kLds = w16::kLdsFloats * (int)sizeof(float);
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)policy_forward_w16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);

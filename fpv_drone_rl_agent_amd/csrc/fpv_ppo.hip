@@ -727,7 +727,10 @@ static hipError_t launch_ppo_grad_t(const float* const* w, float* const* grads, 
                                     const float* actions, const float* old_logp, const float* adv, const float* ret,
                                     int64_t rows, float clip_range, float vf_coef, float ent_coef, float* stats, float* ws,
                                     int in_dim, int act_dim, int cus, hipStream_t s) {
-    static bool attr_set = false;
+    static bool attr_tab[64] = {};                    // hipFuncSetAttribute holds for one device: one flag per ordinal
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    bool& attr_set = attr_tab[dev_ & 63];
     constexpr size_t lds_bytes = (size_t)(kTNet + kHeadFloats) * sizeof(float);
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)ppo_fwd_bwd_kernel<kFwdBwdThreads, ST>,

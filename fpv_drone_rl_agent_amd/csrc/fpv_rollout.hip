@@ -138,6 +138,49 @@ __global__ void advantage_stats_kernel(const double* __restrict__ gathered, int 
     out[1] = sqrt(var);
 }
 
+// Several ranks: VecNormalize's statistics in the same payload (SURVEY §8e "can ride in the same payload").  Every rank starts a
+// rollout from the same statistics `base` = {mean[d], var[d], count} and folds its own drones' samples into them step by step; its
+// row of the gathered payload carries what it holds afterwards.  What rank r added is recovered from (base, after_r) —
+//     c_b = c_1 - c_0,  m_b = (m_1 c_1 - m_0 c_0) / c_b,  M2_b = v_1 c_1 - v_0 c_0 - (m_b - m_0)^2 c_0 c_b / c_1
+// (the inverse of RunningMeanStd.update_from_moments) — and the ranks' batches are merged into `base` in rank order with that
+// very update: every rank derives the same bits, and they are the moments of the union of all ranks' samples.
+// One thread per channel; gathered rows: [adv stats 3][obs mean d, var d, count][ret mean, var, count].
+__global__ void rank_merge_kernel(const double* __restrict__ gathered, int world, int stride, int d, const double* __restrict__ base_obs,
+                                  const double* __restrict__ base_ret, double* __restrict__ out_obs, double* __restrict__ out_ret) {
+    const int c = threadIdx.x;
+    const bool obs_ch = c < d && base_obs != nullptr, ret_ch = c == d && base_ret != nullptr;
+    if (!obs_ch && !ret_ch) return;
+    const double m0 = obs_ch ? base_obs[c] : base_ret[0], v0 = obs_ch ? base_obs[d + c] : base_ret[1];
+    const double c0 = obs_ch ? base_obs[2 * d] : base_ret[2];
+    double mean = m0, var = v0, count = c0;
+    for (int r = 0; r < world; ++r) {
+        const double* row = gathered + (int64_t)r * stride + 3 + (obs_ch ? 0 : 2 * d + 1);
+        const double m1 = obs_ch ? row[c] : row[0], v1 = obs_ch ? row[d + c] : row[1], c1 = obs_ch ? row[2 * d] : row[2];
+        const double cb = c1 - c0;
+        if (!(cb > 0.0)) continue;                       // this rank added nothing
+        const double mb = (m1 * c1 - m0 * c0) / cb, db = mb - m0;
+        double vb = (v1 * c1 - v0 * c0 - db * db * c0 * cb / c1) / cb;
+        if (vb < 0.0) vb = 0.0;
+        const double delta = mb - mean, tot = count + cb;                                       // RunningMeanStd.update_from_moments
+        const double m2 = var * count + vb * cb + delta * delta * count * cb / tot;
+        mean += delta * cb / tot;
+        var = m2 / tot;
+        count = tot;
+    }
+    if (obs_ch) {
+        out_obs[c] = mean; out_obs[d + c] = var;
+        if (c == 0) out_obs[2 * d] = count;
+    } else {
+        out_ret[0] = mean; out_ret[1] = var; out_ret[2] = count;
+    }
+}
+
+hipError_t launch_rank_merge(const double* gathered, int world, int stride, int d, const double* base_obs, const double* base_ret,
+                             double* out_obs, double* out_ret, hipStream_t s) {
+    hipLaunchKernelGGL(rank_merge_kernel, dim3(1), dim3(64), 0, s, gathered, world, stride, d, base_obs, base_ret, out_obs, out_ret);
+    return hipGetLastError();
+}
+
 hipError_t launch_advantage_stats(const double* gathered, int world, int stride, double* out, hipStream_t s) {
     hipLaunchKernelGGL(advantage_stats_kernel, dim3(1), dim3(64), 0, s, gathered, world, stride, out);
     return hipGetLastError();
@@ -587,7 +630,8 @@ hipError_t launch_ledger_scan(const uint32_t* led_count, const int32_t* led_idx,
                               int obs_words, const double* snapshots, int64_t stride, int T, float clip_obs, float eps,
                               float* tobs, int32_t* t_idx, int32_t* d_idx, int64_t cap, int32_t* counters, double* sums,
                               bool counters_are_zero, hipStream_t s) {
-    // zeroed by a kernel — this one, unless the rollout's fpv_rollout_begin has done it
+    // zeroed by a kernel — this one, unless the rollout's fpv_rollout_begin has done it — never by hipMemsetAsync: a memset node
+    // in a captured graph may write garbage from the graph's second replay on (profiles/r03_graph_memset_probe.json)
     if (!counters_are_zero)
         hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<uint32_t*>(counters), (int64_t)4,
                            reinterpret_cast<uint32_t*>(sums), (int64_t)4);

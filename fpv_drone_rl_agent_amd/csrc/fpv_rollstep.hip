@@ -1040,13 +1040,14 @@ __global__ __launch_bounds__(512) void rollout_persistent_kernel(RollPersistArgs
 }
 
 // ---------------------------------------------------------------- launchers
-uint64_t* g_rollout_stamps = nullptr;
-
 // Preconditions (checked by fpv_rollout_step): fp32 handle with motor noise, n a multiple of 256, the task's policy widths.
 hipError_t launch_rollout_step(const float* image, const double* rms, float* obs_n, float* action, float* clipped, float* value,
                                float* logp, uint64_t pol_seed, uint64_t pol_id_offset, float clip_obs, float eps_norm,
-                               const MergeArgs& merge, const StepArgs<float>& st, int yaw, hipStream_t s) {
-    static bool attr_set = false;
+                               const MergeArgs& merge, const StepArgs<float>& st, int yaw, uint64_t* stamps, hipStream_t s) {
+    static bool attr_tab[64] = {};                    // hipFuncSetAttribute holds for one device: one flag per ordinal
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    bool& attr_set = attr_tab[dev_ & 63];
     const int full = (int)((2 * kNetFloats + (kImageFloats - kHeadBase) + 40) * sizeof(float)) + kMergeLdsBytes;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)rollout_step_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, full);
@@ -1055,7 +1056,7 @@ hipError_t launch_rollout_step(const float* image, const double* rms, float* obs
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    RollStepArgs p{image, rms, obs_n, action, clipped, value, logp, pol_seed, pol_id_offset, clip_obs, eps_norm, merge, st, g_rollout_stamps};
+    RollStepArgs p{image, rms, obs_n, action, clipped, value, logp, pol_seed, pol_id_offset, clip_obs, eps_norm, merge, st, stamps};
     if (yaw) hipLaunchKernelGGL(rollout_step_kernel<1>, dim3((unsigned)(st.n / 256)), dim3(512), (size_t)full, s, p);
     else hipLaunchKernelGGL(rollout_step_kernel<0>, dim3((unsigned)(st.n / 256)), dim3(512), (size_t)full, s, p);
     return hipGetLastError();
@@ -1064,7 +1065,10 @@ hipError_t launch_rollout_step(const float* image, const double* rms, float* obs
 int rollout_sync_words() { return kSyncWords; }
 
 hipError_t launch_rollout_persistent(const RollPersistHost& h, const StepArgs<float>& st, hipStream_t s) {
-    static bool attr_set = false;
+    static bool attr_tab[64] = {};                    // hipFuncSetAttribute holds for one device: one flag per ordinal
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    bool& attr_set = attr_tab[dev_ & 63];
     const int full = (int)((2 * kNetFloats + (kImageFloats - kHeadBase) + 40) * sizeof(float)) + kMergeLdsBytes;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)rollout_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, full);
@@ -1081,8 +1085,13 @@ hipError_t launch_rollout_persistent(const RollPersistHost& h, const StepArgs<fl
     p.snapshots = h.snapshots; p.snap_stride = h.snap_stride;
     p.rows[0] = h.rows[0]; p.rows[1] = h.rows[1];
     p.sync = h.sync; p.status = h.status; p.timeout_ticks = h.timeout_ticks;
-    p.stamps = g_rollout_stamps;
-    hipError_t e = hipMemsetAsync(h.sync, 0, sizeof(uint32_t) * kSyncCounterWords, s);
+    p.stamps = h.stamps;
+    // Zeroed by a kernel, not hipMemsetAsync: a memset node captured into a HIP graph is right on the graph's first replay only —
+    // from the second replay on it may fill the words with stale kernel-argument bytes (device-address fragments) instead of the
+    // value (tools/graph_memset_probe.py, profiles/r03_graph_memset_probe.json, tests/test_graph_memset_gpu.py).  Round 2 issued the
+    // memset here: the barrier words then held garbage from the second replay of a captured rollout on, every poll passed at
+    // once and the steps read the previous rollout's column sums without any wait timing out.
+    hipError_t e = launch_zero_words(h.sync, kSyncCounterWords, s);
     if (e != hipSuccess) return e;
     void* args[] = {&p};
     // cooperative launch: the runtime checks that the grid fits on the device at once (the barrier needs every workgroup resident)

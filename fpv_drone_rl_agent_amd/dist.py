@@ -80,3 +80,24 @@ def merge_moments(gathered_mean: torch.Tensor, gathered_var: torch.Tensor, gathe
         mean = mean + delta * bc / tot
         var, count = m2 / tot, tot
     return mean, var, count
+
+
+def merge_rank_statistics(base: torch.Tensor, after: torch.Tensor) -> torch.Tensor:
+    """Host-side statement of fpv_rank_merge (csrc/fpv_rollout.hip) for one RunningMeanStd: base = {mean[d], var[d], count}
+    that every rank started the rollout from, after [world, 2 d + 1] = what each rank holds at its end.  Each rank's batch is
+    recovered from (base, after_r) and merged into base in rank order -> the statistics of the union of all ranks' samples."""
+    d = (base.numel() - 1) // 2
+    m0, v0, c0 = base[:d].double(), base[d:2 * d].double(), base[2 * d].double()
+    mean, var, count = m0.clone(), v0.clone(), c0.clone()
+    for r in range(after.shape[0]):
+        m1, v1, c1 = after[r, :d].double(), after[r, d:2 * d].double(), after[r, 2 * d].double()
+        cb = c1 - c0
+        if not bool(cb > 0):
+            continue
+        mb = (m1 * c1 - m0 * c0) / cb
+        db = mb - m0
+        vb = torch.clamp((v1 * c1 - v0 * c0 - db * db * c0 * cb / c1) / cb, min=0.0)
+        delta, tot = mb - mean, count + cb
+        m2 = var * count + vb * cb + delta * delta * count * cb / tot
+        mean, var, count = mean + delta * cb / tot, m2 / tot, tot
+    return torch.cat([mean, var, count.reshape(1)])

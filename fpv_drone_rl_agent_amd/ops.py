@@ -131,6 +131,17 @@ def advantage_stats(gathered, out):
                                          _stream(gathered.device)), "fpv_advantage_stats")
 
 
+def rank_merge(gathered, obs_words, *, base_obs_rms=None, base_ret_rms=None, obs_rms=None, ret_rms=None):
+    """fpv_rank_merge: gathered [world, >= 3 + 2 O + 1 + 3] f64 rows {adv stats, obs_rms, ret_rms} after a rollout every rank began
+    from the base statistics -> obs_rms / ret_rms = statistics of the union of all ranks' samples (merged in rank order)."""
+    _need(gathered, torch.float64, "gathered")
+    for t in (base_obs_rms, base_ret_rms, obs_rms, ret_rms):
+        if t is not None:
+            _need(t, torch.float64, "statistics")
+    L.check(L.load().fpv_rank_merge(_ptr(gathered), gathered.shape[0], gathered.shape[1], int(obs_words), _ptr(base_obs_rms),
+                                    _ptr(base_ret_rms), _ptr(obs_rms), _ptr(ret_rms), _stream(gathered.device)), "fpv_rank_merge")
+
+
 def ledger_scan(engine, T, *, snapshots, clip_obs, eps, tobs, t_idx, d_idx, counters, sums, prezeroed=False):
     """fpv_ledger_scan on the engine's done ledger: episode statistics + the dense list of truncated-not-terminated
     episode ends of the last T agent steps (see include/fpv_env.h).  No host synchronisation.

@@ -179,6 +179,10 @@ class RolloutCollector:
         self._stats_ready = [torch.cuda.Event() for _ in range(2)]
         self._stats_done = [torch.cuda.Event() for _ in range(2)]
         self._stats_last = 0
+        # several ranks: VecNormalize's statistics ride in the same payload ({adv stats[3], obs_rms[2 O + 1], ret_rms[3]}); every
+        # rank starts a rollout from the statistics of the union of all ranks' samples so far (fpv_rank_merge) — kept here as the base
+        self._base_obs_rms = torch.zeros_like(self.obs_norm.rms)
+        self._base_ret_rms = torch.zeros_like(self.rew_norm.rms)
         self._rollouts = 0
         self._episodes_host = {"count": 0, "ep_len_mean": float("nan"), "ep_rew_mean": float("nan"), "truncated": 0}
         self._graphs = [None, None]
@@ -397,7 +401,14 @@ class RolloutCollector:
     def start(self) -> None:
         """VecNormalize.reset(): reset every drone, fold the first observation into the statistics."""
         self.engine.reset()
+        multi = D.world_size() > 1 and self.norm_obs
+        if multi:
+            self._base_obs_rms.copy_(self.obs_norm.rms)
         self._normalise_obs(self.engine.obs, self.cur_obs)
+        if multi:       # every rank's reset observations count: start from the statistics over all ranks' drones
+            gathered = D.allgather_payload(torch.cat([self.obs_norm.rms.new_zeros(3), self.obs_norm.rms, self.rew_norm.rms]))
+            ops.rank_merge(gathered, self.O, base_obs_rms=self._base_obs_rms, obs_rms=self.obs_norm.rms)
+            self._normalise_obs(self.engine.obs, self.cur_obs, update=False)
         self.rew_norm.ret.zero_()
         self._starts[self.T].fill_(1)
         self._tick0 = self.engine.get_tick()
@@ -453,10 +464,18 @@ class RolloutCollector:
             self.start()
         eng = self.engine
         k = self._slot = self._rollouts % 2
-        if self.use_graph and self._graph is None:
-            self._capture()
         main = torch.cuda.current_stream(self.device)
         main.wait_event(self._stats_done[k])                # this slot's words were last read two rollouts ago: no stall
+        multi = D.world_size() > 1 and (self.norm_obs or self.norm_reward)
+        if multi:
+            # the previous rollout's merged statistics are written by the side stream: this rollout starts from them, and they
+            # are the base its own samples are measured against (taken before the graphs' warm-up step, whose samples the
+            # statistics absorb like any other)
+            main.wait_event(self._stats_done[self._stats_last])
+            self._base_obs_rms.copy_(self.obs_norm.rms)
+            self._base_ret_rms.copy_(self.rew_norm.rms)
+        if self.use_graph and self._graph is None:
+            self._capture()
         if self.fused_policy:
             self._check_status(k)           # what this slot still holds is two rollouts old: no stall
             if self._persistent and self._rollouts:
@@ -490,8 +509,16 @@ class RolloutCollector:
                 self._status_event[k].record(post)
                 self._status_pending[k] = True
             if not (self.fused_policy and D.world_size() == 1):     # (one rank, fused tail: fpv_gae has written mean / std already)
-                gathered = D.allgather_payload(self._stats_k[k])    # the one collective per update (a view at one rank)
+                payload = self._stats_k[k]
+                if multi:                                           # VecNormalize's statistics ride in the same payload
+                    payload = torch.cat([self._stats_k[k], self.obs_norm.rms, self.rew_norm.rms])
+                gathered = D.allgather_payload(payload)             # the one collective per update (a view at one rank)
                 ops.advantage_stats(gathered, self._adv_ms[k])
+                if multi:                                           # every rank: statistics of the union of all ranks' samples
+                    ops.rank_merge(gathered, self.O, base_obs_rms=self._base_obs_rms if self.norm_obs else None,
+                                   base_ret_rms=self._base_ret_rms if self.norm_reward else None,
+                                   obs_rms=self.obs_norm.rms if self.norm_obs else None,
+                                   ret_rms=self.rew_norm.rms if self.norm_reward else None)
             self._stats_done[k].record(post)
         self._stats_last = k
         self._tick0 += self.T

@@ -249,6 +249,13 @@ int fpv_normalize_reward(int64_t n, const float* r, const uint8_t* done, float* 
  * (SURVEY 8e).  gathered [world][stride] (stride >= 3) -> mean_std[2] = {mean, population std} of the advantages over all
  * ranks, added in rank order (every rank derives the same bits). */
 int fpv_advantage_stats(const double* gathered, int32_t world, int32_t stride, double* mean_std, void* stream);
+/* VecNormalize's statistics ride in the same payload: gathered row r = {adv stats[3], obs_rms[2 O + 1], ret_rms[3]} as
+ * rank r holds them after a rollout that every rank started from base_obs_rms / base_ret_rms.  What each rank added is recovered
+ * from (base, its row) and merged into the base in rank order (RunningMeanStd.update_from_moments): obs_rms / ret_rms (may alias
+ * the bases) receive the statistics of the union of all ranks' samples, the same bits on every rank.  Either statistics may be
+ * left out (both pointers NULL).  simulation/train_hover.py:43's VecNormalize over ALL drones, once per update. */
+int fpv_rank_merge(const double* gathered, int32_t world, int32_t stride, int32_t obs_words, const double* base_obs_rms,
+                   const double* base_ret_rms, double* obs_rms, double* ret_rms, void* stream);
 
 /* ---- timeout bootstrap (SB3 OnPolicyAlgorithm.collect_rollouts: reward += gamma * V(terminal observation) where an
  * episode was truncated, hover.py:275, and not terminated) without a host round trip ----
@@ -418,23 +425,8 @@ int fpv_adam_clip_step(float* param, const float* grad, float* exp_avg, float* e
                        float* grad_norm, int64_t n, float lr, float beta1, float beta2, float eps, float max_grad_norm,
                        void* stream);
 
-/* Process-wide tuning knob: hover handles with at most `max_drones` drones (default 32 768) run the env step as a
- * physics wave + helper wave pair per 64-drone tile (the helper draws the motor noise one sub-step pair ahead and
- * stores the observation tile); that pays while the helper wave finds a SIMD of its own.  Larger handles use the
- * single-wave kernel.  0 disables the pair kernel.  Results are bit-identical either way. */
-int fpv_set_pair_threshold(int64_t max_drones);
-
-/* Launches an empty kernel on `stream`: the floor of this library's launch path, for calibrating event timings. */
-int fpv_noop(void* stream);
-
-/* Diagnostic: when device_buffer is not NULL, later fpv_rollout_steps launches write s_memrealtime (100 MHz) phase stamps
- * [workgroup][T][8] into it: 0 step begins, 1 policy done, 2 env step done, 3 arriving at the grid barrier, 4 barrier passed,
- * 5 statistics merged (tools/rollout_phases.py).  NULL switches it off again. */
-int fpv_debug_rollout_stamps(uint64_t* device_buffer);
-/* Diagnostic: bound of every grid-wide wait inside fpv_rollout_steps in ticks of the 100 MHz counter (0 = the default, 2 s).
- * A bound of one tick makes the first wait give up: the way tests/test_rollstep_gpu.py exercises the abandon path (every
- * workgroup leaves its loop, the status word is set, nothing hangs). */
-int fpv_debug_rollout_timeout(uint64_t ticks);
+/* Diagnostic hooks (phase stamps, launch-shape switches, calibration launches) are declared in fpv_env_debug.h: they are not
+ * part of the product interface. */
 
 const char* fpv_last_error(void);
 int fpv_version(void);

@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "fpv_env.h")).read()
+def _declared_symbols(header="fpv_env.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(fpv_[a-z0-9_]+)\s*\(", text)))
 
@@ -23,6 +23,10 @@ def test_header_symbols_all_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/fpv_env.h but not exported"
     assert sorted(_lib.SIGNATURES) == declared, "ctypes binding and header drifted apart"
+    debug = _declared_symbols("fpv_env_debug.h")            # diagnostic hooks live in their own header
+    assert sorted(_lib.DEBUG_SIGNATURES) == debug and not set(debug) & set(declared)
+    assert all(hasattr(lib, name) for name in debug)
+    assert not [n for n in declared if "debug" in n or n in ("fpv_noop", "fpv_set_pair_threshold")]
     # the version handshake (a host built against another header would pass structs of another size): header macro ==
     # library == binding; _lib.load() refuses a stale library
     macro = int(re.search(r"#define FPV_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "fpv_env.h")).read()).group(1))

@@ -64,6 +64,34 @@ def test_two_rank_allgather_matches_single_process():
     assert res[0][1:3] == res[1][1:3] and np.array_equal(res[0][3], res[1][3])
 
 
+def test_rank_merge_reference_equals_the_single_process_union():
+    """dist.merge_rank_statistics (the host statement of fpv_rank_merge): G ranks start a rollout from common statistics, each
+    folds its own samples in step by step (SB3 RunningMeanStd.update), the merge recovers each rank's batch and yields the
+    statistics of ONE process that saw every rank's samples — to rounding, and the same bits whichever rank computes it."""
+    from fpv_drone_rl_agent_amd import dist as D
+    from oracle import oracle as orc
+    rng = np.random.default_rng(7)
+    d, G = 20, 4
+    base = orc.RunningMeanStd((d,))
+    base.update(rng.normal(0.5, 2.0, (5000, d)))                     # what all ranks hold at the start of the rollout
+    b = torch.from_numpy(np.concatenate([base.mean, base.var, [base.count]]))
+    union = orc.RunningMeanStd((d,)); union.mean, union.var, union.count = base.mean.copy(), base.var.copy(), base.count
+    rows = []
+    for r in range(G):
+        mine = orc.RunningMeanStd((d,)); mine.mean, mine.var, mine.count = base.mean.copy(), base.var.copy(), base.count
+        for t in range(8):                                           # eight steps of this rank's drones
+            x = rng.normal(r - 1.0, 1.0 + 0.5 * r, (300 + 50 * r, d))
+            mine.update(x)
+            union.update(x)
+        rows.append(np.concatenate([mine.mean, mine.var, [mine.count]]))
+    merged = D.merge_rank_statistics(b, torch.from_numpy(np.stack(rows))).numpy()
+    assert merged[2 * d] == union.count
+    assert np.allclose(merged[:d], union.mean, rtol=1e-12, atol=1e-12) and np.allclose(merged[d:2 * d], union.var, rtol=1e-10)
+    # a rank that added nothing changes nothing
+    same = D.merge_rank_statistics(b, torch.stack([b, b])).numpy()
+    assert np.array_equal(same, b.numpy())
+
+
 def test_single_process_passthrough():
     from fpv_drone_rl_agent_amd import dist as D
     p = torch.tensor([10.0, 5.0, 30.0], dtype=torch.float64)

@@ -1,6 +1,7 @@
 """Two ranks on one GPU over gloo (rehearsal of the one-process-per-GPU layout): PPO.learn with the hand-written
 update kernels, gradient all-reduce per minibatch, shared early-stop decision.  Both ranks must end with bitwise
-identical parameters (same averaged gradients -> same Adam steps) although they simulate different drones."""
+identical parameters (same averaged gradients -> same Adam steps) although they simulate different drones, and with
+bitwise identical VecNormalize statistics (fpv_rank_merge over the one all-gather's payload)."""
 import os
 import subprocess
 import sys
@@ -29,7 +30,11 @@ model.learn(4 * 2048 * 16 * world)
 torch.cuda.synchronize()
 flat = torch.cat([p.detach().reshape(-1) for p in pol.parameters()]).cpu()
 assert torch.isfinite(flat).all()
-print("DIGEST", rank, hashlib.sha256(flat.numpy().tobytes()).hexdigest(), model.num_timesteps, flush=True)
+col.wait_stats()
+torch.cuda.synchronize()
+rms = torch.cat([col.obs_norm.rms, col.rew_norm.rms]).cpu()
+print("DIGEST", rank, hashlib.sha256(flat.numpy().tobytes()).hexdigest(), model.num_timesteps,
+      hashlib.sha256(rms.numpy().tobytes()).hexdigest(), float(col.obs_norm.rms[40]), flush=True)
 """
 
 
@@ -54,3 +59,8 @@ def test_two_rank_training_keeps_replicas_identical(tmp_path):
     dig = sorted(line.split()[1:] for out in outs for line in out.splitlines() if line.startswith("DIGEST"))
     assert len(dig) == 2 and dig[0][1] == dig[1][1], dig          # identical parameters on both ranks
     assert dig[0][2] == str(4 * 2048 * 16 * 2)                      # timesteps count every rank's drones
+    # VecNormalize's statistics ride in the one all-gather: after every update both ranks hold the statistics of the union of
+    # their drones' samples — bit-identical, and counting both ranks' samples (reset observations, the one warm-up step of the
+    # graph capture, 4 rollouts of 16 steps)
+    assert dig[0][3] == dig[1][3], dig
+    assert abs(float(dig[0][4]) - (2 * 2048 * (1 + 1 + 4 * 16) + 1e-4)) < 1e-3, dig

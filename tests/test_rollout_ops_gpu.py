@@ -154,3 +154,36 @@ def test_statistics_update_inside_step_fused_matches_the_merge_kernel(task, n):
     assert float(stats[0]["obs_rms"][2 * O]) == pytest.approx(1e-4 + 40 * n)
     for e in engs:
         e.close()
+
+
+def test_rank_merge_kernel_matches_the_host_statement(oracle):
+    """fpv_rank_merge (several ranks: VecNormalize's statistics over ALL ranks' drones from the one all-gather's payload) against
+    dist.merge_rank_statistics, whose equality with a single process over the union is a CPU test (tests/test_dist_gloo.py)."""
+    from fpv_drone_rl_agent_amd import dist as D
+    from fpv_drone_rl_agent_amd import ops
+    rng = np.random.default_rng(3)
+    for d in (20, 12):
+        G = 5
+        base_o = oracle.RunningMeanStd((d,)); base_o.update(rng.normal(1.0, 3.0, (4000, d)))
+        base_r = oracle.RunningMeanStd(()); base_r.update(rng.normal(-2.0, 5.0, 4000))
+        b_o = np.concatenate([base_o.mean, base_o.var, [base_o.count]])
+        b_r = np.array([base_r.mean, base_r.var, base_r.count])
+        rows = []
+        for r in range(G):
+            o = oracle.RunningMeanStd((d,)); o.mean, o.var, o.count = base_o.mean.copy(), base_o.var.copy(), base_o.count
+            q = oracle.RunningMeanStd(()); q.mean, q.var, q.count = base_r.mean, base_r.var, base_r.count
+            if r != 2:                                             # rank 2 adds nothing
+                for t in range(4):
+                    o.update(rng.normal(r, 1 + r, (500, d))); q.update(rng.normal(r, 2.0, 500))
+            rows.append(np.concatenate([[1.0, 2.0, 3.0], o.mean, o.var, [o.count], [q.mean, q.var, q.count]]))
+        g = torch.from_numpy(np.stack(rows)).cuda()
+        obs_rms, ret_rms = torch.from_numpy(b_o).cuda(), torch.from_numpy(b_r).cuda()
+        ops.rank_merge(g, d, base_obs_rms=obs_rms.clone(), base_ret_rms=ret_rms.clone(), obs_rms=obs_rms, ret_rms=ret_rms)
+        ref_o = D.merge_rank_statistics(torch.from_numpy(b_o), torch.from_numpy(np.stack(rows))[:, 3:3 + 2 * d + 1])
+        ref_r = D.merge_rank_statistics(torch.from_numpy(b_r), torch.from_numpy(np.stack(rows))[:, 3 + 2 * d + 1:])
+        assert torch.allclose(obs_rms.cpu(), ref_o, rtol=1e-13, atol=1e-13) and torch.allclose(ret_rms.cpu(), ref_r, rtol=1e-13, atol=1e-13)
+        assert float(obs_rms[2 * d]) == base_o.count + 4 * 4 * 500
+        # in place (the collector's use): bases aliasing the outputs
+        o2, r2 = torch.from_numpy(b_o).cuda(), torch.from_numpy(b_r).cuda()
+        ops.rank_merge(g, d, base_obs_rms=o2, base_ret_rms=r2, obs_rms=o2, ret_rms=r2)
+        assert torch.equal(o2, obs_rms) and torch.equal(r2, ret_rms)

@@ -190,29 +190,42 @@ def test_persistent_refuses_more_workgroups_than_cus():
 
 
 def test_persistent_rollout_replays_from_a_graph(oracle):
-    """The persistent launch (a cooperative launch behind a memset node) captured into the collector's HIP graphs: ticks advance
-    by n_steps per replay, the timeout word stays clear, outputs are finite and change from rollout to rollout."""
+    """The persistent launch (a cooperative launch behind the kernel that zeroes its barrier words) captured into the collector's
+    HIP graphs, replayed five times — each of the two graphs at least twice — against the same collector shape launched eagerly:
+    identical batches and statistics at every rollout.  (Round 2 zeroed the barrier words with a captured hipMemsetAsync: from a
+    graph's second replay on they held garbage — tests/test_graph_memset_gpu.py — and the steps read stale column sums.)"""
     from fpv_drone_rl_agent_amd.engine import FpvEngine
     from fpv_drone_rl_agent_amd.rollout import RolloutCollector
     n, T = 65536, 8
-    eng = FpvEngine(n, 0, seed=1, detector="analytic")
-    col = RolloutCollector(eng, _policy(2), n_steps=T, persistent=True)
-    col.start()
-    _synthetic(eng, oracle, 7)
-    t0 = eng.get_tick()
+    cols = []
+    for graph in (True, False):
+        eng = FpvEngine(n, 0, seed=1, detector="analytic")
+        col = RolloutCollector(eng, _policy(2), n_steps=T, persistent=True, use_graph=graph)
+        col.start()
+        if graph:
+            col._capture()                       # the capture's warm-up rollout comes first: load the common state after it
+        _synthetic(eng, oracle, 7)
+        eng.set_tick(1000)
+        cols.append(col)
+    cols[1].obs_norm.rms.copy_(cols[0].obs_norm.rms); cols[1].rew_norm.rms.copy_(cols[0].rew_norm.rms)
+    cols[1].rew_norm.ret.copy_(cols[0].rew_norm.ret); cols[1]._starts.copy_(cols[0]._starts)
+    cols[1].engine.obs.copy_(cols[0].engine.obs)
+    for c in cols:
+        c._tick0 = 1000
     prev = None
-    for r in range(3):
-        b = col.collect()
+    for r in range(5):
+        ba, bb = cols[0].collect(), cols[1].collect()
         torch.cuda.synchronize()
-        assert torch.isfinite(b["advantages"]).all() and torch.isfinite(b["obs"]).all()
+        for k in ("obs", "actions", "values", "log_probs", "advantages", "returns"):
+            assert torch.equal(ba[k], bb[k]), (r, k)
+        assert torch.equal(cols[0].obs_norm.rms, cols[1].obs_norm.rms) and torch.equal(cols[0].rew_norm.rms, cols[1].rew_norm.rms), r
+        assert torch.isfinite(ba["advantages"]).all()
         if prev is not None:
-            assert not torch.equal(prev, b["values"])
-        prev = b["values"].clone()
-    assert col._graph is not None
-    assert col._graphs[0] is not None and col._graphs[1] is not None
-    assert eng.get_tick() == t0 + 4 * T          # ONE warm-up rollout before both of the collector's alternating graphs are
-                                                 # captured (no discarded step after the first rollout), + three replays
-    assert col.episodes["count"] > 0             # reading the episode numbers checks the status words (timeout flag clear)
+            assert not torch.equal(prev, ba["values"])
+        prev = ba["values"].clone()
+    assert cols[0]._graphs[0] is not None and cols[0]._graphs[1] is not None
+    assert cols[0].engine.get_tick() == 1000 + 5 * T
+    assert cols[0].episodes["count"] > 0 and cols[0].episodes["count"] == cols[1].episodes["count"]   # (checks the timeout flag too)
 
 
 def test_persistent_rollout_gives_up_cleanly_when_a_grid_wait_times_out(oracle):
@@ -225,15 +238,16 @@ def test_persistent_rollout_gives_up_cleanly_when_a_grid_wait_times_out(oracle):
     lib = L.load()
     n, T = 65536, 6
     try:
-        lib.fpv_debug_rollout_timeout(1)
-        col = RolloutCollector(FpvEngine(n, 0, seed=4, detector="analytic"), _policy(3), n_steps=T, persistent=True, use_graph=False)
+        eng = FpvEngine(n, 0, seed=4, detector="analytic")
+        lib.fpv_debug_rollout_timeout(eng._h, 1)
+        col = RolloutCollector(eng, _policy(3), n_steps=T, persistent=True, use_graph=False)
         col.start()
         col.collect()
         torch.cuda.synchronize()                 # returns: the launch ended although its barrier never completed
         with pytest.raises(RuntimeError, match="timed out"):
             _ = col.episodes
     finally:
-        lib.fpv_debug_rollout_timeout(0)
+        lib.fpv_debug_rollout_timeout(eng._h, 0)
     col = RolloutCollector(FpvEngine(n, 0, seed=4, detector="analytic"), _policy(3), n_steps=T, persistent=True, use_graph=False)
     col.start()
     _synthetic(col.engine, oracle, 6)

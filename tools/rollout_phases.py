@@ -27,12 +27,12 @@ for _ in range(4):
     col.collect()
 grid = n // 256
 stamps = torch.zeros((grid, T, 8) if persistent else (grid, 16), dtype=torch.int64, device="cuda")
-L.load().fpv_debug_rollout_stamps(C.c_void_p(stamps.data_ptr()))
+L.load().fpv_debug_rollout_stamps(eng._h, C.c_void_p(stamps.data_ptr()))
 col._graph = None            # the stamp pointer is a kernel argument: capture again
 col.collect()
 col.collect()
 torch.cuda.synchronize()
-L.load().fpv_debug_rollout_stamps(None)
+L.load().fpv_debug_rollout_stamps(eng._h, None)
 s = stamps.cpu().numpy().astype(np.float64) / 100.0          # microseconds
 out = {"drones": n, "n_steps": T, "shape": "one launch per rollout" if persistent else "one launch per step"}
 if persistent:
