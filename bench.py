@@ -109,6 +109,11 @@ def host_mode_rate(n: int = 4096, steps: int = 200):
     env = VecNormalize(FpvVecEnv(n, noise_ratio=0.02, seed=0))
     torch.manual_seed(0)
     pol = ActorCritic()                                          # on the CPU
+    threads0 = torch.get_num_threads()
+    try:                                                         # torch sizes its pool by the host's cores, not by what this process may use
+        torch.set_num_threads(max(1, min(threads0, len(os.sched_getaffinity(0)), 16)))
+    except (AttributeError, OSError):
+        pass
     obs = env.reset()
     t_pol = 0.0
 
@@ -130,8 +135,10 @@ def host_mode_rate(n: int = 4096, steps: int = 200):
         obs = one(obs)
     dt = time.perf_counter() - t0
     env.close()
+    used = torch.get_num_threads()
+    torch.set_num_threads(threads0)
     return {"value": n * steps / dt, "unit": "env-steps/s", "drones": n, "us_per_step": round(dt / steps * 1e6, 1),
-            "us_per_step_policy_on_cpu": round(t_pol / steps * 1e6, 1), "cpu_threads_torch": torch.get_num_threads(),
+            "us_per_step_policy_on_cpu": round(t_pol / steps * 1e6, 1), "cpu_threads_torch": used,
             "workload": "BASELINE.json configs[1]: 4 096 hover drones, HIP env-step kernel, torch-CPU MlpPolicy, numpy in / out through "
                         "FpvVecEnv + VecNormalize (PCIe-inclusive)"}
 
@@ -383,6 +390,16 @@ def main() -> None:
             us_plain = timed(lambda: eng.step(act))
             env_bytes = 458 if yaw else ALG_BYTES_PER_STEP
             roofline_env_plain = hbm("fpv::yaw_step_kernel<float,true>" if yaw else "fpv::step_kernel<float,true,false>", us_plain, env_bytes)
+            if not yaw:
+                roofline_env_plain["detector"] = args.detector
+                if args.detector == "pixel" and world == 1:
+                    # the same stand-alone kernel with the analytic detector (the configuration of rounds 1-2 and of the N sweep in
+                    # profiles/r02_step_sweep.json): the pixel rules cost this kernel a serial row walk per drone, which the
+                    # rollout-step kernel spreads over two waves
+                    ea = FpvEngine(n, dev, noise_ratio=0.02, seed=0, detector="analytic")
+                    ea.set_state(torch.from_numpy(synthetic_states(n, seed=0)))
+                    roofline_env_plain["same_kernel_with_the_analytic_detector"] = hbm("fpv::step_kernel<float,true,false>", timed(lambda: ea.step(act)), env_bytes)
+                    ea.close()
             pol_flop = 2 * (2 * (12 * 128 + 128 * 128) + 128 * 1 + 128) if yaw else POLICY_FLOP_PER_ROW
             env_flop = 0 if yaw else ENV_FLOP_PER_STEP      # (the yaw env step's operations have not been counted: left out)
             if col.fused and col._one_launch:
