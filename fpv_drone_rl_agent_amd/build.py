@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libfpv_env.so")
 SOURCES = ["fpv_step.hip", "fpv_yaw.hip", "fpv_rollout.hip", "fpv_policy.hip", "fpv_policy_w16.hip", "fpv_policy_split.hip", "fpv_rollstep.hip", "fpv_ppo.hip", "fpv_capi.hip"]
-HEADERS = ["fpv_dynamics.h", "fpv_internal.h", "fpv_mlp.h", "fpv_policy_image.h", "fpv_step_parts.h", "fpv_yaw_parts.h",
+HEADERS = ["fpv_dynamics.h", "fpv_internal.h", "fpv_mlp.h", "fpv_policy_image.h", "fpv_step_parts.h", "fpv_yaw_parts.h", "fpv_pixel_tile.h",
            os.path.join("..", "..", "include", "fpv_env.h"), os.path.join("..", "..", "include", "fpv_env_debug.h")]
 
 

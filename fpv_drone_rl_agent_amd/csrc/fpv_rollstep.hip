@@ -22,6 +22,7 @@
 // VecNormalize of simulation/train_hover.py:43-58.
 #include "fpv_mlp.h"
 #include "fpv_policy_image.h"
+#include "fpv_pixel_tile.h"
 #include "fpv_step_parts.h"
 #include "fpv_yaw_parts.h"
 
@@ -53,20 +54,12 @@ constexpr int kRsXch = kRsTile + 4 * kRsTileFloats;         // per tile: 128 dou
 constexpr int kRsSum = kRsXch + 4 * 256;                    // 4 x kPartialWords doubles
 static_assert((kRsXch * 4) % 8 == 0 && (kRsSum * 4) % 8 == 0, "fp64 areas must be 8-byte aligned");
 static_assert(kRsSum + 2 * 4 * kPartialWords <= 2 * kNetFloats, "phase-2 exchange must fit in the weight image's space");
-// Pixel detector (hover.py:157-222, SPEC §6b): the blob's rows as work items of the tile's two waves.  Per tile, above the rest
-// of the phase-2 map: the corner block [4][64] f32x4 (u, v, edge slopes, {first span-table entry, jlo, jhi, rows per item} of
-// every drone), the drones' integer accumulators, the item list (kPixItems packed words + the item count) and the span table.
-constexpr int kPixItems = 2 * kTile;                        // one item per lane of the tile's two waves: the chunk size is chosen for that
-constexpr int kPixMinChunk = 2;                             // rows per item at least
-constexpr int kPixAcc = 4 * kTile * 4;                      // floats from the tile's base: behind the corner block [4][64] f32x4
-constexpr int kPixSlots = kPixAcc + 3 * kTile * 4;          // per-drone accumulators [3][64] int4, then the item list
-constexpr int kPixTab = kPixSlots + kPixItems + 4;          // item list: kPixItems packed items, then the item count; then the span table
-constexpr int kPixSpanCap = kTile * 128;                    // u16 entries: a | b << 8 per row, the tile's drones one after the other (every
-                                                            // drone could have all 128 rows)
-constexpr int kPixTileFloats = kPixTab + kPixSpanCap / 2;
+// Pixel detector (hover.py:157-222, SPEC §6b): the blob's rows as work items of the tile's two waves (fpv_pixel_tile.h).  Per tile,
+// above the rest of the phase-2 map: corner block, accumulators, item list and a span table that holds every row a tile can have.
+using RsPix = PixTile<2 * kTile, kTile * 128>;
 constexpr int kRsPix = kRsSum + 2 * 4 * kPartialWords;
-static_assert((kRsPix * 4) % 16 == 0 && (kPixAcc * 4) % 16 == 0 && (kPixTileFloats * 4) % 16 == 0, "16-byte areas must be 16-byte aligned");
-static_assert(kRsPix + 4 * kPixTileFloats <= 2 * kNetFloats, "the pixel detector's exchange must fit in the weight image's space");
+static_assert((kRsPix * 4) % 16 == 0, "16-byte areas must be 16-byte aligned");
+static_assert(kRsPix + 4 * RsPix::kFloats <= 2 * kNetFloats, "the pixel detector's exchange must fit in the weight image's space");
 
 // Workgroup barrier that publishes LDS only: waits for this wave's LDS operations, not for its global stores.  __syncthreads()
 // drains vmcnt too, and in these kernels every barrier would then wait out the ~1-2 us of the rollout-buffer / ledger / flag
@@ -273,71 +266,6 @@ struct TileRegs {
     float tmpl_lane;
 };
 
-// Inclusive sum over the 64 lanes on the VALU (DPP row shifts, then the row broadcasts gfx9 keeps): lane 63 holds the total.
-__device__ __forceinline__ int wave_scan_inclusive(int x) {
-    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);    // row_shr:1
-    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);    // row_shr:2
-    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);    // row_shr:4
-    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);    // row_shr:8
-    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);    // row_bcast:15 -> rows 1, 3
-    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2, 3
-    return x;
-}
-
-// Physics wave, one lane per drone: cut the drone's rows [jlo, jhi] into chunks of ch rows and append the items
-// (drone | chunk << 8) at this lane's place in the list.  Leaves {first entry of the drone in the span table, jlo, jhi, ch} in the
-// corner block.  A lane without rows (jlo > jhi) appends nothing.
-__device__ __forceinline__ void pixel_post_items(float* pix, int lane, int ilo, int ihi) {
-    const int rows = max(ihi - ilo + 1, 0);
-    const int rows_incl = wave_scan_inclusive(rows);
-    const int tile_rows = __builtin_amdgcn_readlane(rows_incl, 63);
-    // rows per item: the fewest that let the 128 lanes take all items in one round (items <= rows / ch + one per drone with rows)
-    const int with_rows = __popcll(__ballot(rows > 0));
-    const int ch = max(kPixMinChunk, (tile_rows + 2 * kTile - with_rows - 1) / (2 * kTile - with_rows));      // uniform
-    // ceil(rows / ch) for 0 <= rows <= 128 without an integer division: floor((rows + ch - 1/2) / ch), the half keeps the
-    // quotient away from the integers by 1 / (2 ch), far more than the rounding of the reciprocal
-    const int items = (int)(((float)(rows + ch) - 0.5f) * (1.0f / (float)ch));
-    const int incl = wave_scan_inclusive(items);
-    uint32_t* slots = reinterpret_cast<uint32_t*>(pix + kPixSlots);
-    for (int k = 0, pos = incl - items; k < items; ++k, ++pos) slots[pos] = (uint32_t)lane | (uint32_t)k << 8;
-    if (lane == kTile - 1) slots[kPixItems] = (uint32_t)incl;
-    reinterpret_cast<f32x4*>(pix)[3 * kTile + lane] = f32x4{(float)(rows_incl - rows), (float)ilo, (float)ihi, (float)ch};
-}
-
-// Both waves of the tile (worker 0 .. 127): walk the rows of items worker, worker + 128, ... and add each item's run to its
-// drone's accumulators.  An item that is not its drone's first also evaluates the row above it and counts the pair of the two
-// rows (pixel_walk's `linked`), so every pair of consecutive rows is counted by exactly one item and the accumulators need
-// sums, minima and maxima only — integer LDS atomics on exact integers: the order does not matter.
-// (Measured and not kept: items cut at the rows where a vertex passes, each walked with the two edges that cross it —
-// 12 instead of 28 instructions per row for the span, but three or more items per drone, vertex rows to sort and three
-// scatter loops on the posting wave, which is the serial part: 68.2 us per step against the plain chunks' figure in DESIGN §4.)
-__device__ __forceinline__ void pixel_work_items(float* pix, int worker) {
-    const uint32_t* slots = reinterpret_cast<const uint32_t*>(pix + kPixSlots);
-    const f32x4* cb = reinterpret_cast<const f32x4*>(pix);
-    int* acc = reinterpret_cast<int*>(pix + kPixAcc);
-    uint16_t* tab = reinterpret_cast<uint16_t*>(pix + kPixTab);
-    const int total = (int)slots[kPixItems];
-    for (int item = worker; item < total; item += 2 * kTile) {
-        const uint32_t rec = slots[item];
-        const int d = (int)(rec & 63u), k = (int)(rec >> 8);
-        const f32x4 qu = cb[d], qv = cb[kTile + d], qs = cb[2 * kTile + d], qr = cb[3 * kTile + d];
-        const float u[4] = {qu.x, qu.y, qu.z, qu.w}, v[4] = {qv.x, qv.y, qv.z, qv.w}, sl[4] = {qs.x, qs.y, qs.z, qs.w};
-        const float jf = qr.y + (float)k * qr.w, jl = fminf(jf + qr.w - 1.0f, qr.z);
-        const int idx = (int)qr.x + (int)(jf - qr.y);            // this item's first entry in the span table
-        float pa = 0.f, pb = 0.f;
-        const bool linked = k > 0 && row_span(u, v, sl, jf - 0.5f, pa, pb);        // the row above, if the blob has it
-        PixelRun<float> r;
-        pixel_walk(u, v, sl, jf, jl, r, tab, idx, kPixSpanCap, linked, pa, pb);
-        if (r.n > 0.f) {
-            int* a = acc + 4 * d;
-            atomicAdd(a, (int)r.n); atomicAdd(a + 1, (int)r.W); atomicAdd(a + 2, (int)r.S); atomicAdd(a + 3, (int)r.H);
-            a += 4 * kTile;
-            atomicMax(a, (int)r.viol); atomicMin(a + 1, (int)r.amin); atomicMax(a + 2, (int)r.bmax); atomicMin(a + 3, (int)r.j0);
-            atomicMax(a + 4 * kTile, (int)r.jn);
-        }
-    }
-}
-
 // Called by all 512 threads after the clipped actions are in LDS (kRsAct) and a workgroup barrier.  Contains eight (eleven with the
 // pixel detector) workgroup barriers on every path.  On return the four observation tiles (+ returns) are still in LDS (kRsTile).
 // (Measured and not kept: a two-party LDS arrival counter per tile in place of the workgroup barriers between a tile's two waves —
@@ -355,7 +283,7 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
     T(*nz)[8][kTile] = reinterpret_cast<T(*)[8][kTile]>(lds + kRsNoise + tl * (2 * 8 * kTile));
     Vec4<T>* tl_lds = reinterpret_cast<Vec4<T>*>(lds + kRsTile + tl * kRsTileFloats);
     double* bsum = reinterpret_cast<double*>(lds + kRsSum);
-    float* pix = lds + kRsPix + tl * kPixTileFloats;   // pixel detector: this tile's corner block, item list and runs
+    float* pix = lds + kRsPix + tl * RsPix::kFloats;   // pixel detector: this tile's corner block, accumulators, item list, span table
 
     if (helper) {
         // ---- noise producer: pair k is published before barrier k (fpv_step.hip, step_kernel_pair)
@@ -382,7 +310,7 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
             }
             if (o_.stamps && threadIdx.x == 256) o_.stamps[10] = __builtin_amdgcn_s_memrealtime();
             lds_barrier();                                 // barrier P: corner block and item list of this tile are in LDS
-            pixel_work_items(pix, kTile + lane);
+            pixel_work_items<2 * kTile, kTile * 128>(pix, kTile + lane);
             if (o_.stamps && threadIdx.x == 256) o_.stamps[11] = __builtin_amdgcn_s_memrealtime();
             lds_barrier();                                 // barrier Q: every item's run is in LDS
         }
@@ -453,23 +381,13 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
         att[kTile + lane] = f32x4{d.er, d.ep, d.eyaw, 0.f};
         lds_barrier();                                     // barrier P0: the helper converts the attitude from here on
         T u[4], v[4], sl[4], jlo, jhi;
-        bool ok = pixel_setup(d, u, v, sl, jlo, jhi);
-        if (pixel_touches_border(u, v, sl, jlo, jhi)) { ok = false; jlo = T(1); jhi = T(0); }     // invisible: no rows to walk
-        f32x4* cb = reinterpret_cast<f32x4*>(pix);
-        cb[lane] = f32x4{u[0], u[1], u[2], u[3]};
-        cb[kTile + lane] = f32x4{v[0], v[1], v[2], v[3]};
-        cb[2 * kTile + lane] = f32x4{sl[0], sl[1], sl[2], sl[3]};
-        typedef int i32x4 __attribute__((ext_vector_type(4)));
-        i32x4* acc = reinterpret_cast<i32x4*>(pix + kPixAcc);
-        acc[lane] = i32x4{0, 0, 0, 0};                     // n, W, S, H
-        acc[kTile + lane] = i32x4{-1000, 128, -1, 128};    // viol, amin, bmax, j0
-        acc[2 * kTile + lane] = i32x4{-1, 0, 0, 0};        // jn
+        const bool ok = pixel_tile_setup<2 * kTile, kTile * 128>(d, pix, lane, u, v, sl, jlo, jhi);
         if (o_.stamps && threadIdx.x == 0) o_.stamps[4] = __builtin_amdgcn_s_memrealtime();
-        pixel_post_items(pix, lane, (int)jlo, (int)jhi);
+        pixel_post_items<2 * kTile, kTile * 128>(pix, lane, (int)jlo, (int)jhi);
         if (o_.stamps && threadIdx.x == 0) o_.stamps[5] = __builtin_amdgcn_s_memrealtime();
         lds_barrier();                                     // barrier P
         if (o_.stamps && threadIdx.x == 0) o_.stamps[6] = __builtin_amdgcn_s_memrealtime();
-        pixel_work_items(pix, lane);
+        pixel_work_items<2 * kTile, kTile * 128>(pix, lane);
         if (o_.stamps && threadIdx.x == 0) o_.stamps[7] = __builtin_amdgcn_s_memrealtime();
         lds_barrier();                                     // barrier Q
         if (o_.stamps && threadIdx.x == 0) o_.stamps[8] = __builtin_amdgcn_s_memrealtime();
@@ -478,24 +396,8 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
             roll = t0.x; pitch = t0.y; yaw = t0.z;
             o[0] = t0.w; o[1] = t1.x; o[2] = t1.y; o[3] = t1.z; o[4] = t1.w; o[5] = t2.x; o[6] = t2.y;
         }
-        const i32x4 a0 = acc[lane], a1 = acc[kTile + lane], a2 = acc[2 * kTile + lane];
-        const int rowbase = (int)cb[3 * kTile + lane].x, ilo = (int)jlo;
-        const uint16_t* tab = reinterpret_cast<const uint16_t*>(pix + kPixTab);
-        auto entry = [&](int idx, T& a, T& b) {             // (rows outside the blob may be asked for — result unused —: kept inside the table)
-            const uint32_t ab = tab[min(max(idx, 0), kPixSpanCap - 1)];
-            a = (T)(ab & 255u); b = (T)(ab >> 8);
-        };
-        PixelRun<T> r;
-        r.n = (T)a0.x; r.W = (T)a0.y; r.S = (T)a0.z; r.H = (T)a0.w;
-        r.viol = (T)a1.x; r.amin = (T)a1.y; r.bmax = (T)a1.z; r.j0 = (T)a1.w; r.jn = (T)a2.x;
-        entry(rowbase + a1.w - ilo, r.a0, r.b0);           // first and last row of the blob (unused when the blob is empty)
-        entry(rowbase + a2.x - ilo, r.pa, r.pb);
-        auto span3 = [&](T jc, T (&a)[3], T (&b)[3]) {
-            const int idx = rowbase + (int)jc - ilo;
-            entry(idx - 1, a[0], b[0]); entry(idx, a[1], b[1]); entry(idx + 1, a[2], b[2]);
-        };
-        const bool seen = pixel_finish(r, u, v, span3, cam_x, cam_y, cam_area, cam_ratio);
-        vis = ok && seen;
+        vis = pixel_tile_features<2 * kTile, kTile * 128>(pix, lane, u, v, sl, jlo, ok, cam_x, cam_y, cam_area, cam_ratio);
+
         if (o_.stamps && threadIdx.x == 0) o_.stamps[9] = __builtin_amdgcn_s_memrealtime();
     } else {
         euler_from_quat(d.qx, d.qy, d.qz, d.qw, roll, pitch, yaw);

@@ -13,9 +13,27 @@
 // under the SB3 VecEnv auto-reset protocol (simulation/train_hover.py:42).
 #include "fpv_dynamics.h"
 #include "fpv_internal.h"
+#include "fpv_pixel_tile.h"
 #include "fpv_step_parts.h"
 
 namespace fpv {
+
+// Observation of hover.py:237-272 with the handle's detector.  fp32 handles walk the pixel detector's rows as work items of the
+// tile's wave (fpv_pixel_tile.h: `pix`, LDS of this wave); fp64 handles, which exist for trajectory-level parity runs, keep
+// the plain walk of one lane per drone.  The same features either way.
+using OneWavePix = PixTile<kTile, kPixCapOneWave>;
+template <typename T>
+__device__ __forceinline__ bool observe_tile(Drone<T>& d, T roll, T pitch, T yaw, T a0, T a1, T a2, T a3, T (&o)[kObsWords], int detector,
+                                             float* pix, int lane) {
+    if constexpr (sizeof(T) == 4) {
+        T cx, cy, area, ratio;
+        const bool vis = detector ? camera_features_pixel_tile(d, pix, lane, cx, cy, area, ratio) : camera_features(d, cx, cy, area, ratio);
+        observe_with(d, roll, pitch, yaw, a0, a1, a2, a3, o, vis, cx, cy, area, ratio);
+        return vis;
+    } else {
+        return observe(d, roll, pitch, yaw, a0, a1, a2, a3, o, detector);
+    }
+}
 
 // ---------------------------------------------------------------- K1
 // TPB tiles (waves) per workgroup.  The waves are independent except at the very end of the fused variant, where a
@@ -23,12 +41,16 @@ namespace fpv {
 // (fpv_moments_merge, or the policy kernel's prologue) has to read shrinks fourfold.
 template <typename T, bool NOISE, bool FUSED, int TPB = 1>
 __global__ __launch_bounds__(kTile * TPB) void step_kernel(StepArgs<T> p) {
-    // per wave: observation tile; fused variant: + 64 returns + a 64 x 2 fp64 exchange area (fp32 handles only)
+    // per wave: observation tile; fused variant: + 64 returns + a 64 x 2 fp64 exchange area (fp32 handles only).  The pixel
+    // detector's tile area (fp32 handles) is used before the observation exists: the two share the wave's LDS.
     constexpr int kLdsPerTile = kTile * kObsWords / 4 + (FUSED ? kTile / 4 + kTile : 0);
-    __shared__ Vec4<T> lds_all[TPB * kLdsPerTile];
+    constexpr int kObsBytes = kLdsPerTile * (int)sizeof(Vec4<T>), kPixBytes = sizeof(T) == 4 ? OneWavePix::kFloats * 4 : 0;
+    constexpr int kWaveBytes = kObsBytes > kPixBytes ? kObsBytes : kPixBytes;
+    __shared__ __attribute__((aligned(32))) unsigned char lds_raw[TPB * kWaveBytes];
     __shared__ double bsum[TPB > 1 ? TPB * kPartialWords : 1];
     const int lane = threadIdx.x & (kTile - 1), wv = threadIdx.x / kTile;
-    Vec4<T>* lds = lds_all + wv * kLdsPerTile;
+    Vec4<T>* lds = reinterpret_cast<Vec4<T>*>(lds_raw + wv * kWaveBytes);
+    float* pix = reinterpret_cast<float*>(lds_raw + wv * kWaveBytes);
     const int64_t tile = (int64_t)blockIdx.x * TPB + wv;
     const int64_t i = tile * kTile + lane;
     const bool live = i < p.n;
@@ -66,7 +88,7 @@ __global__ __launch_bounds__(kTile * TPB) void step_kernel(StepArgs<T> p) {
     T roll, pitch, yaw;
     euler_from_quat(d.qx, d.qy, d.qz, d.qw, roll, pitch, yaw);
     T o[kObsWords];
-    const bool vis = observe(d, roll, pitch, yaw, act.x, act.y, act.z, act.w, o, p.detector);
+    const bool vis = observe_tile(d, roll, pitch, yaw, act.x, act.y, act.z, act.w, o, p.detector, pix, lane);
     uint32_t bits;
     const T reward = reward_and_flags(d, roll, pitch, vis, o, act.x, act.y, act.z, act.w, p.floor_check != 0, bits);
     d.er = roll; d.ep = pitch; d.eyaw = yaw;
@@ -164,6 +186,7 @@ __global__ __launch_bounds__(2 * kTile) void step_kernel_pair(StepArgs<float> p)
     using T = float;
     __shared__ T nz[2][8][kTile];
     __shared__ Vec4<T> lds[kTile * kObsWords / 4 + (FUSED ? kTile / 4 : 0)];
+    __shared__ __attribute__((aligned(16))) float pix[OneWavePix::kFloats];     // pixel detector: the physics wave's tile area
     const int lane = threadIdx.x & (kTile - 1);
     const bool helper = threadIdx.x >= kTile;
     const int64_t tile = blockIdx.x;
@@ -228,7 +251,7 @@ __global__ __launch_bounds__(2 * kTile) void step_kernel_pair(StepArgs<float> p)
     T roll, pitch, yaw;
     euler_from_quat(d.qx, d.qy, d.qz, d.qw, roll, pitch, yaw);
     T o[kObsWords];
-    const bool vis = observe(d, roll, pitch, yaw, act.x, act.y, act.z, act.w, o, p.detector);
+    const bool vis = observe_tile(d, roll, pitch, yaw, act.x, act.y, act.z, act.w, o, p.detector, pix, lane);
     uint32_t bits;
     const T reward = reward_and_flags(d, roll, pitch, vis, o, act.x, act.y, act.z, act.w, p.floor_check != 0, bits);
     d.er = roll; d.ep = pitch; d.eyaw = yaw;
