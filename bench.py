@@ -279,16 +279,25 @@ def main() -> None:
     elapsed = repeats[len(repeats) // 2] if len(repeats) % 2 else 0.5 * (repeats[len(repeats) // 2 - 1] + repeats[len(repeats) // 2])
     episodes = int(col.episodes["count"])
 
-    # ---- extra (not the headline): the same K steps with the policy GEMMs on the 6-term bf16 split ----
-    split_value = None
+    # ---- extra (not the headline): the same K steps with the policy GEMMs on the 6-term bf16 split — as ONE kernel per step
+    # (rollout_step_split_kernel) where the one-kernel step is served, and as two kernels per step ----
+    split_value = split_value_two = None
     if not yaw and not args.no_split_extra:
+        def split_rate():
+            for _ in range(2):
+                col.collect()
+            r2 = sorted(timed_region() for _ in range(max(1, min(3, n_rep))))
+            return n * world * K / r2[len(r2) // 2]
+        was_one = col._one_launch
         col.set_policy_gemm("bf16x6")
-        for _ in range(2):
-            col.collect()
-        r2 = sorted(timed_region() for _ in range(max(1, min(3, n_rep))))
-        el2 = r2[len(r2) // 2]
-        split_value = n * world * K / el2
+        if col._one_launch:
+            split_value = split_rate()
+            col._one_launch = False
+            col._graph = None
+        split_value_two = split_rate()
         col.set_policy_gemm("f32")
+        col._one_launch = was_one
+        col._graph = None
 
     # ---- rooflines: kernel-only passes in this process, HIP events on the launch stream (events cannot bracket a
     # node inside the replayed graph).  `roofline` is the kernel that dominates the timed region by time (the fused
@@ -551,10 +560,11 @@ def main() -> None:
             out["roofline_hbm_whole_kernel"] = out_hbm_whole
         if roofline_env_fused is not None:
             out["roofline_env_step_standalone_fused"] = roofline_env_fused
-        if split_value is not None:
-            out["extra"] = {"value_with_policy_gemm_bf16x6": split_value,
+        if split_value is not None or split_value_two is not None:
+            out["extra"] = {"value_one_kernel_bf16x6": split_value, "value_with_policy_gemm_bf16x6": split_value_two,
                             "note": "same workload with the policy's hidden GEMMs on a 6-term bf16 split (fp32-level error, "
-                                    "tests/test_policy_gpu.py); the headline value uses exact-fp32 MFMA"}
+                                    "tests/test_policy_gpu.py): value_one_kernel_bf16x6 = one kernel per step (rollout_step_split_kernel), "
+                                    "value_with_policy_gemm_bf16x6 = two kernels per step; the headline value uses exact-fp32 MFMA"}
         if f64_value is not None:
             out.setdefault("extra", {})["value_f64_env"] = f64_value
             out["extra"]["value_f64_env_note"] = ("env-steps/s of fpv_step on an FPV_F64 handle (env step only, no policy, HIP events over "

@@ -627,8 +627,9 @@ int fpv_rollout_step(fpv_env* e, fpv_policy* p, const fpv_policy_io* io, float* 
     if (e->cfg.num_envs % 256 != 0) return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: num_envs must be a multiple of 256");
     if (io->n != e->cfg.num_envs) return fail(FPV_ERR_ARG, "fpv_rollout_step: io->n must equal num_envs");
     const bool yaw = e->cfg.task == FPV_TASK_YAW;
-    if (p->in_dim != e->obs_words || p->act_dim != e->act_words || p->gemm != 0)
-        return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: policy widths must be the task's (%d / %d), gemm mode 0", e->obs_words, e->act_words);
+    if (p->in_dim != e->obs_words || p->act_dim != e->act_words || (p->gemm != 0 && !(p->gemm == 1 && !yaw)))
+        return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: policy widths must be the task's (%d / %d), gemm mode 0 (or 1, the bf16 split, for the hover task)",
+                    e->obs_words, e->act_words);
     if (io->eps_in || io->eps_out || io->deterministic || io->narrow || io->n_dev || (io->nets != 0 && io->nets != 3))
         return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: eps_in / eps_out / deterministic / narrow / n_dev / single nets are not served");
     if (ex && (ex->obs_rms || ex->ret_rms || ex->snapshot))
@@ -666,8 +667,12 @@ int fpv_rollout_step(fpv_env* e, fpv_policy* p, const fpv_policy_io* io, float* 
     a.partials = ex ? ex->partials : nullptr;
     a.gamma = ex ? ex->gamma : 0.0f;
     a.mg_count = (double)e->cfg.num_envs;
-    FPV_HIP(launch_rollout_step(p->image, io->rms, io->obs_n, io->action, io->clipped, io->value, io->logp, io->seed, io->id_offset,
-                                io->clip_obs, io->eps_norm, mg, a, yaw ? 1 : 0, e->stamps, (hipStream_t)stream));
+    if (p->gemm == 1)
+        FPV_HIP(launch_rollout_step_split(p->split_image, io->rms, io->obs_n, io->action, io->clipped, io->value, io->logp, io->seed,
+                                          io->id_offset, io->clip_obs, io->eps_norm, mg, a, e->stamps, (hipStream_t)stream));
+    else
+        FPV_HIP(launch_rollout_step(p->image, io->rms, io->obs_n, io->action, io->clipped, io->value, io->logp, io->seed, io->id_offset,
+                                    io->clip_obs, io->eps_norm, mg, a, yaw ? 1 : 0, e->stamps, (hipStream_t)stream));
     return FPV_OK;
 }
 

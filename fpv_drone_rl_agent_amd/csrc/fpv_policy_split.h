@@ -1,0 +1,228 @@
+// fpv_policy_split.h — the 6-term bf16 split of the actor-critic forward (fpv_policy_split.hip) as device code shared by the
+// stand-alone policy kernel and the one-kernel rollout step (fpv_rollstep.hip: rollout_step_split_kernel), so that both run the
+// same instructions on a row.  See fpv_policy_split.hip for the arithmetic and the image layout.
+#pragma once
+#include "fpv_mlp.h"
+#include "fpv_policy_image.h"   // kIn
+
+namespace fpv {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+
+constexpr int kSplitThreads = 512;
+constexpr int kSplitDrones = kSplitThreads / 2;   // 32 drones per wave
+// per-net image, byte offsets
+constexpr int kW2Bytes = 4 * 4 * 2 * 3 * 64 * 16;   // [m][kt][s][part][lane][8 bf16] = 98 304
+constexpr int kW1Bytes = 4 * 2 * 3 * 64 * 16;       // [m][s][part][lane][8 bf16]     = 24 576
+constexpr int kBiasBytes = 2 * 128 * 4;             // b1p, b2p (fp32, accumulator order)
+constexpr int kNetBytes = kW2Bytes + kW1Bytes + kBiasBytes;   // 123 904
+constexpr int kHeadFloats = 660;                    // Wa[512] Wv[128] ba[4] bv[1] pad log_std[4] std[4] logp_const
+constexpr int kSplitImageBytes = 2 * kNetBytes + kHeadFloats * 4;
+constexpr int kSplitLdsBytes = kNetBytes + kHeadFloats * 4 + 40 * 4 + kMergeLdsBytes;   // one net + heads + normaliser + merge exchange
+
+__host__ __device__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+// k index (inside a 32-row tile) of element j of lane half h at k-step s when an accumulator tile is the B operand
+__host__ __device__ constexpr int frag_row(int s, int j, int h) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
+
+__device__ __forceinline__ __bf16 piece(float v, int part) {
+    const __bf16 p1 = (__bf16)v;
+    if (part == 0) return p1;
+    const float r1 = v - (float)p1;
+    const __bf16 p2 = (__bf16)r1;
+    if (part == 1) return p2;
+    return (__bf16)(r1 - (float)p2);
+}
+
+// three bf16 fragments of eight fp32 values
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& p1, bf16x8& p2, bf16x8& p3) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 a = (__bf16)v[j];
+        const float r1 = v[j] - (float)a;
+        const __bf16 b = (__bf16)r1;
+        const __bf16 c = (__bf16)(r1 - (float)b);
+        p1[j] = a; p2[j] = b; p3[j] = c;
+    }
+}
+
+// acc += W . X for one k-step of 16 with the six retained piece products, small terms first
+__device__ __forceinline__ f32x16 mfma6(const bf16x8* __restrict__ wfrag /* 3 parts, stride 64 fragments */, int lane,
+                                        const bf16x8& x1, const bf16x8& x2, const bf16x8& x3, f32x16 acc) {
+    const bf16x8 w1 = wfrag[lane], w2 = wfrag[64 + lane], w3 = wfrag[128 + lane];
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, x1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x3, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x1, acc, 0, 0, 0);
+    return acc;
+}
+
+// Which outputs a pass over one net writes for its row (each pointer may be null)
+struct SplitOut {
+    float *obs_n, *action, *clipped, *value, *logp, *eps_out;
+};
+
+// One net (0: pi with the sampling epilogue, 1: V) for this lane's row d; the net's split image is in LDS at `img`, the head block
+// and the normaliser (mean[20], 1 / sigma[20]) at `head` / `nrm`.  Returns the clipped action (net 0; undefined for net 1).
+__device__ __forceinline__ f32x4 split_net_row(int net, const unsigned char* img, const float* head, const float* nrm, float clip,
+                                               const float* __restrict__ obs, int64_t d, bool live, int lane, const SplitOut& out,
+                                               const float* eps_in, uint64_t tick, bool deterministic, uint64_t seed, uint64_t id_offset) {
+    const int h = lane >> 5;
+    const bf16x8* w2img = reinterpret_cast<const bf16x8*>(img);
+    const bf16x8* w1img = reinterpret_cast<const bf16x8*>(img + kW2Bytes);
+    const float* bias = reinterpret_cast<const float*>(img + kW2Bytes + kW1Bytes);
+    f32x4 cl = f32x4{0.f, 0.f, 0.f, 0.f};
+    // observation slice of this lane half (k = 12 h .. 12 h + 11), normalised
+    float x[16];
+    {
+        const f32x4* row = reinterpret_cast<const f32x4*>(obs + (live ? d : 0) * kIn);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const bool have = live && (h == 0 || q < 2);
+            const f32x4 v = have ? row[3 * h + q] : f32x4{0.f, 0.f, 0.f, 0.f};
+            x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const int k = 12 * h + j;
+            if (k < kIn) x[j] = fminf(fmaxf((x[j] - nrm[k]) * nrm[20 + k], -clip), clip);
+        }
+        x[12] = x[13] = x[14] = x[15] = 0.0f;
+        if (net == 0 && out.obs_n && live) {
+            f32x4* o = reinterpret_cast<f32x4*>(out.obs_n + d * kIn);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                if (h == 0 || q < 2) o[3 * h + q] = f32x4{x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+        }
+    }
+    // ---- layer 1 (K = 20 padded to 32: two k-steps)
+    f32x16 a[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[m][r] = bias[(m * 2 + h) * 16 + r];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = x[8 * s + j];
+        bf16x8 x1, x2, x3;
+        split8(v, x1, x2, x3);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a[m] = mfma6(w1img + (m * 2 + s) * 3 * 64, lane, x1, x2, x3, a[m]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a[m][r] = fast_tanh(a[m][r]);
+    // ---- layer 2: accumulator tiles of layer 1 are the B operands (registers 8 s .. 8 s + 7 per k-step)
+    f32x16 c[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[m][r] = bias[128 + (m * 2 + h) * 16 + r];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = a[kt][8 * s + j];
+            bf16x8 x1, x2, x3;
+            split8(v, x1, x2, x3);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                c[m] = mfma6(w2img + ((m * 4 + kt) * 2 + s) * 3 * 64, lane, x1, x2, x3, c[m]);
+            __builtin_amdgcn_sched_barrier(0);   // keep the next k-step's 12 weight fragments from being hoisted here
+        }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[m][r] = fast_tanh(c[m][r]);
+
+    // The two lane halves are combined with half_sum() (v_permlane32_swap, VALU only).  The first version went
+    // through __shfl_xor -> ds_bpermute_b32 and about 1 row in 3 000 came out with a wrong FIRST head component
+    // (1 311 bad rows in 3.9 x 10^6 with -DFPV_HALFSUM_BPERMUTE, 0 in 2 x 10^7 with the VALU swap; tools/stress_policy.py;
+    // cause unproven).
+    if (net == 0) {
+        // ---- action head on the VALU, sampling epilogue
+        float mu[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(head + (((h * 4 + kt) * 16 + r) * 4));
+                const float v = c[kt][r];
+                mu[0] += w.x * v; mu[1] += w.y * v; mu[2] += w.z * v; mu[3] += w.w * v;
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mu[j] = half_sum(mu[j]) + head[640 + j];
+        float eps[4] = {0.f, 0.f, 0.f, 0.f};
+        if (!deterministic) {
+            if (eps_in) {
+                const f32x4 e = live ? reinterpret_cast<const f32x4*>(eps_in)[d] : f32x4{0.f, 0.f, 0.f, 0.f};
+                eps[0] = e.x; eps[1] = e.y; eps[2] = e.z; eps[3] = e.w;
+            } else {
+                uint32_t xr[4];
+                philox4x32_10((uint32_t)(id_offset + (uint64_t)d), (uint32_t)tick, (uint32_t)(tick >> 32), 0x504F4C31u,
+                             (uint32_t)seed, (uint32_t)(seed >> 32), xr);
+                constexpr float k24 = 5.9604644775390625e-8f, m2ln2 = -1.3862943611198906f;
+                const float u0 = ((float)(xr[0] >> 8) + 0.5f) * k24, u1 = ((float)(xr[1] >> 8) + 0.5f) * k24;
+                const float u2 = ((float)(xr[2] >> 8) + 0.5f) * k24, u3 = ((float)(xr[3] >> 8) + 0.5f) * k24;
+                const float ra = __builtin_amdgcn_sqrtf(m2ln2 * __log2f(u0)), rb = __builtin_amdgcn_sqrtf(m2ln2 * __log2f(u2));
+                eps[0] = ra * __builtin_amdgcn_cosf(u1); eps[1] = ra * __builtin_amdgcn_sinf(u1);
+                eps[2] = rb * __builtin_amdgcn_cosf(u3); eps[3] = rb * __builtin_amdgcn_sinf(u3);
+            }
+        }
+        float act[4], lp = head[656];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            act[j] = __builtin_fmaf(head[652 + j], eps[j], mu[j]);      // (explicit fmas: the same instructions in every kernel this
+            lp = __builtin_fmaf(-0.5f * eps[j], eps[j], lp);             // function is inlined into, whatever contraction would choose)
+        }
+        cl = f32x4{fminf(fmaxf(act[0], -1.f), 1.f), fminf(fmaxf(act[1], -1.f), 1.f), fminf(fmaxf(act[2], -1.f), 1.f),
+                   fminf(fmaxf(act[3], -1.f), 1.f)};
+        if (live) {
+            if (h == 0) {
+                if (out.action) reinterpret_cast<f32x4*>(out.action)[d] = f32x4{act[0], act[1], act[2], act[3]};
+                if (out.clipped) reinterpret_cast<f32x4*>(out.clipped)[d] = cl;
+            } else {
+                if (out.logp) out.logp[d] = lp;
+                if (out.eps_out) reinterpret_cast<f32x4*>(out.eps_out)[d] = f32x4{eps[0], eps[1], eps[2], eps[3]};
+            }
+        }
+    } else {
+        float v = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v += head[512 + (h * 4 + kt) * 16 + r] * c[kt][r];
+        v = half_sum(v);
+        if (live && h == 1) out.value[d] = v + head[644];
+    }
+    return cl;
+}
+
+// this net's split image -> LDS (all requests in flight before the first LDS write); THREADS = workgroup size
+template <int THREADS>
+__device__ __forceinline__ void split_stage_image(const unsigned char* __restrict__ image, int net, unsigned char* lds_raw) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(image + (size_t)net * kNetBytes);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds_raw);
+    constexpr int kGran = kNetBytes / 16, kPer = (kGran + THREADS - 1) / THREADS;
+    f32x4 stage[kPer];
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+        const int g = q * THREADS + threadIdx.x;
+        stage[q] = src[g < kGran ? g : 0];
+    }
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+        const int g = q * THREADS + threadIdx.x;
+        if (g < kGran) dst[g] = stage[q];
+    }
+}
+
+}  // namespace fpv

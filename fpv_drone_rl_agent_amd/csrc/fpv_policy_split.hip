@@ -10,41 +10,14 @@
 // kernel (accumulator tile -> next layer's B fragment; k order baked into the weight image).  The split weight
 // image of one net is 121 KB, so the workgroup makes two passes over its drones: pi (and the sampling epilogue)
 // with the pi image resident, then V with the V image.
-#include "fpv_mlp.h"
+#include "fpv_policy_split.h"
 
 namespace fpv {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int kIn = 20;
-constexpr int kSplitThreads = 512;
-constexpr int kSplitDrones = kSplitThreads / 2;   // 32 drones per wave
-// per-net image, byte offsets
-constexpr int kW2Bytes = 4 * 4 * 2 * 3 * 64 * 16;   // [m][kt][s][part][lane][8 bf16] = 98 304
-constexpr int kW1Bytes = 4 * 2 * 3 * 64 * 16;       // [m][s][part][lane][8 bf16]     = 24 576
-constexpr int kBiasBytes = 2 * 128 * 4;             // b1p, b2p (fp32, accumulator order)
-constexpr int kNetBytes = kW2Bytes + kW1Bytes + kBiasBytes;   // 123 904
-constexpr int kHeadFloats = 660;                    // Wa[512] Wv[128] ba[4] bv[1] pad log_std[4] std[4] logp_const
-constexpr int kSplitImageBytes = 2 * kNetBytes + kHeadFloats * 4;
-constexpr int kSplitLdsBytes = kNetBytes + kHeadFloats * 4 + 40 * 4 + kMergeLdsBytes;   // one net + heads + normaliser + merge exchange
-
-__host__ __device__ constexpr int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-// k index (inside a 32-row tile) of element j of lane half h at k-step s when an accumulator tile is the B operand
-__host__ __device__ constexpr int frag_row(int s, int j, int h) { return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3); }
 
 struct SplitParams {
     const float *pi_w1, *pi_b1, *pi_w2, *pi_b2, *wa, *ba, *log_std;
     const float *vf_w1, *vf_b1, *vf_w2, *vf_b2, *wv, *bv;
 };
-
-__device__ __forceinline__ __bf16 piece(float v, int part) {
-    const __bf16 p1 = (__bf16)v;
-    if (part == 0) return p1;
-    const float r1 = v - (float)p1;
-    const __bf16 p2 = (__bf16)r1;
-    if (part == 1) return p2;
-    return (__bf16)(r1 - (float)p2);
-}
 
 __global__ void policy_split_pack_kernel(SplitParams p, unsigned char* __restrict__ img) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;   // one bf16 / fp32 element per thread
@@ -90,31 +63,6 @@ __global__ void policy_split_pack_kernel(SplitParams p, unsigned char* __restric
 }
 
 
-// three bf16 fragments of eight fp32 values
-__device__ __forceinline__ void split8(const float (&v)[8], bf16x8& p1, bf16x8& p2, bf16x8& p3) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const __bf16 a = (__bf16)v[j];
-        const float r1 = v[j] - (float)a;
-        const __bf16 b = (__bf16)r1;
-        const __bf16 c = (__bf16)(r1 - (float)b);
-        p1[j] = a; p2[j] = b; p3[j] = c;
-    }
-}
-
-// acc += W . X for one k-step of 16 with the six retained piece products, small terms first
-__device__ __forceinline__ f32x16 mfma6(const bf16x8* __restrict__ wfrag /* 3 parts, stride 64 fragments */, int lane,
-                                        const bf16x8& x1, const bf16x8& x2, const bf16x8& x3, f32x16 acc) {
-    const bf16x8 w1 = wfrag[lane], w2 = wfrag[64 + lane], w3 = wfrag[128 + lane];
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, x1, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x3, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x2, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x1, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x2, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x1, acc, 0, 0, 0);
-    return acc;
-}
-
 struct SplitArgs {
     const unsigned char* image;
     const float* obs;
@@ -151,163 +99,13 @@ __global__ __launch_bounds__(kSplitThreads) void policy_split_forward_kernel(Spl
 #pragma unroll 1
     for (int net = 0; net < 2; ++net) {
         __syncthreads();   // everyone is done with the previous image
-        {                  // stage this net's image: all requests in flight before the first LDS write
-            const f32x4* src = reinterpret_cast<const f32x4*>(p.image + (size_t)net * kNetBytes);
-            f32x4* dst = reinterpret_cast<f32x4*>(lds_raw);
-            constexpr int kGran = kNetBytes / 16, kPer = (kGran + kSplitThreads - 1) / kSplitThreads;
-            f32x4 stage[kPer];
-#pragma unroll
-            for (int q = 0; q < kPer; ++q) {
-                const int g = q * kSplitThreads + threadIdx.x;
-                stage[q] = src[g < kGran ? g : 0];
-            }
-#pragma unroll
-            for (int q = 0; q < kPer; ++q) {
-                const int g = q * kSplitThreads + threadIdx.x;
-                if (g < kGran) dst[g] = stage[q];
-            }
-        }
+        split_stage_image<kSplitThreads>(p.image, net, lds_raw);
         __syncthreads();
-        const bf16x8* w2img = reinterpret_cast<const bf16x8*>(lds_raw);
-        const bf16x8* w1img = reinterpret_cast<const bf16x8*>(lds_raw + kW2Bytes);
-        const float* bias = reinterpret_cast<const float*>(lds_raw + kW2Bytes + kW1Bytes);
-
+        const SplitOut out{p.obs_n, p.action, p.clipped, p.value, p.logp, p.eps_out};
+        const uint64_t tick = p.tick ? p.tick[0] : 0ull;
         for (int64_t base = (int64_t)blockIdx.x * kSplitDrones; base < p.n; base += (int64_t)gridDim.x * kSplitDrones) {
             const int64_t d = base + wave * 32 + col;
-            const bool live = d < p.n;
-            // observation slice of this lane half (k = 12 h .. 12 h + 11), normalised
-            float x[16];
-            {
-                const f32x4* row = reinterpret_cast<const f32x4*>(p.obs + (live ? d : 0) * kIn);
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const bool have = live && (h == 0 || q < 2);
-                    const f32x4 v = have ? row[3 * h + q] : f32x4{0.f, 0.f, 0.f, 0.f};
-                    x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
-                }
-#pragma unroll
-                for (int j = 0; j < 12; ++j) {
-                    const int k = 12 * h + j;
-                    if (k < kIn) x[j] = fminf(fmaxf((x[j] - nrm[k]) * nrm[20 + k], -clip), clip);
-                }
-                x[12] = x[13] = x[14] = x[15] = 0.0f;
-                if (net == 0 && p.obs_n && live) {
-                    f32x4* out = reinterpret_cast<f32x4*>(p.obs_n + d * kIn);
-#pragma unroll
-                    for (int q = 0; q < 3; ++q)
-                        if (h == 0 || q < 2) out[3 * h + q] = f32x4{x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
-                }
-            }
-            // ---- layer 1 (K = 20 padded to 32: two k-steps)
-            f32x16 a[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a[m][r] = bias[(m * 2 + h) * 16 + r];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = x[8 * s + j];
-                bf16x8 x1, x2, x3;
-                split8(v, x1, x2, x3);
-#pragma unroll
-                for (int m = 0; m < 4; ++m) a[m] = mfma6(w1img + (m * 2 + s) * 3 * 64, lane, x1, x2, x3, a[m]);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) a[m][r] = fast_tanh(a[m][r]);
-            // ---- layer 2: accumulator tiles of layer 1 are the B operands (registers 8 s .. 8 s + 7 per k-step)
-            f32x16 c[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) c[m][r] = bias[128 + (m * 2 + h) * 16 + r];
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    float v[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = a[kt][8 * s + j];
-                    bf16x8 x1, x2, x3;
-                    split8(v, x1, x2, x3);
-#pragma unroll
-                    for (int m = 0; m < 4; ++m)
-                        c[m] = mfma6(w2img + ((m * 4 + kt) * 2 + s) * 3 * 64, lane, x1, x2, x3, c[m]);
-                    __builtin_amdgcn_sched_barrier(0);   // keep the next k-step's 12 weight fragments from being hoisted here
-                }
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) c[m][r] = fast_tanh(c[m][r]);
-
-            // The two lane halves are combined with half_sum() (v_permlane32_swap, VALU only).  The first version went
-            // through __shfl_xor -> ds_bpermute_b32 and about 1 row in 3 000 came out with a wrong FIRST head component:
-            // the ds_bpermute that read mu[0] issued two instructions after the v_pk_fma_f32 that wrote it and, while
-            // the SIMD's partner wave was streaming bf16 MFMAs, picked up the stale register (1 311 bad rows in 3.9 x 10^6
-            // with -DFPV_HALFSUM_BPERMUTE, 0 in 2 x 10^7 with the VALU swap; tools/stress_policy.py).  A workgroup
-            // barrier here used to hide it by keeping MFMA loops and epilogues apart; it is no longer needed.
-            if (net == 0) {
-                // ---- action head on the VALU, sampling epilogue
-                float mu[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const f32x4 w = *reinterpret_cast<const f32x4*>(head + (((h * 4 + kt) * 16 + r) * 4));
-                        const float v = c[kt][r];
-                        mu[0] += w.x * v; mu[1] += w.y * v; mu[2] += w.z * v; mu[3] += w.w * v;
-                    }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) mu[j] = half_sum(mu[j]) + head[640 + j];
-                float eps[4] = {0.f, 0.f, 0.f, 0.f};
-                if (!p.deterministic) {
-                    if (p.eps_in) {
-                        const f32x4 e = live ? reinterpret_cast<const f32x4*>(p.eps_in)[d] : f32x4{0.f, 0.f, 0.f, 0.f};
-                        eps[0] = e.x; eps[1] = e.y; eps[2] = e.z; eps[3] = e.w;
-                    } else {
-                        const uint64_t t = p.tick ? p.tick[0] : 0ull;
-                        uint32_t xr[4];
-                        philox4x32_10((uint32_t)(p.id_offset + (uint64_t)d), (uint32_t)t, (uint32_t)(t >> 32), 0x504F4C31u,
-                                     (uint32_t)p.seed, (uint32_t)(p.seed >> 32), xr);
-                        constexpr float k24 = 5.9604644775390625e-8f, m2ln2 = -1.3862943611198906f;
-                        const float u0 = ((float)(xr[0] >> 8) + 0.5f) * k24, u1 = ((float)(xr[1] >> 8) + 0.5f) * k24;
-                        const float u2 = ((float)(xr[2] >> 8) + 0.5f) * k24, u3 = ((float)(xr[3] >> 8) + 0.5f) * k24;
-                        const float ra = __builtin_amdgcn_sqrtf(m2ln2 * __log2f(u0)), rb = __builtin_amdgcn_sqrtf(m2ln2 * __log2f(u2));
-                        eps[0] = ra * __builtin_amdgcn_cosf(u1); eps[1] = ra * __builtin_amdgcn_sinf(u1);
-                        eps[2] = rb * __builtin_amdgcn_cosf(u3); eps[3] = rb * __builtin_amdgcn_sinf(u3);
-                    }
-                }
-                float act[4], lp = head[656];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    act[j] = mu[j] + head[652 + j] * eps[j];
-                    lp -= 0.5f * eps[j] * eps[j];
-                }
-                if (live) {
-                    if (h == 0) {
-                        if (p.action) reinterpret_cast<f32x4*>(p.action)[d] = f32x4{act[0], act[1], act[2], act[3]};
-                        if (p.clipped)
-                            reinterpret_cast<f32x4*>(p.clipped)[d] =
-                                f32x4{fminf(fmaxf(act[0], -1.f), 1.f), fminf(fmaxf(act[1], -1.f), 1.f),
-                                      fminf(fmaxf(act[2], -1.f), 1.f), fminf(fmaxf(act[3], -1.f), 1.f)};
-                    } else {
-                        if (p.logp) p.logp[d] = lp;
-                        if (p.eps_out) reinterpret_cast<f32x4*>(p.eps_out)[d] = f32x4{eps[0], eps[1], eps[2], eps[3]};
-                    }
-                }
-            } else {
-                float v = 0.f;
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v += head[512 + (h * 4 + kt) * 16 + r] * c[kt][r];
-                v = half_sum(v);
-                if (live && h == 1) p.value[d] = v + head[644];
-            }
+            split_net_row(net, lds_raw, head, nrm, clip, p.obs, d, d < p.n, lane, out, p.eps_in, tick, p.deterministic != 0, p.seed, p.id_offset);
         }
     }
 }

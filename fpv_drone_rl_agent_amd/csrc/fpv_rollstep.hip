@@ -22,6 +22,9 @@
 // VecNormalize of simulation/train_hover.py:43-58.
 #include "fpv_mlp.h"
 #include "fpv_policy_image.h"
+#pragma clang fp contract(fast)
+#include "fpv_policy_split.h"   // (the split policy arithmetic is compiled as in fpv_policy_split.hip: contract fast)
+#pragma clang fp contract(on)
 #include "fpv_pixel_tile.h"
 #include "fpv_step_parts.h"
 #include "fpv_yaw_parts.h"
@@ -672,6 +675,72 @@ __global__ __launch_bounds__(512) void rollout_step_kernel(RollStepArgs p) {
 #undef RS1_STAMP
 }
 
+// ---------------------------------------------------------------- the one-step kernel with the policy on the 6-term bf16 split
+// rollout_step_kernel<0> with fpv_policy_split.hip's arithmetic in phase 1 (hover task): the split image of one net is 121 KB, so
+// the workgroup stages pi, evaluates pi and samples for its 256 drones, stages V over it, evaluates V, and then steps the same
+// drones exactly as above (rs_tail).  The policy pass already holds 238 registers, so the drone state is requested after it —
+// the previous launch's stores left it in L2 / MALL — not under the matrix work.  Bit-identical to fpv_policy_forward in gemm
+// mode 1 followed by fpv_step_fused (tests/test_rollstep_gpu.py).  Not the headline: the exact-fp32 policy is.
+struct RollStepSplitArgs {
+    const unsigned char* image;   // split image: two nets + heads (kSplitImageBytes)
+    const double* rms;
+    float *obs_n, *action, *clipped, *value, *logp;
+    uint64_t pol_seed, pol_id_offset;
+    float clip_obs, eps_norm;
+    MergeArgs mg;
+    StepArgs<float> st;
+    uint64_t* stamps;
+};
+constexpr int kRsSplitLdsBytes = (kRsPix + 4 * RsPix::kFloats) * 4 > kSplitLdsBytes ? (kRsPix + 4 * RsPix::kFloats) * 4 : kSplitLdsBytes;
+
+#pragma clang fp contract(fast)
+__global__ __launch_bounds__(512) void rollout_step_split_kernel(RollStepSplitArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    unsigned char* lds_raw = reinterpret_cast<unsigned char*>(lds);
+    float* head = reinterpret_cast<float*>(lds_raw + kNetBytes);            // kHeadFloats, then mean[20], inv[20]
+    float* nrm = head + kHeadFloats;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31;
+    const float clip = p.rms ? p.clip_obs : 3.0e38f;
+#define RSS_STAMP(k) do { if (p.stamps && threadIdx.x == 0) p.stamps[(int64_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    RSS_STAMP(0);
+    for (int q = threadIdx.x; q < kHeadFloats; q += 512)
+        head[q] = reinterpret_cast<const float*>(p.image + 2 * (size_t)kNetBytes)[q];
+    if (p.mg.rows) {                            // fold the previous env step's tile sums into the statistics first
+        MergeRegs mr;
+        merge_request(p.mg, mr);
+        merge_prologue(p.mg, mr, p.rms, reinterpret_cast<double*>(nrm + 40), p.eps_norm, nrm, nrm + 20);
+    } else if ((int)threadIdx.x < kIn) {
+        nrm[threadIdx.x] = p.rms ? (float)p.rms[threadIdx.x] : 0.0f;
+        nrm[20 + threadIdx.x] = p.rms ? (float)(1.0 / sqrt(p.rms[kIn + threadIdx.x] + (double)p.eps_norm)) : 1.0f;
+    }
+    const int64_t d = (int64_t)blockIdx.x * 256 + wave * 32 + col;
+    const uint64_t tick = p.st.tick[(int64_t)blockIdx.x * 4];       // this workgroup's own tile's copy (rollout_step_kernel)
+    const SplitOut out{p.obs_n, p.action, p.clipped, p.value, p.logp, nullptr};
+    f32x4 cl = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int net = 0; net < 2; ++net) {
+        __syncthreads();   // everyone is done with the previous image (and the head block / normaliser are written)
+        split_stage_image<512>(p.image, net, lds_raw);
+        __syncthreads();
+        if (net == 0) RSS_STAMP(1);
+        const f32x4 r = split_net_row(net, lds_raw, head, nrm, clip, p.st.obs, d, d < p.st.n, lane, out, nullptr, tick, false, p.pol_seed,
+                                      p.pol_id_offset);
+        if (net == 0) cl = r;
+    }
+    TileRegs tr;
+    rs_load_tile(p.st, tr);
+    lds_barrier();                                     // every wave is done with the image: its space is free
+    RSS_STAMP(2);
+    if (lane < 32) reinterpret_cast<f32x4*>(lds + kRsAct)[wave * 32 + lane] = cl;
+    lds_barrier();
+    const TailOut to{p.st.reward, p.st.terminated, p.st.truncated, p.st.done, p.st.partials, true, false, true,
+                     p.stamps ? p.stamps + (int64_t)blockIdx.x * 16 + 4 : nullptr};
+    rs_tail(p.st, lds, tr, to);
+    RSS_STAMP(3);
+#undef RSS_STAMP
+}
+#pragma clang fp contract(on)
+
 // ---------------------------------------------------------------- the persistent kernel: T rollout steps in one launch
 // One workgroup per CU keeps the weight image in LDS and its 256 drones' state in registers for the whole rollout.  What
 // crosses workgroups is VecNormalize's statistics only: RunningMeanStd.update needs the moment sums of ALL drones of step t
@@ -961,6 +1030,23 @@ hipError_t launch_rollout_step(const float* image, const double* rms, float* obs
     RollStepArgs p{image, rms, obs_n, action, clipped, value, logp, pol_seed, pol_id_offset, clip_obs, eps_norm, merge, st, stamps};
     if (yaw) hipLaunchKernelGGL(rollout_step_kernel<1>, dim3((unsigned)(st.n / 256)), dim3(512), (size_t)full, s, p);
     else hipLaunchKernelGGL(rollout_step_kernel<0>, dim3((unsigned)(st.n / 256)), dim3(512), (size_t)full, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_rollout_step_split(const unsigned char* image, const double* rms, float* obs_n, float* action, float* clipped, float* value,
+                                     float* logp, uint64_t pol_seed, uint64_t pol_id_offset, float clip_obs, float eps_norm,
+                                     const MergeArgs& merge, const StepArgs<float>& st, uint64_t* stamps, hipStream_t s) {
+    static bool attr_tab[64] = {};                    // hipFuncSetAttribute holds for one device: one flag per ordinal
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    bool& attr_set = attr_tab[dev_ & 63];
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)rollout_step_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kRsSplitLdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    RollStepSplitArgs p{image, rms, obs_n, action, clipped, value, logp, pol_seed, pol_id_offset, clip_obs, eps_norm, merge, st, stamps};
+    hipLaunchKernelGGL(rollout_step_split_kernel, dim3((unsigned)(st.n / 256)), dim3(512), (size_t)kRsSplitLdsBytes, s, p);
     return hipGetLastError();
 }
 

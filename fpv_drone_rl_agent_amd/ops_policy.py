@@ -43,6 +43,8 @@ class FusedPolicy:
         modes = {"f32": 0, "bf16x6": 1, "f32_w16": 2}
         if gemm not in modes:
             raise ValueError("gemm must be 'f32', 'bf16x6' or 'f32_w16'")
+        if gemm == "bf16x6" and (self.obs_dim, self.act_dim) != (20, 4):
+            raise ValueError("the bf16 split kernel takes the hover task's widths (20 -> 4) only")
         L.check(self.lib.fpv_policy_set_gemm(self._h, modes[gemm]), "fpv_policy_set_gemm")
         self.gemm = gemm
 

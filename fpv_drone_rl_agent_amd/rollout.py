@@ -128,12 +128,14 @@ class RolloutCollector:
             # bit-identical results.  Served for both tasks with motor noise, drone counts that are multiples of 256 up
             # to 256 x 1 024, the exact-fp32 policy, and the statistics merge in the launch prologue (or no normalisation).
             norm = self.norm_obs or self.norm_reward
+            # (hover also with policy_gemm="bf16x6": rollout_step_split_kernel)
+            self._one_launch_gemms = ("f32", "bf16x6") if engine.task == "hover" else ("f32",)
             can = (engine.noise_ratio > 0.0 and N % 256 == 0 and N // 256 <= 1024
-                   and policy_gemm == "f32" and not self.overlap_critic and not self._merge_in_step
+                   and policy_gemm in self._one_launch_gemms and not self.overlap_critic and not self._merge_in_step
                    and (self._merge_in_policy or not norm))
             if one_launch and not can:
-                raise ValueError("one_launch needs motor noise, num_envs a multiple of 256 (<= 262 144), policy_gemm='f32' and the "
-                                 "default statistics-merge placement")
+                raise ValueError("one_launch needs motor noise, num_envs a multiple of 256 (<= 262 144), policy_gemm='f32' (or 'bf16x6' "
+                                 "for the hover task) and the default statistics-merge placement")
             # Default: where every workgroup finds a CU of its own (num_envs <= 256 x CUs).  Beyond that the second round of
             # workgroups stages the weight image again, while the two-kernel shape's policy kernel keeps it in LDS across its
             # chunks: measured 128.2 vs 126.3 us per step at 131 072 drones, 257.2 vs 234.9 at 262 144.
@@ -142,7 +144,7 @@ class RolloutCollector:
             # persistent: the WHOLE rollout of n_steps as one launch (fpv_rollout_steps): weights stay in LDS, drone state in
             # registers, a grid-wide barrier + statistics merge between steps.  Same bits again.  Needs every workgroup resident:
             # at most one per CU, i.e. num_envs <= 256 x CUs.
-            can_p = can and N // 256 <= cus and engine.task == "hover" and engine.detector == "analytic"
+            can_p = can and N // 256 <= cus and engine.task == "hover" and engine.detector == "analytic" and policy_gemm == "f32"
             if persistent and not can_p:
                 raise ValueError("persistent needs what one_launch needs, num_envs <= 256 x the device's CU count and "
                                  "detector='analytic'")
@@ -448,7 +450,7 @@ class RolloutCollector:
         if not self.fused:
             raise ValueError("policy_gemm applies to the fused path")
         self.fp.set_gemm(gemm)
-        self._one_launch = self._one_launch_ok and gemm == "f32"    # fpv_rollout_step(s) serve the exact-fp32 policy
+        self._one_launch = self._one_launch_ok and gemm in self._one_launch_gemms   # fpv_rollout_step: exact fp32, and the split for hover
         self._persistent = self._persistent_ok and gemm == "f32"
         self.overlap_critic = self._vstream is not None and gemm == "f32"
         self._graph = None

@@ -27,8 +27,11 @@ def _synthetic(engine, oracle, seed):
     engine.set_state(torch.from_numpy(st.astype(np.float32)).cuda())
 
 
+@pytest.mark.parametrize("gemm", ["f32", "bf16x6"])
 @pytest.mark.parametrize("n,pair_threshold", [(1024, 0), (65536, 32768)])
-def test_one_launch_equals_policy_then_step(oracle, n, pair_threshold):
+def test_one_launch_equals_policy_then_step(oracle, n, pair_threshold, gemm):
+    """gemm = "f32": rollout_step_kernel<0> (the default and the headline); "bf16x6": rollout_step_split_kernel, the same step with
+    the policy's hidden GEMMs on the 6-term bf16 split — each against its own two-kernel form, bit for bit."""
     from fpv_drone_rl_agent_amd import _lib as L
     from fpv_drone_rl_agent_amd import ops
     from fpv_drone_rl_agent_amd.engine import FpvEngine
@@ -37,7 +40,7 @@ def test_one_launch_equals_policy_then_step(oracle, n, pair_threshold):
     lib.fpv_set_pair_threshold(pair_threshold)
     try:
         engs = [FpvEngine(n, 0, seed=5, ledger_capacity=8 * n) for _ in range(2)]
-        fp = FusedPolicy(_policy(), seed=11)
+        fp = FusedPolicy(_policy(), seed=11, gemm=gemm)
         bufs = []
         obs0 = torch.randn((n, 20), device="cuda", generator=torch.Generator(device="cuda").manual_seed(8))
         for e in engs:
@@ -123,7 +126,15 @@ def test_default_collector_takes_the_one_launch_path_where_served():
     assert RolloutCollector(FpvEngine(4096, 0), _policy(), n_steps=4)._one_launch
     assert not RolloutCollector(FpvEngine(4000, 0), _policy(), n_steps=4)._one_launch            # not a multiple of 256
     assert not RolloutCollector(FpvEngine(4096, 0, noise_ratio=0.0), _policy(), n_steps=4)._one_launch
-    assert not RolloutCollector(FpvEngine(4096, 0), _policy(), n_steps=4, policy_gemm="bf16x6")._one_launch
+    c = RolloutCollector(FpvEngine(4096, 0), _policy(), n_steps=4, policy_gemm="bf16x6")        # hover: rollout_step_split_kernel
+    assert c._one_launch
+    c.set_policy_gemm("f32_w16"); assert not c._one_launch
+    c.set_policy_gemm("bf16x6"); assert c._one_launch
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    yaw = RolloutCollector(FpvEngine(4096, 0, task="yaw"), ActorCritic(obs_dim=12, act_dim=1).cuda(), n_steps=4)
+    assert yaw._one_launch
+    with pytest.raises(ValueError):                       # the split kernel takes the hover widths only
+        yaw.set_policy_gemm("bf16x6")
     with pytest.raises(ValueError):
         RolloutCollector(FpvEngine(4000, 0), _policy(), n_steps=4, one_launch=True)
 
@@ -386,3 +397,41 @@ def test_both_graphs_are_captured_before_the_first_rollout(oracle):
         last_obs = col.cur_obs.clone()
     assert eng.get_tick() == t0 + 1 + 4 * T
     assert float(col.obs_norm.rms[40]) == count1 + 3 * T * n
+
+
+@pytest.mark.parametrize("gemm", ["f32", "bf16x6"])
+def test_one_kernel_step_policy_half_keeps_fp32_accuracy_over_repeated_launches(oracle, gemm):
+    """fpv_rollout_step at the bench size, 25 launches, EVERY row: V against an fp64 evaluation of the same network at the bar of
+    tests/test_policy_gpu.py (the 6-term bf16 split must sit at the exact-fp32 kernel's error level), log pi(a) of the sampled
+    action against the fp64 mean, and the draws standard normal.  (The first split kernel returned ~1 row in 3 000 with a wrong
+    action-head component on the ds_bpermute route — DESIGN §5b; the one-kernel form is held to the same every-row check.)"""
+    import copy
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.ops_policy import FusedPolicy
+    n = 65536
+    pol = _policy(7)
+    with torch.no_grad():
+        pol.log_std.fill_(-0.5)
+    m64 = copy.deepcopy(pol).double()
+    fp = FusedPolicy(pol, seed=3, gemm=gemm)
+    eng = FpvEngine(n, 0, seed=9, ledger_capacity=8 * n)
+    _synthetic(eng, oracle, 5)
+    act, val, lp = torch.zeros(n, 4, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    part = torch.zeros((2, n // 256, 44), dtype=torch.float64, device="cuda")
+    worst_v = worst_lp = 0.0
+    for trial in range(25):
+        obs = torch.randn((n, 20), device="cuda", generator=torch.Generator(device="cuda").manual_seed(trial)) * 2
+        eng.obs.copy_(obs)
+        fp.rollout_step(eng, rms=None, action=act, value=val, logp=lp, partials=part[trial % 2])
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            mu64, v64 = m64.mean_value(obs.double())
+            z = (act.double() - mu64) * torch.exp(-m64.log_std)
+            lp64 = (-0.5 * z * z - m64.log_std - 0.9189385332046727).sum(dim=1)
+        worst_v = max(worst_v, float((val.double() - v64).abs().max()))
+        worst_lp = max(worst_lp, float((lp.double() - lp64).abs().max()))
+        assert float((val.double() - v64).abs().max()) <= 1e-5, trial
+        assert float((lp.double() - lp64).abs().max()) <= 5e-4, trial          # (|z| up to ~5: an error of 1e-6 in mu / sigma is 1e-5 here)
+        assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1.0) < 0.01, trial
+    print(gemm, "worst |V - V64|", worst_v, "worst |logp - logp64|", worst_lp)
+    eng.close()
