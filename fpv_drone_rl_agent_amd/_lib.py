@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-from .build import LIB_PATH, build_extension
+from .build import LIB_PATH, LIB_PATH_EXPERIMENTS, build_extension
 
 FPV_F32, FPV_F64 = 0, 1
 TASK_HOVER, TASK_YAW = 0, 1
@@ -113,12 +113,15 @@ SIGNATURES = {
     "fpv_policy_set_gemm": (C.c_int, [_vp, _i32]),
     "fpv_policy_forward": (C.c_int, [_vp, C.POINTER(FpvPolicyIo), _vp]),
     "fpv_rollout_step": (C.c_int, [_vp, _vp, C.POINTER(FpvPolicyIo), _vp, _vp, _vp, C.POINTER(FpvStepExtras), _vp]),
-    "fpv_rollout_steps": (C.c_int, [_vp, _vp, C.POINTER(FpvRolloutIo), _vp]),
     "fpv_ppo_workspace_bytes": (C.c_int, [_vp, _i64, C.POINTER(_i64)]),
     "fpv_ppo_grad": (C.c_int, [_vp, C.POINTER(FpvPpoIo), _vp]),
     "fpv_adam_clip_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp]),
     "fpv_last_error": (C.c_char_p, []),
     "fpv_version": (C.c_int, []),
+}
+# include/fpv_env_experiments.h: exported by libfpv_env_experiments.so only (FPV_EXPERIMENTS=1 in the environment selects it)
+EXPERIMENT_SIGNATURES = {
+    "fpv_rollout_steps": (C.c_int, [_vp, _vp, C.POINTER(FpvRolloutIo), _vp]),
 }
 # include/fpv_env_debug.h: diagnostic hooks (tools/, bench.py's phase report, tests) — not the product interface
 DEBUG_SIGNATURES = {
@@ -131,24 +134,38 @@ DEBUG_SIGNATURES = {
 }
 
 _lib = None
+EXPERIMENTS = os.environ.get("FPV_EXPERIMENTS", "") not in ("", "0")    # which library this process loads
+
+
+def experiments() -> bool:
+    """True when this process runs on libfpv_env_experiments.so (FPV_EXPERIMENTS=1): the measured alternatives of DESIGN §5b."""
+    return EXPERIMENTS
+
+
+def require_experiments(what: str) -> None:
+    if not EXPERIMENTS:
+        raise RuntimeError(f"{what} is one of the measured alternatives that lost (DESIGN §5b): it is built into "
+                           "libfpv_env_experiments.so only — set FPV_EXPERIMENTS=1 in the environment before importing the package")
 
 
 def load(build_if_missing: bool = True):
-    """Load libfpv_env.so (building it in-tree with hipcc when absent).  Raises on failure."""
+    """Load libfpv_env.so — or libfpv_env_experiments.so when FPV_EXPERIMENTS=1 — (building it in-tree with hipcc when absent).
+    Raises on failure."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    lib_path = LIB_PATH_EXPERIMENTS if EXPERIMENTS else LIB_PATH
+    if not os.path.exists(lib_path):
         if not build_if_missing:
-            raise RuntimeError(f"{LIB_PATH} is missing: build it with fpv_drone_rl_agent_amd.build.build_extension()")
-        build_extension()
-    lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in {**SIGNATURES, **DEBUG_SIGNATURES}.items():
+            raise RuntimeError(f"{lib_path} is missing: build it with fpv_drone_rl_agent_amd.build.build_extension()")
+        build_extension(experiments=EXPERIMENTS)
+    lib = C.CDLL(lib_path)
+    for name, (res, args) in {**SIGNATURES, **DEBUG_SIGNATURES, **(EXPERIMENT_SIGNATURES if EXPERIMENTS else {})}.items():
         fn = getattr(lib, name)  # AttributeError if the ABI and the headers drift apart
         fn.restype, fn.argtypes = res, args
     built = lib.fpv_version()
     if built != ABI_VERSION:         # struct layouts / enum values differ between versions: refuse before the first real call
-        raise RuntimeError(f"{LIB_PATH} was built for FPV_ABI_VERSION {built}, this binding is version {ABI_VERSION}: "
+        raise RuntimeError(f"{lib_path} was built for FPV_ABI_VERSION {built}, this binding is version {ABI_VERSION}: "
                            "rebuild it (fpv_drone_rl_agent_amd.build.build_extension(force=True))")
     _lib = lib
     return lib

@@ -12,9 +12,16 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libfpv_env.so")
-SOURCES = ["fpv_step.hip", "fpv_yaw.hip", "fpv_rollout.hip", "fpv_policy.hip", "fpv_policy_w16.hip", "fpv_policy_split.hip", "fpv_rollstep.hip", "fpv_ppo.hip", "fpv_capi.hip"]
+# The experiments library: the same sources with -DFPV_EXPERIMENTS=1 plus the 16-wave policy kernel — the measured alternatives that
+# lost (persistent whole-rollout launch, 16-wave policy kernel, 256-thread policy launches, in-launch statistics merge of the env
+# step).  Selected by FPV_EXPERIMENTS=1 in the environment (fpv_drone_rl_agent_amd._lib); the product library does
+# not contain them.
+LIB_PATH_EXPERIMENTS = os.path.join(_HERE, "libfpv_env_experiments.so")
+SOURCES = ["fpv_step.hip", "fpv_yaw.hip", "fpv_rollout.hip", "fpv_policy.hip", "fpv_policy_split.hip", "fpv_rollstep.hip", "fpv_ppo.hip", "fpv_capi.hip"]
+EXPERIMENT_SOURCES = ["fpv_policy_w16.hip"]
 HEADERS = ["fpv_dynamics.h", "fpv_internal.h", "fpv_mlp.h", "fpv_policy_image.h", "fpv_step_parts.h", "fpv_yaw_parts.h", "fpv_pixel_tile.h",
-           os.path.join("..", "..", "include", "fpv_env.h"), os.path.join("..", "..", "include", "fpv_env_debug.h")]
+           "fpv_policy_split.h", os.path.join("..", "..", "include", "fpv_env.h"), os.path.join("..", "..", "include", "fpv_env_debug.h"),
+           os.path.join("..", "..", "include", "fpv_env_experiments.h")]
 
 
 def _hipcc() -> str:
@@ -24,24 +31,26 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: the MI355X extension cannot be built")
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB_PATH):
+def _stale(lib_path: str) -> bool:
+    if not os.path.exists(lib_path):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    files = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    t = os.path.getmtime(lib_path)
+    files = [os.path.join(CSRC, f) for f in SOURCES + EXPERIMENT_SOURCES + HEADERS]
     return any(os.path.exists(f) and os.path.getmtime(f) > t for f in files)
 
 
-def build_extension(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/*.hip into libfpv_env.so for gfx950.  Returns the library path."""
-    if not force and not _stale():
-        return LIB_PATH
-    extra = os.environ.get("FPV_EXTRA_HIPCC_FLAGS", "").split()
-    base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + extra
-    objdir = os.path.join(_HERE, "build")
+def build_extension(force: bool = False, verbose: bool = False, experiments: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into libfpv_env.so, or with experiments=True into libfpv_env_experiments.so
+    (-DFPV_EXPERIMENTS=1).  Returns the library path."""
+    lib_path = LIB_PATH_EXPERIMENTS if experiments else LIB_PATH
+    if not force and not _stale(lib_path):
+        return lib_path
+    extra = os.environ.get("FPV_EXTRA_HIPCC_FLAGS", "").split() + (["-DFPV_EXPERIMENTS=1"] if experiments else [])
+    base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"] + extra
+    objdir = os.path.join(_HERE, "build", "experiments" if experiments else "product")
     os.makedirs(objdir, exist_ok=True)
     objs = []
-    for f in SOURCES:
+    for f in SOURCES + (EXPERIMENT_SOURCES if experiments else []):
         src = os.path.join(CSRC, f)
         if not os.path.exists(src):
             continue
@@ -56,12 +65,13 @@ def build_extension(force: bool = False, verbose: bool = False) -> str:
             print(" ".join(cmd))
         subprocess.check_call(cmd, cwd=CSRC)
         objs.append(obj)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == "__main__":
     print(build_extension(force=True, verbose=True))
+    print(build_extension(force=True, verbose=True, experiments=True))

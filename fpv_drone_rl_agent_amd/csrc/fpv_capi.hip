@@ -4,6 +4,9 @@
 // caller's stream.  No allocation and no host synchronisation inside fpv_step.
 #include "../../include/fpv_env.h"
 #include "../../include/fpv_env_debug.h"
+#ifdef FPV_EXPERIMENTS
+#include "../../include/fpv_env_experiments.h"
+#endif
 #include "fpv_dynamics.h"
 #include "fpv_internal.h"
 
@@ -132,6 +135,8 @@ static int step_impl(fpv_env* e, const T* actions, T* obs, T* reward, uint8_t* t
 
 __global__ void fpv_noop_kernel() {}
 
+// the library is compiled with -fvisibility=hidden: only the C ABI of include/*.h is exported
+#pragma GCC visibility push(default)
 extern "C" {
 
 int fpv_set_pair_threshold(int64_t max_drones) {
@@ -217,7 +222,7 @@ int fpv_create(const fpv_config* cfg, fpv_env** out) {
     alloc(&e->tmpl, (size_t)(kStateWords + kObsWords) * e->word);
     alloc((void**)&e->tick, (size_t)e->tiles * sizeof(uint64_t));
     alloc((void**)&e->merge_ticket, 64);
-    alloc((void**)&e->rollout_sync, sizeof(uint32_t) * (size_t)rollout_sync_words());
+    alloc((void**)&e->rollout_sync, sizeof(uint32_t) * (size_t)(rollout_sync_words() > 0 ? rollout_sync_words() : 16));
     alloc((void**)&e->led_count, (size_t)e->tiles * sizeof(uint32_t));
     alloc((void**)&e->led_idx, (size_t)e->led_cap * sizeof(int32_t));
     alloc((void**)&e->led_info, (size_t)e->led_cap * sizeof(uint32_t));
@@ -529,7 +534,9 @@ int fpv_policy_create(int32_t device, fpv_policy** out) {
     p->image16 = nullptr;
     hipError_t e = hipMalloc((void**)&p->image, sizeof(float) * (size_t)policy_image_floats());
     if (e == hipSuccess) e = hipMalloc((void**)&p->split_image, (size_t)policy_split_image_bytes());
+#ifdef FPV_EXPERIMENTS
     if (e == hipSuccess) e = hipMalloc((void**)&p->image16, sizeof(float) * (size_t)policy16_image_floats());
+#endif
     if (e != hipSuccess) {
         delete p;
         return fail(FPV_ERR_HIP, "fpv_policy_create: %s", hipGetErrorString(e));
@@ -552,7 +559,9 @@ int fpv_policy_load(fpv_policy* p, const float* const* weights, void* stream) {
     for (int i = 0; i < 13; ++i)
         if (!weights[i]) return fail(FPV_ERR_ARG, "fpv_policy_load: weight pointer %d is null", i);
     FPV_HIP(launch_policy_pack(weights, p->image, p->in_dim, p->act_dim, (hipStream_t)stream));
+#ifdef FPV_EXPERIMENTS
     if (p->in_dim <= 20) FPV_HIP(launch_policy16_pack(weights, p->image16, p->in_dim, p->act_dim, (hipStream_t)stream));
+#endif
     if (p->in_dim == 20 && p->act_dim == 4) FPV_HIP(launch_policy_split_pack(weights, p->split_image, (hipStream_t)stream));
     return FPV_OK;
 }
@@ -570,6 +579,9 @@ int fpv_policy_set_gemm(fpv_policy* p, int32_t mode) {
     if (!p) return fail(FPV_ERR_ARG, "fpv_policy_set_gemm: null handle");
     if (mode < 0 || mode > 2)
         return fail(FPV_ERR_ARG, "fpv_policy_set_gemm: mode must be 0 (fp32 MFMA), 1 (bf16 6-term split) or 2 (fp32 MFMA, 16-wave kernel)");
+#ifndef FPV_EXPERIMENTS
+    if (mode == 2) return fail(FPV_ERR_UNSUPPORTED, "fpv_policy_set_gemm: mode 2 (the 16-wave kernel) is part of the FPV_EXPERIMENTS build");
+#endif
     p->gemm = mode;
     return FPV_OK;
 }
@@ -604,6 +616,7 @@ int fpv_policy_forward(fpv_policy* p, const fpv_policy_io* io, void* stream) {
                                             io->clip_obs, io->eps_norm, io->deterministic, p->cus, mg, (hipStream_t)stream));
         return FPV_OK;
     }
+#ifdef FPV_EXPERIMENTS
     if (p->gemm == 2 && nets == 3 && !io->narrow && !mg.rows && !io->eps_in && !io->deterministic && !io->n_dev && p->in_dim <= 20) {
         // the rollout's launch shape (both nets, in-kernel sampling): 16-wave workgroups on 16x16x4 tiles
         FPV_HIP(launch_policy16_forward(p->image16, io->obs, io->rms, io->tick, io->obs_n, io->action, io->clipped, io->value,
@@ -611,6 +624,9 @@ int fpv_policy_forward(fpv_policy* p, const fpv_policy_io* io, void* stream) {
                                         p->cus, p->in_dim, p->act_dim, (hipStream_t)stream));
         return FPV_OK;
     }
+#else
+    if (io->narrow) return fail(FPV_ERR_UNSUPPORTED, "fpv_policy_forward: narrow (256-thread) launches are part of the FPV_EXPERIMENTS build");
+#endif
     FPV_HIP(launch_policy_forward(p->image, io->obs, io->rms, io->eps_in, io->tick, io->obs_n, io->action, io->clipped,
                                   io->value, io->logp, io->eps_out, io->n, io->seed, io->id_offset, io->clip_obs,
                                   io->eps_norm, io->deterministic, p->cus, nets, io->narrow ? 1 : 0, p->in_dim, p->act_dim, mg,
@@ -676,6 +692,7 @@ int fpv_rollout_step(fpv_env* e, fpv_policy* p, const fpv_policy_io* io, float* 
     return FPV_OK;
 }
 
+#ifdef FPV_EXPERIMENTS   // the persistent launch: measured slower than one launch per step
 int fpv_rollout_steps(fpv_env* e, fpv_policy* p, const fpv_rollout_io* io, void* stream) {
     if (!e || !p || !io) return fail(FPV_ERR_ARG, "fpv_rollout_steps: null argument");
     if (io->T <= 0) return fail(FPV_ERR_ARG, "fpv_rollout_steps: T must be positive");
@@ -734,6 +751,7 @@ int fpv_rollout_steps(fpv_env* e, fpv_policy* p, const fpv_rollout_io* io, void*
     FPV_HIP(launch_rollout_persistent(h, a, (hipStream_t)stream));
     return FPV_OK;
 }
+#endif   // FPV_EXPERIMENTS
 
 int fpv_ppo_workspace_bytes(fpv_policy* p, int64_t rows, int64_t* bytes) {
     if (!p || !bytes || rows <= 0) return fail(FPV_ERR_ARG, "fpv_ppo_workspace_bytes: null argument or rows <= 0");
@@ -777,3 +795,4 @@ int fpv_adam_clip_step(float* param, const float* grad, float* exp_avg, float* e
 }
 
 }  // extern "C"
+#pragma GCC visibility pop

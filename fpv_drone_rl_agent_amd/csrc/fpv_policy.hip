@@ -329,8 +329,10 @@ hipError_t launch_policy_forward(const float* image, const float* obs, const dou
     if (!attr_set) {
         const int full = (int)((2 * kNetFloats + (kImageFloats - kHeadBase) + 40) * sizeof(float)) + kMergeLdsBytes;
         hipError_t e = hipFuncSetAttribute((const void*)policy_forward_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, full);
+#ifdef FPV_EXPERIMENTS
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)policy_forward_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, full);
+#endif
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -342,9 +344,13 @@ hipError_t launch_policy_forward(const float* image, const float* obs, const dou
     const int threads = narrow ? 256 : 512, chunk = threads / 2;
     int64_t blocks = (n + chunk - 1) / chunk;
     if (blocks > max_blocks) blocks = max_blocks;
+#ifdef FPV_EXPERIMENTS   // the 256-thread form exists for the critic-beside-the-env-step experiment only
     if (narrow)
         hipLaunchKernelGGL(policy_forward_kernel<256>, dim3((unsigned)blocks), dim3(256), lds_bytes, s, p, net_first, net_count);
     else
+#else
+    if (narrow) return hipErrorNotSupported;
+#endif
         hipLaunchKernelGGL(policy_forward_kernel<512>, dim3((unsigned)blocks), dim3(512), lds_bytes, s, p, net_first, net_count);
     return hipGetLastError();
 }

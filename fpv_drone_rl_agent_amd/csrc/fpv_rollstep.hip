@@ -741,6 +741,7 @@ __global__ __launch_bounds__(512) void rollout_step_split_kernel(RollStepSplitAr
 }
 #pragma clang fp contract(on)
 
+#ifdef FPV_EXPERIMENTS   // measured slower than one launch per step: built into libfpv_env_experiments.so only
 // ---------------------------------------------------------------- the persistent kernel: T rollout steps in one launch
 // One workgroup per CU keeps the weight image in LDS and its 256 drones' state in registers for the whole rollout.  What
 // crosses workgroups is VecNormalize's statistics only: RunningMeanStd.update needs the moment sums of ALL drones of step t
@@ -1010,6 +1011,8 @@ __global__ __launch_bounds__(512) void rollout_persistent_kernel(RollPersistArgs
     if (!ok && tid == 0) *p.status = 1u;
 }
 
+#endif   // FPV_EXPERIMENTS
+
 // ---------------------------------------------------------------- launchers
 // Preconditions (checked by fpv_rollout_step): fp32 handle with motor noise, n a multiple of 256, the task's policy widths.
 hipError_t launch_rollout_step(const float* image, const double* rms, float* obs_n, float* action, float* clipped, float* value,
@@ -1050,6 +1053,7 @@ hipError_t launch_rollout_step_split(const unsigned char* image, const double* r
     return hipGetLastError();
 }
 
+#ifdef FPV_EXPERIMENTS
 int rollout_sync_words() { return kSyncWords; }
 
 hipError_t launch_rollout_persistent(const RollPersistHost& h, const StepArgs<float>& st, hipStream_t s) {
@@ -1086,5 +1090,9 @@ hipError_t launch_rollout_persistent(const RollPersistHost& h, const StepArgs<fl
     return hipLaunchCooperativeKernel((const void*)rollout_persistent_kernel, dim3((unsigned)(st.n / 256)), dim3(512), args,
                                       (unsigned)full, s);
 }
+
+#else
+int rollout_sync_words() { return 0; }
+#endif   // FPV_EXPERIMENTS
 
 }  // namespace fpv

@@ -156,13 +156,18 @@ __global__ __launch_bounds__(kTile * TPB) void step_kernel(StepArgs<T> p) {
                     if (wv == 0 && lane < kPartialWords) {
                         const double v = (bsum[lane] + bsum[kPartialWords + lane]) + (bsum[2 * kPartialWords + lane] + bsum[3 * kPartialWords + lane]);
                         double* row = p.partials + (int64_t)blockIdx.x * kPartialWords + lane;
+#ifdef FPV_EXPERIMENTS
                         if (p.mg_ticket) row_store_sc1(row, v);      // write-through: read by the last workgroup of this launch
-                        else *row = v;
+                        else
+#endif
+                        *row = v;
                     }
+#ifdef FPV_EXPERIMENTS                                                  // (merge_in_step: measured slower)
                     if (p.mg_ticket) {                                  // uniform
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         step_merge_tail(p, p.partials, kObsWords, bsum);
                     }
+#endif
                 }
             }
         }
@@ -398,8 +403,13 @@ hipError_t launch_step(const StepArgs<T>& a_in, bool noise, hipStream_t s, bool*
     // of sums per thread-way comfortably (tiles / 4 <= 4 096)
     const bool pair = sizeof(T) == 4 && noise && g_pair_max_tiles > 0 && tiles <= g_pair_max_tiles;
     const bool can_merge = sizeof(T) == 4 && fused && a.partials && a.mg_ticket && !pair && tiles % 4 == 0 && tiles / 4 <= 4096;
+#ifndef FPV_EXPERIMENTS
+    a.mg_ticket = nullptr;                        // the in-launch merge is an FPV_EXPERIMENTS build's
+    if (merged) *merged = false;
+#else
     if (!can_merge) a.mg_ticket = nullptr;
     if (merged) *merged = can_merge;
+#endif
     if constexpr (sizeof(T) == 4) {
         // few enough tiles that the chip would sit at one wave per SIMD: physics wave + helper wave per tile
         if (noise && g_pair_max_tiles > 0 && tiles <= g_pair_max_tiles) {

@@ -116,13 +116,18 @@ __global__ __launch_bounds__(kTile * TPB) void yaw_step_kernel(StepArgs<T> p) {
                     if (wv == 0 && lane < kRow) {
                         const double v = (bsum[lane] + bsum[kRow + lane]) + (bsum[2 * kRow + lane] + bsum[3 * kRow + lane]);
                         double* row = p.partials + (int64_t)blockIdx.x * kRow + lane;
+#ifdef FPV_EXPERIMENTS
                         if (p.mg_ticket) row_store_sc1(row, v);      // write-through: read by the last workgroup of this launch
-                        else *row = v;
+                        else
+#endif
+                        *row = v;
                     }
+#ifdef FPV_EXPERIMENTS                                                  // (merge_in_step: measured slower)
                     if (p.mg_ticket) {                                  // uniform
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         step_merge_tail(p, p.partials, kYawObsWords, bsum);
                     }
+#endif
                 }
             }
         }
@@ -175,8 +180,14 @@ hipError_t launch_yaw_step(const StepArgs<T>& a_in, bool noise, hipStream_t s, b
     const int64_t tiles = (a.n + kTile - 1) / kTile;
     const bool fused = a.done || a.ret || a.partials;
     const bool can_merge = sizeof(T) == 4 && fused && a.partials && a.mg_ticket && tiles % 4 == 0 && tiles / 4 <= 4096;
+#ifndef FPV_EXPERIMENTS
+    a.mg_ticket = nullptr;                             // the in-launch merge is an FPV_EXPERIMENTS build's
+    if (merged) *merged = false;
+    (void)can_merge;
+#else
     if (!can_merge) a.mg_ticket = nullptr;             // (the in-launch merge lives in the four-tiles-per-workgroup variant)
     if (merged) *merged = can_merge;
+#endif
     if constexpr (sizeof(T) == 4) {
         if (fused) {
             if (tiles % 4 == 0) {               // four tiles per workgroup, one partial row per workgroup (yaw_partial_rows)

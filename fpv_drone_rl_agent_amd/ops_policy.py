@@ -43,6 +43,8 @@ class FusedPolicy:
         modes = {"f32": 0, "bf16x6": 1, "f32_w16": 2}
         if gemm not in modes:
             raise ValueError("gemm must be 'f32', 'bf16x6' or 'f32_w16'")
+        if gemm == "f32_w16":
+            L.require_experiments("policy_gemm='f32_w16' (the 16-wave policy kernel)")
         if gemm == "bf16x6" and (self.obs_dim, self.act_dim) != (20, 4):
             raise ValueError("the bf16 split kernel takes the hover task's widths (20 -> 4) only")
         L.check(self.lib.fpv_policy_set_gemm(self._h, modes[gemm]), "fpv_policy_set_gemm")
@@ -74,6 +76,8 @@ class FusedPolicy:
         fpv_step_fused's tile sums into the statistics in this launch (rms / ret_rms are read, *_out written).
         n_dev: int32 device scalar; only the first min(n, n_dev) rows are evaluated."""
         n = obs.shape[0]
+        if narrow:
+            L.require_experiments("narrow=True (256-thread policy launches)")
         if obs.dtype != torch.float32 or not obs.is_contiguous() or obs.shape[1] != self.obs_dim:
             raise ValueError(f"obs must be a contiguous [n,{self.obs_dim}] fp32 device tensor")
         mask = {"both": 3, "pi": 1, "v": 2}[nets]

@@ -62,6 +62,11 @@ class RolloutCollector:
                  persistent: bool | None = None):
         if engine.dtype != torch.float32:
             raise ValueError("the rollout collector runs on an fp32 engine")
+        from . import _lib as _L
+        for flag, what in ((persistent, "persistent=True (the whole rollout as one launch)"),
+                           (overlap_critic, "overlap_critic=True (the critic beside the env step)")):
+            if flag:
+                _L.require_experiments(what)       # (merge_in_step works in either library: in-launch there, a merge kernel here)
         self.engine, self.policy = engine, policy
         self.T, self.N = int(n_steps), engine.num_envs
         self.gamma, self.lam = float(gamma), float(lam)

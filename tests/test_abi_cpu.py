@@ -27,6 +27,16 @@ def test_header_symbols_all_exported_and_bound():
     assert sorted(_lib.DEBUG_SIGNATURES) == debug and not set(debug) & set(declared)
     assert all(hasattr(lib, name) for name in debug)
     assert not [n for n in declared if "debug" in n or n in ("fpv_noop", "fpv_set_pair_threshold")]
+    # the measured alternatives that lost live in a third header and a second library; the product library has none of them
+    exper = _declared_symbols("fpv_env_experiments.h")
+    assert sorted(_lib.EXPERIMENT_SIGNATURES) == exper and not set(exper) & set(declared)
+    if not _lib.experiments():
+        assert not any(hasattr(lib, name) for name in exper)
+    from fpv_drone_rl_agent_amd.build import build_extension
+    elib = ctypes.CDLL(build_extension(experiments=True))
+    assert all(hasattr(elib, name) for name in declared + debug + exper)
+    elib.fpv_version.restype = ctypes.c_int
+    assert elib.fpv_version() == _lib.ABI_VERSION
     # the version handshake (a host built against another header would pass structs of another size): header macro ==
     # library == binding; _lib.load() refuses a stale library
     macro = int(re.search(r"#define FPV_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "fpv_env.h")).read()).group(1))
@@ -46,9 +56,9 @@ def test_every_struct_layout_matches_the_header(tmp_path):
     from fpv_drone_rl_agent_amd import _lib
     pairs = {"fpv_config": _lib.FpvConfig, "fpv_ledger": _lib.FpvLedger, "fpv_step_extras": _lib.FpvStepExtras,
              "fpv_policy_io": _lib.FpvPolicyIo, "fpv_ppo_io": _lib.FpvPpoIo, "fpv_rollout_io": _lib.FpvRolloutIo}
-    header = open(os.path.join(ROOT, "include", "fpv_env.h")).read()
+    header = open(os.path.join(ROOT, "include", "fpv_env.h")).read() + open(os.path.join(ROOT, "include", "fpv_env_experiments.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
-    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "fpv_env.h"', 'int main(void) {']
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "fpv_env.h"', '#include "fpv_env_experiments.h"', 'int main(void) {']
     fields = {}
     for cname, cls in pairs.items():
         body = re.search(r"typedef struct\s*\{([^}]*)\}\s*" + cname + r"\s*;", header, flags=re.S).group(1)
@@ -85,7 +95,8 @@ def test_argument_errors_reported_without_gpu():
     assert lib.fpv_gae(0, 0, None, None, None, None, None, 0.99, 0.95, None, None, None, None, None) == -1
     assert lib.fpv_destroy(None) == 0
     assert lib.fpv_rollout_step(None, None, None, None, None, None, None, None) == -1 and b"fpv_rollout_step" in lib.fpv_last_error()
-    assert lib.fpv_rollout_steps(None, None, None, None) == -1 and b"fpv_rollout_steps" in lib.fpv_last_error()
+    if _lib.experiments():
+        assert lib.fpv_rollout_steps(None, None, None, None) == -1 and b"fpv_rollout_steps" in lib.fpv_last_error()
     assert lib.fpv_rollout_begin(None, None, None, None, None, None) == -1
     with pytest.raises(ValueError):
         _lib.check(-1, "x")

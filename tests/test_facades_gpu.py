@@ -265,6 +265,7 @@ def test_collector_turns_a_ledger_overflow_into_an_error():
 
 
 @pytest.mark.parametrize("T", [7, 8])
+@pytest.mark.both_libraries        # merge_in_step: a merge kernel behind the step in the product library, inside the step's launch in the other
 @pytest.mark.parametrize("norm", [(True, True), (True, False), (False, True)])
 def test_in_launch_statistics_merge_equals_the_merge_kernel(T, norm):
     """fpv_policy_io.merge_* (statistics folded into the next policy launch, ping-pong buffers: odd and even rollout
@@ -297,6 +298,7 @@ def test_in_launch_statistics_merge_equals_the_merge_kernel(T, norm):
             assert torch.allclose(a[k], x[k], rtol=1e-3, atol=2e-3), k
 
 
+@pytest.mark.both_libraries
 @pytest.mark.parametrize("n", [100, 4160, 70000])
 def test_collector_at_ragged_sizes(n):
     """Drone counts that exercise the other dispatch branches of the rollout step: 100 (wave-pair kernel, one partial

@@ -135,7 +135,7 @@ def test_policy_kernel_repeated_launches_every_row(gemm):
         assert float((r["value"].double() - v64).abs().max()) <= 1e-5, trial
 
 
-@pytest.mark.parametrize("narrow", [False, True])
+@pytest.mark.parametrize("narrow", [False, pytest.param(True, marks=pytest.mark.experiments)])
 def test_single_net_launches_match_the_joint_launch(narrow):
     m, fp = _setup(9)
     n = 7777
@@ -154,6 +154,7 @@ def test_single_net_launches_match_the_joint_launch(narrow):
     assert torch.equal(lp, lp_ref) and torch.equal(v, v_ref)
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("n", [1, 17, 256, 5000, 65536, 200000])
 def test_w16_kernel_matches_the_two_wave_kernel_on_the_rollout_launch(n):
     """gemm = "f32_w16" (fpv_policy_w16.hip: 16 drones per wave on 16x16x4 tiles, four waves per SIMD, LDS-DMA staging) against

@@ -128,8 +128,12 @@ def test_default_collector_takes_the_one_launch_path_where_served():
     assert not RolloutCollector(FpvEngine(4096, 0, noise_ratio=0.0), _policy(), n_steps=4)._one_launch
     c = RolloutCollector(FpvEngine(4096, 0), _policy(), n_steps=4, policy_gemm="bf16x6")        # hover: rollout_step_split_kernel
     assert c._one_launch
-    c.set_policy_gemm("f32_w16"); assert not c._one_launch
-    c.set_policy_gemm("bf16x6"); assert c._one_launch
+    c.set_policy_gemm("f32"); assert c._one_launch
+    from fpv_drone_rl_agent_amd import _lib as L
+    if not L.experiments():                               # the alternatives that lost are not in the product library
+        for kw in ({"persistent": True}, {"overlap_critic": True}, {"policy_gemm": "f32_w16"}):
+            with pytest.raises(RuntimeError, match="FPV_EXPERIMENTS=1"):
+                RolloutCollector(FpvEngine(4096, 0, detector="analytic"), _policy(), n_steps=4, **kw)
     from fpv_drone_rl_agent_amd.policy import ActorCritic
     yaw = RolloutCollector(FpvEngine(4096, 0, task="yaw"), ActorCritic(obs_dim=12, act_dim=1).cuda(), n_steps=4)
     assert yaw._one_launch
@@ -156,6 +160,7 @@ def test_unserved_requests_are_refused():
     eng.close()
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("n,T", [(65536, 12), (1024, 5), (4096, 1)])
 def test_persistent_rollout_equals_step_by_step(oracle, n, T):
     """RolloutCollector(persistent=True): the whole rollout as ONE launch (grid barrier + in-launch statistics merge between
@@ -190,6 +195,7 @@ def test_persistent_rollout_equals_step_by_step(oracle, n, T):
         L.load().fpv_set_pair_threshold(32768)
 
 
+@pytest.mark.experiments
 def test_persistent_refuses_more_workgroups_than_cus():
     from fpv_drone_rl_agent_amd.engine import FpvEngine
     from fpv_drone_rl_agent_amd.rollout import RolloutCollector
@@ -200,6 +206,7 @@ def test_persistent_refuses_more_workgroups_than_cus():
         RolloutCollector(FpvEngine(1024, 0), _policy(), n_steps=4, persistent=True)
 
 
+@pytest.mark.experiments
 def test_persistent_rollout_replays_from_a_graph(oracle):
     """The persistent launch (a cooperative launch behind the kernel that zeroes its barrier words) captured into the collector's
     HIP graphs, replayed five times — each of the two graphs at least twice — against the same collector shape launched eagerly:
@@ -239,6 +246,7 @@ def test_persistent_rollout_replays_from_a_graph(oracle):
     assert cols[0].episodes["count"] > 0 and cols[0].episodes["count"] == cols[1].episodes["count"]   # (checks the timeout flag too)
 
 
+@pytest.mark.experiments
 def test_persistent_rollout_gives_up_cleanly_when_a_grid_wait_times_out(oracle):
     """Every grid-wide wait of fpv_rollout_steps is bounded.  With the bound set to one tick (fpv_debug_rollout_timeout) the
     first wait is abandoned: the launch must still END — every workgroup leaves its step loop — with the status word set,

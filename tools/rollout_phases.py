@@ -9,6 +9,8 @@ import sys
 import numpy as np
 import torch
 
+if os.environ.get("SHAPE", "step") == "rollout":
+    os.environ.setdefault("FPV_EXPERIMENTS", "1")  # the persistent launch lives in libfpv_env_experiments.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import synthetic_states  # noqa: E402
 from fpv_drone_rl_agent_amd import _lib as L  # noqa: E402

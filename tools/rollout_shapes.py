@@ -8,6 +8,7 @@ import time
 import numpy as np
 import torch
 
+os.environ.setdefault("FPV_EXPERIMENTS", "1")     # the one-launch-per-rollout shape lives in libfpv_env_experiments.so
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import synthetic_states  # noqa: E402
 from fpv_drone_rl_agent_amd.engine import FpvEngine  # noqa: E402
