@@ -143,13 +143,13 @@ int main(int argc, char** argv) {
         vio.deterministic = 1; vio.nets = 2; vio.clip_obs = 10.f; vio.eps_norm = 1e-8f;
         CK(fpv_policy_forward(pol, &vio, s));
         CK(fpv_reward_finalize(T, n, raw_rew, snap, 10.f, 1e-8f, buf_rew, s));
-        CK(fpv_ledger_scan(env, snap, 44, T, 10.f, 1e-8f, tobs, t_idx, d_idx, cap, counters, sums, 1, s));
+        CK(fpv_ledger_scan(env, snap, 44, T, 10.f, 1e-8f, tobs, t_idx, d_idx, cap, counters, sums, 1, NULL, s));
         fpv_policy_io lio;
         memset(&lio, 0, sizeof lio);
         lio.n = cap; lio.obs = tobs; lio.value = tvals; lio.deterministic = 1; lio.nets = 2; lio.n_dev = counters;
         lio.clip_obs = 10.f; lio.eps_norm = 1e-8f;
-        CK(fpv_policy_forward(pol, &lio, s));
-        CK(fpv_ledger_scatter(counters, t_idx, d_idx, tvals, gamma, buf_rew, n, cap, s));
+        lio.scatter_t = t_idx; lio.scatter_d = d_idx; lio.scatter_out = buf_rew; lio.scatter_stride = n; lio.scatter_scale = gamma;
+        CK(fpv_policy_forward(pol, &lio, s));        /* r[t][d] += gamma * V(terminal observation), in the launch that evaluates V */
         CK(fpv_gae(T, n, buf_rew, buf_val, starts, last_val, starts + (size_t)T * n, gamma, lam, adv, ret, adv_stats, NULL, s));
         CK(fpv_advantage_stats(adv_stats, 1, 3, mean_std, s));
     }

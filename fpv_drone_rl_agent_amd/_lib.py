@@ -13,7 +13,7 @@ from .build import LIB_PATH, LIB_PATH_EXPERIMENTS, build_extension
 FPV_F32, FPV_F64 = 0, 1
 TASK_HOVER, TASK_YAW = 0, 1
 DETECTOR_PIXEL, DETECTOR_ANALYTIC = 0, 1   # fpv_detector: the reference's pixel rules are the default
-ABI_VERSION = 2                              # FPV_ABI_VERSION of include/fpv_env.h this binding was written against
+ABI_VERSION = 3                              # FPV_ABI_VERSION of include/fpv_env.h this binding was written against
 STATE_WORDS, OBS_WORDS, ACT_WORDS = 36, 20, 4
 INFO_TERMINATED, INFO_TRUNCATED, INFO_OUT_OF_BOUNDS, INFO_ON_FLOOR = 1, 2, 4, 8
 
@@ -63,6 +63,8 @@ class FpvPolicyIo(C.Structure):
         ("narrow", C.c_int32), ("reserved", C.c_int32),
         ("merge_partials", C.c_void_p), ("merge_rows", C.c_int64), ("merge_count", C.c_double), ("rms_out", C.c_void_p),
         ("ret_rms", C.c_void_p), ("ret_rms_out", C.c_void_p), ("merge_snapshot", C.c_void_p), ("n_dev", C.c_void_p),
+        ("scatter_t", C.c_void_p), ("scatter_d", C.c_void_p), ("scatter_out", C.c_void_p), ("scatter_stride", C.c_int64),
+        ("scatter_scale", C.c_float), ("reserved2", C.c_int32),
     ]
 
 
@@ -101,7 +103,7 @@ SIGNATURES = {
     "fpv_ledger_bind": (C.c_int, [_vp, C.POINTER(FpvLedger)]),
     "fpv_advantage_stats": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "fpv_rank_merge": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
-    "fpv_ledger_scan": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp]),
+    "fpv_ledger_scan": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp]),
     "fpv_ledger_scatter": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _vp, _i64, _i64, _vp]),
     "fpv_gae": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "fpv_normalize": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _i32, _f32, _f32, _vp]),

@@ -42,7 +42,7 @@ struct fpv_env {
     void* state;         // [tiles][9][64] granules
     void* tmpl;          // 56 reals
     uint64_t* tick;      // device [tiles]
-    uint32_t* merge_ticket;   // device counter of the in-launch statistics merge (zero between launches)
+    uint32_t* merge_ticket;   // 16 device words, zero between launches: [0] the in-launch statistics merge, [4] fpv_ledger_scan's last-workgroup ticket
     uint32_t* rollout_sync;   // barrier words of fpv_rollout_steps (zeroed on the stream before every launch)
     uint64_t* stamps;         // fpv_debug_rollout_stamps: diagnostic buffer of this handle's rollout kernels, or null
     uint64_t timeout_ticks;   // fpv_debug_rollout_timeout: 0 = the default bound of fpv_rollout_steps' grid-wide waits
@@ -461,14 +461,15 @@ int fpv_rank_merge(const double* gathered, int32_t world, int32_t stride, int32_
 
 int fpv_ledger_scan(fpv_env* e, const double* snapshots, int64_t snapshot_stride, int32_t T, float clip_obs, float eps_norm,
                     float* tobs, int32_t* t_idx, int32_t* d_idx, int64_t cap, int32_t* counters, double* sums,
-                    int32_t counters_are_zero, void* stream) {
+                    int32_t counters_are_zero, void* status_out, void* stream) {
     if (!e || !tobs || !t_idx || !d_idx || !counters || !sums || cap <= 0 || T <= 0)
         return fail(FPV_ERR_ARG, "fpv_ledger_scan: null argument, cap <= 0 or T <= 0");
     if (e->cfg.precision != FPV_F32) return fail(FPV_ERR_UNSUPPORTED, "fpv_ledger_scan: fp32 handles");
     if (snapshots && snapshot_stride < 2 * e->obs_words) return fail(FPV_ERR_ARG, "fpv_ledger_scan: snapshot rows hold {mean[O], var[O], ...}");
     FPV_HIP(launch_ledger_scan(e->led_count, e->led_idx, e->led_info, e->led_tag, (const float*)e->led_ret, (const float*)e->led_obs,
                                e->tick, e->tiles, (int)e->led_rows, e->obs_words, snapshots, snapshot_stride, T, clip_obs, eps_norm,
-                               tobs, t_idx, d_idx, cap, counters, sums, counters_are_zero != 0, (hipStream_t)stream));
+                               tobs, t_idx, d_idx, cap, counters, sums, counters_are_zero != 0, e->merge_ticket + 4, status_out,
+                               (hipStream_t)stream));
     return FPV_OK;
 }
 
@@ -608,16 +609,22 @@ int fpv_policy_forward(fpv_policy* p, const fpv_policy_io* io, void* stream) {
         mg = MergeArgs{io->merge_partials, io->ret_rms, io->rms ? io->rms_out : nullptr, io->ret_rms ? io->ret_rms_out : nullptr,
                        io->merge_snapshot, io->merge_count, (int32_t)io->merge_rows, p->in_dim};
     }
+    ScatterArgs sc{};
+    if (io->scatter_out) {
+        if (!(nets & 2) || !io->scatter_t || !io->scatter_d || io->scatter_stride <= 0)
+            return fail(FPV_ERR_ARG, "fpv_policy_forward: scatter needs the V net, scatter_t, scatter_d and a positive scatter_stride");
+        sc = ScatterArgs{io->scatter_t, io->scatter_d, io->scatter_out, io->scatter_stride, io->scatter_scale};
+    }
     // the bf16-split kernel evaluates both nets of the hover widths in 512-thread workgroups over a host-side row count;
     // any other request is served by the exact-fp32 kernel (its image is always packed)
-    if (p->gemm == 1 && p->in_dim == 20 && p->act_dim == 4 && nets == 3 && !io->narrow && !io->n_dev) {
+    if (p->gemm == 1 && p->in_dim == 20 && p->act_dim == 4 && nets == 3 && !io->narrow && !io->n_dev && !sc.out) {
         FPV_HIP(launch_policy_split_forward(p->split_image, io->obs, io->rms, io->eps_in, io->tick, io->obs_n, io->action,
                                             io->clipped, io->value, io->logp, io->eps_out, io->n, io->seed, io->id_offset,
                                             io->clip_obs, io->eps_norm, io->deterministic, p->cus, mg, (hipStream_t)stream));
         return FPV_OK;
     }
 #ifdef FPV_EXPERIMENTS
-    if (p->gemm == 2 && nets == 3 && !io->narrow && !mg.rows && !io->eps_in && !io->deterministic && !io->n_dev && p->in_dim <= 20) {
+    if (p->gemm == 2 && nets == 3 && !io->narrow && !mg.rows && !io->eps_in && !io->deterministic && !io->n_dev && !sc.out && p->in_dim <= 20) {
         // the rollout's launch shape (both nets, in-kernel sampling): 16-wave workgroups on 16x16x4 tiles
         FPV_HIP(launch_policy16_forward(p->image16, io->obs, io->rms, io->tick, io->obs_n, io->action, io->clipped, io->value,
                                         io->logp, io->eps_out, io->n, io->seed, io->id_offset, io->clip_obs, io->eps_norm,
@@ -630,7 +637,7 @@ int fpv_policy_forward(fpv_policy* p, const fpv_policy_io* io, void* stream) {
     FPV_HIP(launch_policy_forward(p->image, io->obs, io->rms, io->eps_in, io->tick, io->obs_n, io->action, io->clipped,
                                   io->value, io->logp, io->eps_out, io->n, io->seed, io->id_offset, io->clip_obs,
                                   io->eps_norm, io->deterministic, p->cus, nets, io->narrow ? 1 : 0, p->in_dim, p->act_dim, mg,
-                                  io->n_dev, (hipStream_t)stream));
+                                  io->n_dev, sc, (hipStream_t)stream));
     return FPV_OK;
 }
 
@@ -646,8 +653,8 @@ int fpv_rollout_step(fpv_env* e, fpv_policy* p, const fpv_policy_io* io, float* 
     if (p->in_dim != e->obs_words || p->act_dim != e->act_words || (p->gemm != 0 && !(p->gemm == 1 && !yaw)))
         return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: policy widths must be the task's (%d / %d), gemm mode 0 (or 1, the bf16 split, for the hover task)",
                     e->obs_words, e->act_words);
-    if (io->eps_in || io->eps_out || io->deterministic || io->narrow || io->n_dev || (io->nets != 0 && io->nets != 3))
-        return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: eps_in / eps_out / deterministic / narrow / n_dev / single nets are not served");
+    if (io->eps_in || io->eps_out || io->deterministic || io->narrow || io->n_dev || io->scatter_out || (io->nets != 0 && io->nets != 3))
+        return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: eps_in / eps_out / deterministic / narrow / n_dev / scatter / single nets are not served");
     if (ex && (ex->obs_rms || ex->ret_rms || ex->snapshot))
         return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: the statistics update rides in the next call's io->merge_* fields");
     if (((uintptr_t)io->obs | (uintptr_t)io->obs_n | (yaw ? 0 : ((uintptr_t)io->action | (uintptr_t)io->clipped))) & 15)

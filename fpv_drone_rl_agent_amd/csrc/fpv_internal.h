@@ -201,7 +201,7 @@ hipError_t launch_ledger_scan(const uint32_t* led_count, const int32_t* led_idx,
                               const float* led_ret, const float* led_obs, const uint64_t* tick, int64_t tiles, int rows,
                               int obs_words, const double* snapshots, int64_t stride, int T, float clip_obs, float eps,
                               float* tobs, int32_t* t_idx, int32_t* d_idx, int64_t cap, int32_t* counters, double* sums,
-                              bool counters_are_zero, hipStream_t s);
+                              bool counters_are_zero, uint32_t* ticket, void* status_out, hipStream_t s);
 hipError_t launch_ledger_scatter(const int32_t* counters, const int32_t* t_idx, const int32_t* d_idx, const float* v, float gamma,
                                  float* rewards, int64_t n, int64_t cap, hipStream_t s);
 
@@ -219,6 +219,13 @@ struct MergeArgs {
     double* snapshot;        // [kPartialWords] or null
     double batch_count;
     int32_t nrows, obs_words;   // rows of 2 O + 4 words (O = obs_words <= 20)
+};
+struct ScatterArgs {         // fpv_policy_io.scatter_*: out[t_idx[k] * stride + d_idx[k]] += scale * value[k]; out == null: none
+    const int32_t* t_idx;
+    const int32_t* d_idx;
+    float* out;
+    int64_t stride;
+    float scale;
 };
 constexpr int kPrologueMergeWays = 9;                                   // 9 x 44 = 396 threads of a 512-thread workgroup
 constexpr int kMergeLdsBytes = kPrologueMergeWays * kPartialWords * 8;   // 3 168 B of exchange space
@@ -312,7 +319,8 @@ hipError_t launch_policy_forward(const float* image, const float* obs, const dou
                                  const uint64_t* tick, float* obs_n, float* action, float* clipped, float* value,
                                  float* logp, float* eps_out, int64_t n, uint64_t seed, uint64_t id_offset,
                                  float clip_obs, float eps_norm, int deterministic, int max_blocks, int nets, int narrow,
-                                 int in_dim, int act_dim, const MergeArgs& merge, const int32_t* n_dev, hipStream_t s);
+                                 int in_dim, int act_dim, const MergeArgs& merge, const int32_t* n_dev, const ScatterArgs& sc,
+                                 hipStream_t s);
 int policy_image_floats();
 // fpv_policy_w16.hip
 hipError_t launch_policy16_pack(const float* const* w, float* image, int in_dim, int act_dim, hipStream_t s);

@@ -88,6 +88,11 @@ struct PolicyArgs {
     int32_t in_dim, act_dim;
     MergeArgs mg;            // mg.rows != null: fold the previous env step's tile sums into rms first (512 threads)
     const int32_t* n_dev;    // optional device-side row count: rows = min(n, *n_dev)
+    const int32_t* sc_t;     // optional: sc_out[sc_t[d] * sc_stride + sc_d[d]] += sc_scale * value[d] (fpv_policy_io.scatter_*)
+    const int32_t* sc_d;
+    float* sc_out;
+    int64_t sc_stride;
+    float sc_scale;
 };
 
 // THREADS = 512: two waves per SIMD (the stand-alone shape).  THREADS = 256: one wave per SIMD and <= 256 VGPRs of
@@ -248,7 +253,11 @@ __global__ __launch_bounds__(THREADS) void policy_forward_kernel(PolicyArgs p, i
         // ---- combine the two lane halves, add biases
 #pragma unroll
         for (int j = 0; j < 5; ++j) head[j] = half_sum(head[j]);
-        if (do_v && live && h == 1) p.value[d] = head[4] + hb[644];
+        if (do_v && live && h == 1) {
+            const float v = head[4] + hb[644];
+            p.value[d] = v;
+            if (p.sc_out) p.sc_out[(int64_t)p.sc_t[d] * p.sc_stride + p.sc_d[d]] += p.sc_scale * v;
+        }
         if (!do_pi) continue;
         const float mu[4] = {head[0] + hb[640], head[1] + hb[641], head[2] + hb[642], head[3] + hb[643]};
 
@@ -319,7 +328,8 @@ hipError_t launch_policy_forward(const float* image, const float* obs, const dou
                                  const uint64_t* tick, float* obs_n, float* action, float* clipped, float* value,
                                  float* logp, float* eps_out, int64_t n, uint64_t seed, uint64_t id_offset,
                                  float clip_obs, float eps_norm, int deterministic, int max_blocks, int nets, int narrow,
-                                 int in_dim, int act_dim, const MergeArgs& merge, const int32_t* n_dev, hipStream_t s) {
+                                 int in_dim, int act_dim, const MergeArgs& merge, const int32_t* n_dev, const ScatterArgs& sc,
+                                 hipStream_t s) {
     // nets: 3 = pi + V (one launch), 1 = pi only (with the sampling epilogue), 2 = V only.
     // narrow: 256-thread workgroups (one wave per SIMD) so that other kernels can co-reside.
     static bool attr_tab[64] = {};                    // hipFuncSetAttribute holds for one device: one flag per ordinal
@@ -340,7 +350,8 @@ hipError_t launch_policy_forward(const float* image, const float* obs, const dou
     const size_t lds_bytes = (size_t)(net_count * kNetFloats + (kImageFloats - kHeadBase) + 40) * sizeof(float) +
                              (merge.rows ? kMergeLdsBytes : 0);
     PolicyArgs p{image, obs, rms, eps_in, tick, obs_n, action, clipped, value, logp, eps_out,
-                 n, seed, id_offset, clip_obs, eps_norm, deterministic, in_dim, act_dim, merge, n_dev};
+                 n, seed, id_offset, clip_obs, eps_norm, deterministic, in_dim, act_dim, merge, n_dev,
+                 sc.t_idx, sc.d_idx, sc.out, sc.stride, sc.scale};
     const int threads = narrow ? 256 : 512, chunk = threads / 2;
     int64_t blocks = (n + chunk - 1) / chunk;
     if (blocks > max_blocks) blocks = max_blocks;

@@ -7,6 +7,7 @@
 // Semantics: SB3 RolloutBuffer.compute_returns_and_advantage and VecNormalize /
 // RunningMeanStd as used by simulation/train_hover.py:42-60.
 #include "fpv_internal.h"
+#include <type_traits>
 
 namespace fpv {
 
@@ -48,42 +49,55 @@ __global__ __launch_bounds__(kRedBlock) void gae_kernel(int64_t T, int64_t n, co
         float next_v = last_values[i];
         float next_nt = 1.0f - (float)last_dones[i];
         float last = 0.0f;
-        // the scan is a dependent chain, its inputs are not: four time steps' rows are requested before the first is used
-        // (a plain loop waits out one memory round trip per step); same operations in the same order
-        int64_t t = T - 1;
-        for (; t >= 3; t -= 4) {
-            float v4[4], r4[4];
-            uint8_t s4[4];
+        // The scan is a dependent chain, its inputs are not.  The rows of 16 time steps are requested as a block, and the next
+        // block's rows before the current block is worked through, so that a rollout of <= 32 steps waits out ONE memory round
+        // trip (a plain loop waits one per step: ~15 us for 32 steps at 65 536 drones, one wave per SIMD).  Same operations in
+        // the same order as the plain loop.
+        constexpr int Q = 16;
+        float vA[Q], rA[Q], vB[Q], rB[Q];
+        uint8_t sA[Q], sB[Q];
+        // (requests are unconditional — rows below 0 are clamped to row 0 and not used — so that no load sits under a branch:
+        // the compiler waits at every conditional load)
+        auto request = [&](float (&v_)[Q], float (&r_)[Q], uint8_t (&s_)[Q], int64_t t) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int64_t e = (t - q) * n + i;
-                v4[q] = values[e]; r4[q] = rewards[e]; s4[q] = starts[e];
+            for (int q = 0; q < Q; ++q) {
+                const int64_t e = (t - q > 0 ? t - q : 0) * n + i;
+                v_[q] = values[e]; r_[q] = rewards[e]; s_[q] = starts[e];
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int64_t e = (t - q) * n + i;
-                const float v = v4[q];
-                const float delta = r4[q] + gamma * next_v * next_nt - v;
-                last = delta + gamma * lam * next_nt * last;
-                adv[e] = last;
-                returns[e] = last + v;
-                s1 += (double)last;
-                s2 += (double)last * (double)last;
-                next_v = v;
-                next_nt = 1.0f - (float)s4[q];
-            }
-        }
-        for (; t >= 0; --t) {
-            const int64_t e = t * n + i;
-            const float v = values[e];
-            const float delta = rewards[e] + gamma * next_v * next_nt - v;
+        };
+        auto step = [&](float v, float r, uint8_t st, int64_t e) {
+            const float delta = r + gamma * next_v * next_nt - v;
             last = delta + gamma * lam * next_nt * last;
             adv[e] = last;
             returns[e] = last + v;
             s1 += (double)last;
             s2 += (double)last * (double)last;
             next_v = v;
-            next_nt = 1.0f - (float)starts[e];
+            next_nt = 1.0f - (float)st;
+        };
+        auto work = [&](const float (&v_)[Q], const float (&r_)[Q], const uint8_t (&s_)[Q], int64_t t, int cnt) {
+            if (cnt == Q) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) step(v_[q], r_[q], s_[q], (t - q) * n + i);
+            } else {
+#pragma unroll
+                for (int q = 0; q < Q; ++q)
+                    if (q < cnt) step(v_[q], r_[q], s_[q], (t - q) * n + i);
+            }
+        };
+        int64_t t = T - 1;
+        int cnt = t + 1 < Q ? (int)(t + 1) : Q;
+        request(vA, rA, sA, t);
+        while (cnt > 0) {
+            int64_t tn = t - cnt;
+            int cn = tn + 1 < Q ? (int)(tn + 1) : Q;
+            if (cn > 0) request(vB, rB, sB, tn);
+            work(vA, rA, sA, t, cnt);
+            if (cn <= 0) break;
+            t = tn - cn;
+            cnt = t + 1 < Q ? (int)(t + 1) : Q;
+            if (cnt > 0) request(vA, rA, sA, t);
+            work(vB, rB, sB, tn, cn);
         }
     }
     if (partial) {
@@ -508,6 +522,9 @@ struct LedgerScanArgs {
     int32_t* d_idx;           // [cap]
     int32_t* counters;        // {K, valid rows, episodes (incl. overflowed), flags: 1 ledger overflow, 2 tag outside rollout, 4 list overflow}
     double* sums;             // {sum ep_return, sum ep_len}
+    uint32_t* ticket;         // per-handle device word, zero between launches (used when status_out is given)
+    void* status_out;         // optional, 32 bytes {counters[4], sums[2]} as they stand when every workgroup has added its share;
+                              // may be host memory the device can write (pinned): the host then needs no copy behind the launch
 };
 
 // Each workgroup walks kScanPerThread x 256 consecutive slots and adds its statistics with ONE set of atomics (an
@@ -613,6 +630,24 @@ __global__ __launch_bounds__(256) void ledger_scan_kernel(LedgerScanArgs a) {
         if (nv) { atomicAdd(&a.counters[1], nv); atomicAdd(&a.sums[0], sr); atomicAdd(&a.sums[1], sl); }
         if (episodes) atomicAdd(&a.counters[2], episodes);
         if (flags) atomicOr(&a.counters[3], flags);
+        if (a.status_out) {
+            // The workgroup that draws the last ticket sees every other workgroup's additions (each fenced its own before taking
+            // a ticket) and publishes the totals with system-scope stores: a D2H copy node behind the rollout's graph stood
+            // ~20 us between one rollout's last kernel and the next one's first (profiles/r03_rollout_boundary.md).
+            __threadfence();
+            const unsigned tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (tk == gridDim.x - 1u) {
+                int32_t* oi = reinterpret_cast<int32_t*>(a.status_out);
+                double* od = reinterpret_cast<double*>(a.status_out) + 2;
+                for (int k = 0; k < 4; ++k)
+                    __hip_atomic_store(oi + k, __hip_atomic_load(a.counters + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                for (int k = 0; k < 2; ++k)
+                    __hip_atomic_store(od + k, __hip_atomic_load(a.sums + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 
@@ -629,14 +664,14 @@ hipError_t launch_ledger_scan(const uint32_t* led_count, const int32_t* led_idx,
                               const float* led_ret, const float* led_obs, const uint64_t* tick, int64_t tiles, int rows,
                               int obs_words, const double* snapshots, int64_t stride, int T, float clip_obs, float eps,
                               float* tobs, int32_t* t_idx, int32_t* d_idx, int64_t cap, int32_t* counters, double* sums,
-                              bool counters_are_zero, hipStream_t s) {
+                              bool counters_are_zero, uint32_t* ticket, void* status_out, hipStream_t s) {
     // zeroed by a kernel — this one, unless the rollout's fpv_rollout_begin has done it — never by hipMemsetAsync: a memset node
     // in a captured graph may write garbage from the graph's second replay on (profiles/r03_graph_memset_probe.json)
     if (!counters_are_zero)
         hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<uint32_t*>(counters), (int64_t)4,
                            reinterpret_cast<uint32_t*>(sums), (int64_t)4);
     LedgerScanArgs a{led_count, led_idx, led_info, led_tag, led_ret, led_obs, tick, snapshots, tiles, stride, cap,
-                     rows, T, obs_words, 0, clip_obs, eps, tobs, t_idx, d_idx, counters, sums};
+                     rows, T, obs_words, 0, clip_obs, eps, tobs, t_idx, d_idx, counters, sums, ticket, status_out};
     const int64_t slots = tiles * rows, per_block = 256 * kScanPerThread;
     if (slots >= (1ll << 31)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(ledger_scan_kernel, dim3((unsigned)((slots + per_block - 1) / per_block)), dim3(256), 0, s, a);

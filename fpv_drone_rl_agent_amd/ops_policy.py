@@ -69,12 +69,14 @@ class FusedPolicy:
 
     def forward(self, obs, *, rms=None, eps_in=None, tick=None, obs_n=None, action=None, clipped=None, value=None,
                 logp=None, eps_out=None, clip_obs: float = 10.0, eps_norm: float = 1e-8, deterministic: bool = False,
-                nets: str = "both", narrow: bool = False, merge: dict | None = None, n_dev=None):
+                nets: str = "both", narrow: bool = False, merge: dict | None = None, n_dev=None, scatter: dict | None = None):
         """obs [n,20] fp32 raw observations; rms = fp64[41] VecNormalize statistics or None.  Output tensors
         are written in place when given; value is always produced.  Returns dict of the outputs.
         merge = {partials [rows,44] f64, count, rms_out, ret_rms, ret_rms_out, snapshot}: fold the previous
         fpv_step_fused's tile sums into the statistics in this launch (rms / ret_rms are read, *_out written).
-        n_dev: int32 device scalar; only the first min(n, n_dev) rows are evaluated."""
+        n_dev: int32 device scalar; only the first min(n, n_dev) rows are evaluated.
+        scatter = {t_idx int32[n], d_idx int32[n], out fp32 [T][stride], scale}: out[t_idx[k], d_idx[k]] += scale * value[k] for the
+        evaluated rows, in this launch (ops.ledger_scatter without its own)."""
         n = obs.shape[0]
         if narrow:
             L.require_experiments("narrow=True (256-thread policy launches)")
@@ -87,6 +89,14 @@ class FusedPolicy:
                            _ptr(value), _ptr(logp), _ptr(eps_out), self.seed, self.id_offset, float(clip_obs),
                            float(eps_norm), 1 if deterministic else 0, mask, 1 if narrow else 0, 0)
         io.n_dev = _ptr(n_dev)
+        if scatter is not None:
+            out = scatter["out"]
+            if out.dtype != torch.float32 or out.dim() != 2 or not out.is_contiguous() or not mask & 2:
+                raise ValueError("scatter: out is a contiguous fp32 [T][n] table and the V net must be evaluated")
+            if scatter["t_idx"].dtype != torch.int32 or scatter["d_idx"].dtype != torch.int32 or min(scatter["t_idx"].numel(), scatter["d_idx"].numel()) < n:
+                raise ValueError("scatter: t_idx / d_idx are int32 with one entry per row")
+            io.scatter_t, io.scatter_d, io.scatter_out = _ptr(scatter["t_idx"]), _ptr(scatter["d_idx"]), _ptr(out)
+            io.scatter_stride, io.scatter_scale = out.shape[1], float(scatter["scale"])
         if merge is not None:
             io.merge_partials, io.merge_rows = _ptr(merge["partials"]), merge["partials"].shape[0]
             io.merge_count = float(merge["count"])

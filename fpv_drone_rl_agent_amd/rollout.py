@@ -29,6 +29,7 @@ Two step implementations:
 from __future__ import annotations
 
 import os
+import struct
 
 import torch
 
@@ -175,6 +176,7 @@ class RolloutCollector:
             self._rs_status_k = [t[4:5].view(torch.int32)[0:1] for t in self._post]
             self._led_sums_k = [t[2:4] for t in self._post]
             self._status_host = [torch.zeros((8,), dtype=torch.float64).pin_memory() for _ in range(2)]
+            self._status_np = [t.numpy() for t in self._status_host]      # the same pinned words
             self._status_event = [torch.cuda.Event() for _ in range(2)]
             self._status_pending = [False, False]
         # the collective and the advantage statistics run on a side stream: nothing on the main stream waits for them
@@ -389,6 +391,8 @@ class RolloutCollector:
                      "ret_rms_out": self.rew_norm.rms if self.norm_reward else None, "snapshot": self.snap[merge_step]}
             self.fp.forward(eng.obs, rms=o_in, obs_n=self.cur_obs, value=self.last_val, deterministic=True, nets="v",
                             clip_obs=self.obs_norm.clip, eps_norm=self.obs_norm.eps, merge=merge)
+        # (V(s_T) beside the chain below on a second captured stream was measured: 70.7 vs 69.3 us per step with one 20-step
+        # rollout per timed region — each fork / join edge of the graph costs 4-12 us, more than the overlap returns)
         if self.fused:
             if self.norm_reward:
                 ops.reward_finalize(self.raw_rew, self.snap, clip=self.rew_norm.clip, eps=self.rew_norm.eps, out=self.buf_rew)
@@ -396,9 +400,11 @@ class RolloutCollector:
                 self.buf_rew.copy_(self.raw_rew)
         ops.ledger_scan(eng, self.T, snapshots=self.snap if self.norm_obs else None, clip_obs=self.obs_norm.clip,
                         eps=self.obs_norm.eps, tobs=self._tobs, t_idx=self._t_idx, d_idx=self._d_idx,
-                        counters=self._led_counters, sums=self._led_sums, prezeroed=self._scan_prezeroed)
-        self.fp.forward(self._tobs, value=self._tv, deterministic=True, nets="v", n_dev=self._led_counters[0:1])
-        ops.ledger_scatter(self._led_counters, self._t_idx, self._d_idx, self._tv, self.gamma, self.buf_rew)
+                        counters=self._led_counters, sums=self._led_sums, prezeroed=self._scan_prezeroed,
+                        status_out=None if self._persistent else self._status_host[self._slot])   # straight into pinned host memory
+        # V(terminal observations) and r_t += gamma * V in one launch (fpv_policy_io.scatter_*; ops.ledger_scatter is that as a launch)
+        self.fp.forward(self._tobs, value=self._tv, deterministic=True, nets="v", n_dev=self._led_counters[0:1],
+                        scatter={"t_idx": self._t_idx, "d_idx": self._d_idx, "out": self.buf_rew, "scale": self.gamma})
         # one rank: the advantage mean / std come out of the GAE launch itself (with several ranks: after the all-gather)
         ops.gae(self.buf_rew, self.buf_val, self.buf_start, self.last_val, self.episode_start, self.gamma,
                 self.lam, advantages=self.adv, returns=self.ret, stats=self.stats,
@@ -484,7 +490,10 @@ class RolloutCollector:
         if self.use_graph and self._graph is None:
             self._capture()
         if self.fused_policy:
-            self._check_status(k)           # what this slot still holds is two rollouts old: no stall
+            # What this slot's status words still hold is two rollouts old (no stall).  They are taken off the pinned words before
+            # the launch — the rollout about to start overwrites them at its end — and turned into numbers / exceptions after it:
+            # host work ahead of the launch is time the device sits idle when a caller synchronises after every rollout.
+            raw = self._fetch_status(k)
             if self._persistent and self._rollouts:
                 # the persistent launch wants the whole device: let the previous rollout's collective finish first
                 main.wait_event(self._stats_done[self._stats_last])
@@ -492,6 +501,7 @@ class RolloutCollector:
                 self._graph.replay()
             else:
                 self._all_steps()
+            self._parse_status(raw)
         else:
             eng.ledger_clear()
             self._all_steps()
@@ -512,7 +522,11 @@ class RolloutCollector:
             if post is not main:
                 post.wait_event(self._stats_ready[k])
             if self.fused_policy:
-                self._status_host[k].copy_(self._post[k][0:8], non_blocking=True)
+                # the ledger scan has written the episode statistics / overflow flags into the pinned host words itself: a copy
+                # node here stood ~20 us between this rollout's last kernel and the next one's first.  (The persistent launch of
+                # the experiments library has one more status word, on the device: it keeps the copy.)
+                if self._persistent:
+                    self._status_host[k].copy_(self._post[k][0:8], non_blocking=True)
                 self._status_event[k].record(post)
                 self._status_pending[k] = True
             if not (self.fused_policy and D.world_size() == 1):     # (one rank, fused tail: fpv_gae has written mean / std already)
@@ -547,15 +561,23 @@ class RolloutCollector:
         self.wait_stats()
         return self._adv_ms[self._stats_last][1]
 
-    def _check_status(self, slot: int) -> None:
-        """Wait for the status words copied out after an earlier rollout and turn its flags into exceptions."""
+    def _fetch_status(self, slot: int):
+        """Wait for the rollout that last used this slot and take its status words (None when they were taken already)."""
         if not self._status_pending[slot]:
-            return
+            return None
         self._status_event[slot].synchronize()
         self._status_pending[slot] = False
-        host = self._status_host[slot]
-        k, valid, episodes, flags = (int(x) for x in host[:2].view(torch.int32))
-        if int(host[4:5].view(torch.int32)[0]) != 0:
+        return self._status_np[slot].tobytes()
+
+    def _check_status(self, slot: int) -> None:
+        """Wait for the status words written at the end of an earlier rollout and turn its flags into exceptions."""
+        self._parse_status(self._fetch_status(slot))
+
+    def _parse_status(self, raw) -> None:
+        if raw is None:
+            return
+        k, valid, episodes, flags, sum_ret, sum_len, timed_out = struct.unpack_from("<4i2di", raw)
+        if timed_out != 0:
             raise RuntimeError("persistent rollout: a grid-wide wait timed out (not every workgroup was resident, or the device "
                                "was shared); this rollout is invalid — use RolloutCollector(persistent=False)")
         if flags & 1:
@@ -566,10 +588,9 @@ class RolloutCollector:
             raise RuntimeError("done-ledger tag outside this rollout: tick bookkeeping is out of sync")
         if flags & 4:
             raise RuntimeError("more truncated episodes in one rollout than drones x ceil(T / 401): ledger inconsistent")
-        sums = host[2:4]
         self._episodes_host = {"count": episodes, "truncated": k,
-                               "ep_rew_mean": float(sums[0]) / valid if valid else float("nan"),
-                               "ep_len_mean": float(sums[1]) / valid if valid else float("nan")}
+                               "ep_rew_mean": sum_ret / valid if valid else float("nan"),
+                               "ep_len_mean": sum_len / valid if valid else float("nan")}
 
     @property
     def episodes(self) -> dict:

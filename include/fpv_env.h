@@ -29,7 +29,7 @@ extern "C" {
  * compares the two before its first call (fpv_step_extras grew and fpv_detector was renumbered between 1 and 2, so a host
  * built against another header would pass structs of another size).  History: 1 = rounds 1-2; 2 = round 3
  * (FPV_DETECTOR_PIXEL = 0 is the default, debug hooks moved to fpv_env_debug.h). */
-#define FPV_ABI_VERSION 2
+#define FPV_ABI_VERSION 3
 
 #define FPV_STATE_WORDS 36 /* docs/SPEC.md §2 canonical order */
 #define FPV_OBS_WORDS 20   /* simulation/hover.py:63-70 */
@@ -266,10 +266,14 @@ int fpv_rank_merge(const double* gathered, int32_t world, int32_t stride, int32_
  * (terminal observation, normalised with snapshots[t_idx[k]] = {mean[O], var[O], ...} when snapshots != NULL).
  * The value net then runs over tobs with fpv_policy_io.n_dev = &counters[0], and fpv_ledger_scatter adds
  * gamma * values[k] to rewards[t_idx[k]][d_idx[k]] ([T][n]).  The list order is arbitrary, the result is not.
- * counters_are_zero != 0: counters / sums were zeroed by this rollout's fpv_rollout_begin (else a small launch zeroes them here). */
+ * counters_are_zero != 0: counters / sums were zeroed by this rollout's fpv_rollout_begin (else a small launch zeroes them here).
+ * status_out (optional, 32 bytes, 8-byte aligned): receives {counters[4], sums[2]} as they stand at the end of the launch, written
+ * by the workgroup that finishes last with system-scope stores — so it may be pinned HOST memory that the device can address
+ * (hipHostMalloc / a pinned torch tensor): the host reads the episode statistics and the overflow flags after waiting for the
+ * launch, with no device-to-host copy queued behind the rollout. */
 int fpv_ledger_scan(fpv_env* env, const double* snapshots, int64_t snapshot_stride, int32_t T, float clip_obs, float eps_norm,
                     float* tobs, int32_t* t_idx, int32_t* d_idx, int64_t cap, int32_t* counters, double* sums,
-                    int32_t counters_are_zero, void* stream);
+                    int32_t counters_are_zero, void* status_out, void* stream);
 int fpv_ledger_scatter(const int32_t* counters, const int32_t* t_idx, const int32_t* d_idx, const float* values, float gamma,
                        float* rewards, int64_t n, int64_t cap, void* stream);
 
@@ -323,6 +327,15 @@ typedef struct {
     double* ret_rms_out;     /* [3] */
     double* merge_snapshot;  /* [FPV_PARTIAL_WORDS] or NULL */
     const int32_t* n_dev;    /* optional DEVICE row count: rows = min(n, *n_dev) (lists whose length only the device knows) */
+    /* Optional scatter of the values (V evaluated; NULL to skip): scatter_out[scatter_t[k] * scatter_stride + scatter_d[k]] +=
+     * scatter_scale * value[k] for every evaluated row k — fpv_ledger_scatter in the launch that produces the values (the timeout
+     * bootstrap: t_idx / d_idx of fpv_ledger_scan, the [T][n] reward table, gamma).  Every (t, d) pair must be distinct. */
+    const int32_t* scatter_t;
+    const int32_t* scatter_d;
+    float* scatter_out;
+    int64_t scatter_stride;
+    float scatter_scale;
+    int32_t reserved2;
 } fpv_policy_io;
 
 int fpv_policy_forward(fpv_policy* pol, const fpv_policy_io* io, void* stream);

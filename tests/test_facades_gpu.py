@@ -223,11 +223,30 @@ def test_ledger_scan_and_scatter_match_a_torch_restatement(oracle):
     tobs = torch.zeros((cap, 20), device="cuda"); t_idx = torch.zeros(cap, dtype=torch.int32, device="cuda")
     d_idx = torch.zeros(cap, dtype=torch.int32, device="cuda"); tv = torch.zeros(cap, device="cuda")
     counters = torch.full((4,), 77, dtype=torch.int32, device="cuda"); sums = torch.full((2,), 5.0, dtype=torch.float64, device="cuda")
-    ops.ledger_scan(eng, T, snapshots=snap, clip_obs=10.0, eps=1e-8, tobs=tobs, t_idx=t_idx, d_idx=d_idx, counters=counters, sums=sums)
+    # status_out: the same totals written by the scan's last workgroup straight into pinned host memory (and, second call, into
+    # device memory), no copy queued; the ticket it takes resets itself, so the launch repeats
+    host = torch.full((4,), -1.0, dtype=torch.float64).pin_memory()
+    ops.ledger_scan(eng, T, snapshots=snap, clip_obs=10.0, eps=1e-8, tobs=tobs, t_idx=t_idx, d_idx=d_idx, counters=counters, sums=sums,
+                    status_out=host)
+    torch.cuda.synchronize()
+    assert host[:2].view(torch.int32).tolist() == counters.tolist() and host[2:4].tolist() == sums.tolist() and int(counters[1]) > 0
+    dev_out = torch.zeros(4, dtype=torch.float64, device="cuda")
+    ops.ledger_scan(eng, T, snapshots=snap, clip_obs=10.0, eps=1e-8, tobs=tobs, t_idx=t_idx, d_idx=d_idx, counters=counters, sums=sums,
+                    status_out=dev_out)
+    torch.cuda.synchronize()
+    assert torch.equal(dev_out.cpu(), host)
+    with pytest.raises(ValueError, match="pinned"):
+        ops.ledger_scan(eng, T, snapshots=snap, clip_obs=10.0, eps=1e-8, tobs=tobs, t_idx=t_idx, d_idx=d_idx, counters=counters,
+                        sums=sums, status_out=torch.zeros(4, dtype=torch.float64))
     fp.forward(tobs, value=tv, deterministic=True, nets="v", n_dev=counters[0:1])
     rew = torch.zeros((T, n), device="cuda")
     ops.ledger_scatter(counters, t_idx, d_idx, tv, gamma, rew)
+    # the same addition inside the launch that evaluates V (fpv_policy_io.scatter_*): what the collector's tail uses
+    rew_in, tv_in = torch.zeros((T, n), device="cuda"), torch.zeros(cap, device="cuda")
+    fp.forward(tobs, value=tv_in, deterministic=True, nets="v", n_dev=counters[0:1],
+               scatter={"t_idx": t_idx, "d_idx": d_idx, "out": rew_in, "scale": gamma})
     torch.cuda.synchronize()
+    assert torch.equal(tv_in, tv) and torch.equal(rew_in, rew) and int((rew != 0).sum()) == int(counters[0])
     info, tag, idx = led["info"], led["tag"], led["idx"]
     mask = ((info & 2) != 0) & ((info & 1) == 0)
     k, valid, episodes, flags = counters.tolist()
