@@ -187,6 +187,7 @@ class RolloutCollector:
         self._adv_ms = [torch.zeros((2,), dtype=torch.float64, device=dev) for _ in range(2)]
         self._stats_ready = [torch.cuda.Event() for _ in range(2)]
         self._stats_done = [torch.cuda.Event() for _ in range(2)]
+        self._done_stream = [None, None]                 # the stream each _stats_done was last recorded on
         self._stats_last = 0
         # several ranks: VecNormalize's statistics ride in the same payload ({adv stats[3], obs_rms[2 O + 1], ret_rms[3]}); every
         # rank starts a rollout from the statistics of the union of all ranks' samples so far (fpv_rank_merge) — kept here as the base
@@ -478,7 +479,8 @@ class RolloutCollector:
         eng = self.engine
         k = self._slot = self._rollouts % 2
         main = torch.cuda.current_stream(self.device)
-        main.wait_event(self._stats_done[k])                # this slot's words were last read two rollouts ago: no stall
+        if self._done_stream[k] is not None and self._done_stream[k] != main:
+            main.wait_event(self._stats_done[k])            # this slot's words were last read two rollouts ago: no stall
         multi = D.world_size() > 1 and (self.norm_obs or self.norm_reward)
         if multi:
             # the previous rollout's merged statistics are written by the side stream: this rollout starts from them, and they
@@ -511,15 +513,17 @@ class RolloutCollector:
             ops.gae(self.buf_rew, self.buf_val, self.buf_start, self.last_val, self.episode_start, self.gamma,
                     self.lam, advantages=self.adv, returns=self.ret, stats=self.stats)
         self._rollouts += 1
-        self._stats_ready[k].record(main)                   # the rollout is complete on the main stream here
         # What follows the rollout reads this slot's words where the rollout left them.  Several ranks: on the side stream, so
         # that the main stream never waits for the collective.  One rank: there is no collective, and handing the two tiny
         # operations to another stream costs more in cross-stream event latency than they take (measured at 65 536 drones:
         # 65.6 vs 67.0 us per step with one 20-step rollout per timed region, 63.0 vs 63.6 in steady state), so they follow
         # the rollout on the main stream (FPV_POST_STREAM=side restores the side stream).
+        # Every event recorded between two graph launches is a packet the second launch queues behind: on one stream the rollout
+        # needs exactly one (the host waits on it for the status words), where it used to record three.
         post = self._side if (D.world_size() > 1 or os.environ.get("FPV_POST_STREAM", "") == "side") else main
         with torch.cuda.stream(post):
             if post is not main:
+                self._stats_ready[k].record(main)           # the rollout is complete on the main stream here
                 post.wait_event(self._stats_ready[k])
             if self.fused_policy:
                 # the ledger scan has written the episode statistics / overflow flags into the pinned host words itself: a copy
@@ -527,7 +531,7 @@ class RolloutCollector:
                 # the experiments library has one more status word, on the device: it keeps the copy.)
                 if self._persistent:
                     self._status_host[k].copy_(self._post[k][0:8], non_blocking=True)
-                self._status_event[k].record(post)
+                self._status_event[k].record(post)          # (the one event left costs ~0.2 us per step at 32-step rollouts)
                 self._status_pending[k] = True
             if not (self.fused_policy and D.world_size() == 1):     # (one rank, fused tail: fpv_gae has written mean / std already)
                 payload = self._stats_k[k]
@@ -540,7 +544,11 @@ class RolloutCollector:
                                    base_ret_rms=self._base_ret_rms if self.norm_reward else None,
                                    obs_rms=self.obs_norm.rms if self.norm_obs else None,
                                    ret_rms=self.rew_norm.rms if self.norm_reward else None)
-            self._stats_done[k].record(post)
+            if post is main and self.fused_policy:
+                self._stats_done[k] = self._status_event[k]     # recorded just above, at this point of this stream
+            else:
+                self._stats_done[k].record(post)
+        self._done_stream[k] = post
         self._stats_last = k
         self._tick0 += self.T
         return _Batch(self, {"obs": self.buf_obs, "actions": self.buf_act, "values": self.buf_val, "log_probs": self.buf_logp,
@@ -549,7 +557,9 @@ class RolloutCollector:
 
     def wait_stats(self) -> None:
         """Order the current stream after the collective + advantage statistics of the last collect()."""
-        torch.cuda.current_stream(self.device).wait_event(self._stats_done[self._stats_last])
+        cur = torch.cuda.current_stream(self.device)
+        if self._done_stream[self._stats_last] is not None and self._done_stream[self._stats_last] != cur:
+            cur.wait_event(self._stats_done[self._stats_last])      # (the same stream is ordered already)
 
     @property
     def adv_mean(self):
