@@ -462,8 +462,8 @@ int fpv_rank_merge(const double* gathered, int32_t world, int32_t stride, int32_
 int fpv_ledger_scan(fpv_env* e, const double* snapshots, int64_t snapshot_stride, int32_t T, float clip_obs, float eps_norm,
                     float* tobs, int32_t* t_idx, int32_t* d_idx, int64_t cap, int32_t* counters, double* sums,
                     int32_t counters_are_zero, void* status_out, void* stream) {
-    if (!e || !tobs || !t_idx || !d_idx || !counters || !sums || cap <= 0 || T <= 0)
-        return fail(FPV_ERR_ARG, "fpv_ledger_scan: null argument, cap <= 0 or T <= 0");
+    if (!e || !tobs || !t_idx || !d_idx || !counters || !sums || cap <= 0 || T <= 0 || T > 65535)
+        return fail(FPV_ERR_ARG, "fpv_ledger_scan: null argument, cap <= 0 or T outside 1..65535");
     if (e->cfg.precision != FPV_F32) return fail(FPV_ERR_UNSUPPORTED, "fpv_ledger_scan: fp32 handles");
     if (snapshots && snapshot_stride < 2 * e->obs_words) return fail(FPV_ERR_ARG, "fpv_ledger_scan: snapshot rows hold {mean[O], var[O], ...}");
     FPV_HIP(launch_ledger_scan(e->led_count, e->led_idx, e->led_info, e->led_tag, (const float*)e->led_ret, (const float*)e->led_obs,

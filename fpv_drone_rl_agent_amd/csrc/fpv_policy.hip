@@ -159,18 +159,26 @@ __global__ __launch_bounds__(THREADS) void policy_forward_kernel(PolicyArgs p, i
     constexpr int kChunk = THREADS / 2;              // 32 drones per wave
 
     int64_t rows = p.n;
+    int chunk = kChunk;                              // rows per workgroup and pass: 32 per wave
     if (p.n_dev) {
+        // A list whose length only the device knows (the truncated episodes of a rollout) is usually short.  A workgroup takes as
+        // long for 256 rows as the whole grid for 256 each, so the rows are spread: 32 per wave, and only as many waves per
+        // workgroup as it takes to cover the list with the whole grid (3 300 rows at 65 536 yaw drones: 24 -> 9 us).
         const int64_t nd = *p.n_dev;
         rows = nd < rows ? (nd > 0 ? nd : 0) : rows;
+        const int64_t waves = (rows + 32 * (int64_t)gridDim.x - 1) / (32 * (int64_t)gridDim.x);
+        const int wu = waves < 1 ? 1 : (waves > THREADS / 64 ? THREADS / 64 : (int)waves);
+        if (wave >= wu) return;                      // (no workgroup barrier from here on)
+        chunk = 32 * wu;
     }
-    for (int64_t base = (int64_t)blockIdx.x * kChunk; base < rows; base += (int64_t)gridDim.x * kChunk) {
+    for (int64_t base = (int64_t)blockIdx.x * chunk; base < rows; base += (int64_t)gridDim.x * chunk) {
         const int64_t d = base + wave * 32 + col;   // this lane's drone (both halves of the wave share it)
         const bool live = d < rows;
         // ---- observation: half h of the wave holds words k = half * h + j, j < half (10 + 10 for the hover row)
         float x[12];
         {
             const f32x2* row = reinterpret_cast<const f32x2*>(p.obs + (live ? d : 0) * p.in_dim + half * h);
-            const bool first_chunk = base == (int64_t)blockIdx.x * kChunk;     // its rows were requested before the staging
+            const bool first_chunk = !p.n_dev && base == (int64_t)blockIdx.x * kChunk;   // its rows were requested before the staging
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
                 const bool have = live && 2 * q < half;
