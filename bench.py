@@ -398,7 +398,12 @@ def main() -> None:
         else:
             us_plain = timed(lambda: eng.step(act))
             env_bytes = 458 if yaw else ALG_BYTES_PER_STEP
-            roofline_env_plain = hbm("fpv::yaw_step_kernel<float,true>" if yaw else "fpv::step_kernel<float,true,false>", us_plain, env_bytes)
+            # launch_step's dispatch (csrc/fpv_step.hip): pixel-detector handles of 8 192 < n <= 65 536 drones step through
+            # step_quad_kernel (physics + helper wave per tile, the phase 2 of the rollout-step kernel as a launch of its own)
+            quad = not yaw and args.detector == "pixel" and 8192 < n <= 65536 and n % 256 == 0
+            k_plain = "fpv::step_quad_kernel" if quad else "fpv::step_kernel<float,true,false>"
+            k_fused = "fpv::step_quad_kernel" if quad else "fpv::step_kernel<float,true,true>"
+            roofline_env_plain = hbm("fpv::yaw_step_kernel<float,true>" if yaw else k_plain, us_plain, env_bytes)
             if not yaw:
                 roofline_env_plain["detector"] = args.detector
                 if args.detector == "pixel" and world == 1:
@@ -486,7 +491,7 @@ def main() -> None:
                                         "note": "duration of the phase only; no bandwidth fraction is claimed for it (its state loads were "
                                                 "issued under the policy phase) — see roofline_hbm_whole_kernel and "
                                                 "roofline_env_step_unfused for HBM figures"}
-                roofline_env_fused = hbm("fpv::yaw_step_kernel<float,true,true>" if yaw else "fpv::step_kernel<float,true,true>", ev_fused, env_bytes)
+                roofline_env_fused = hbm("fpv::yaw_step_kernel<float,true,true>" if yaw else k_fused, ev_fused, env_bytes)
                 roofline_env_fused.update(measured="HIP events around back-to-back launches (the stand-alone fpv_step_fused kernel; "
                                                    "not launched by the default rollout)")
             elif col.fused:
@@ -498,12 +503,12 @@ def main() -> None:
                 in_graph = graph_kernel_times()
                 us_pol = pick(in_graph, "policy_forward_kernel", at_least=0.75 * ev_pol) or ev_pol
                 us_pol_all = pick(in_graph, "policy_forward_kernel")     # what a per-symbol profiler average shows
-                us_fused = pick(in_graph, "step_kernel<float,true,true") or ev_fused
+                us_fused = pick(in_graph, "step_quad_kernel" if quad else "step_kernel<float,true,true") or ev_fused
                 if not (0.6 * ev_pol < us_pol < 1.6 * ev_pol and 0.6 * ev_fused < us_fused < 1.6 * ev_fused):
                     in_graph, us_pol, us_fused = {}, ev_pol, ev_fused     # tracer output implausible: trust the events
                 how = "device timestamps of the launches inside the replayed rollout graph" if in_graph else \
                       "HIP events around back-to-back launches"
-                roofline_env = hbm("fpv::step_kernel<float,true,true>", us_fused, ALG_BYTES_PER_STEP)
+                roofline_env = hbm(k_fused, us_fused, ALG_BYTES_PER_STEP)
                 roofline_env.update(measured=how, us_per_launch_hip_events_back_to_back=round(ev_fused, 2))
                 tf = POLICY_FLOP_PER_ROW * n / us_pol / 1e6
                 roofline = {"bound": "mfma", "kernel": "fpv::policy_forward_kernel", "achieved": round(tf, 1),

@@ -128,6 +128,7 @@ EXPERIMENT_SIGNATURES = {
 # include/fpv_env_debug.h: diagnostic hooks (tools/, bench.py's phase report, tests) — not the product interface
 DEBUG_SIGNATURES = {
     "fpv_set_pair_threshold": (C.c_int, [_i64]),
+    "fpv_set_quad_range": (C.c_int, [_i64, _i64]),
     "fpv_noop": (C.c_int, [_vp]),
     "fpv_debug_rollout_stamps": (C.c_int, [_vp, _vp]),
     "fpv_debug_rollout_timeout": (C.c_int, [_vp, _u64]),

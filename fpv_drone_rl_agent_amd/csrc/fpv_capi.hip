@@ -124,7 +124,7 @@ static int step_impl(fpv_env* e, const T* actions, T* obs, T* reward, uint8_t* t
     if (want_merge && !merged) {
         // launch shapes without the in-kernel reducer (one tile per workgroup, the wave-pair kernel): the merge kernel
         int64_t rows = e->cfg.task == FPV_TASK_YAW ? yaw_partial_rows(e->cfg.num_envs)
-                                                   : step_partial_rows(e->cfg.num_envs, e->cfg.noise_ratio != 0.0);
+                                                   : step_partial_rows(e->cfg.num_envs, e->cfg.noise_ratio != 0.0, e->cfg.detector == FPV_DETECTOR_PIXEL);
         double* scratch = nullptr;
         if (int rc = scratch_for_current_device(&scratch)) return rc;
         FPV_HIP(launch_moments_merge_tiles(rows, ex->partials, (double)e->cfg.num_envs, nullptr, nullptr, ex->obs_rms, ex->ret_rms,
@@ -141,6 +141,12 @@ extern "C" {
 
 int fpv_set_pair_threshold(int64_t max_drones) {
     fpv::g_pair_max_tiles = max_drones <= 0 ? 0 : (max_drones + kTile - 1) / kTile;
+    return FPV_OK;
+}
+
+int fpv_set_quad_range(int64_t min_drones, int64_t max_drones) {
+    fpv::g_quad_min_tiles = min_drones <= 0 ? 0 : (min_drones + kTile - 1) / kTile;
+    fpv::g_quad_max_tiles = max_drones <= 0 ? 0 : (max_drones + kTile - 1) / kTile;
     return FPV_OK;
 }
 
@@ -328,7 +334,7 @@ int fpv_partial_rows(fpv_env* e, int64_t* rows) {
     if (!e || !rows) return fail(FPV_ERR_ARG, "fpv_partial_rows: null argument");
     if (e->cfg.precision != 0) return fail(FPV_ERR_UNSUPPORTED, "fpv_partial_rows: fpv_step_fused serves fp32 handles");
     *rows = e->cfg.task == FPV_TASK_YAW ? yaw_partial_rows(e->cfg.num_envs)
-                                        : step_partial_rows(e->cfg.num_envs, e->cfg.noise_ratio != 0.0);
+                                        : step_partial_rows(e->cfg.num_envs, e->cfg.noise_ratio != 0.0, e->cfg.detector == FPV_DETECTOR_PIXEL);
     return FPV_OK;
 }
 

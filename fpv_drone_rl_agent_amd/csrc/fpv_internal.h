@@ -160,7 +160,9 @@ template <typename T>
 hipError_t launch_yaw_convert(void* state, void* canon, int64_t n, bool to_canon, hipStream_t s);
 
 extern int64_t g_pair_max_tiles;
-int64_t step_partial_rows(int64_t n, bool noise);
+extern int64_t g_quad_min_tiles, g_quad_max_tiles;   // launch_step: step_quad_kernel (fpv_rollstep.hip) for tile counts in (min, max]
+hipError_t launch_step_quad(const StepArgs<float>& st, uint64_t* stamps, hipStream_t s);
+int64_t step_partial_rows(int64_t n, bool noise, bool pixel);
 int64_t yaw_partial_rows(int64_t n);
 hipError_t launch_tick_fill(uint64_t* tick, int64_t tiles, uint64_t v, hipStream_t s);
 

@@ -675,6 +675,42 @@ __global__ __launch_bounds__(512) void rollout_step_kernel(RollStepArgs p) {
 #undef RS1_STAMP
 }
 
+// ---------------------------------------------------------------- phase 2 alone: the env step of fpv_step / fpv_step_fused
+// The same four-tiles-per-workgroup step (physics wave + helper wave per tile: noise hand-off, shared pixel-detector rows, tile
+// store and moment sums beside the ledger writes) as a launch of its own, for actions that come from memory.  Same bits as
+// step_kernel (fpv_step.hip) — rs_tail is what tests/test_rollstep_gpu.py compares with it — in less time where the chip would
+// otherwise sit at one wave per SIMD with the pixel detector's row walk in that one wave (launch_step's dispatch, fpv_step.hip).
+__global__ __launch_bounds__(512) void step_quad_kernel(StepArgs<float> st, uint64_t* stamps) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    TileRegs tr;
+    rs_load_tile(st, tr);
+    if (threadIdx.x < 256) {
+        const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        reinterpret_cast<f32x4*>(lds + kRsAct)[threadIdx.x] = i < st.n ? reinterpret_cast<const f32x4*>(st.actions)[i] : f32x4{0.f, 0.f, 0.f, -1.f};
+    }
+    __syncthreads();
+    const TailOut to{st.reward, st.terminated, st.truncated, st.done, st.partials, true, false, true,
+                     stamps ? stamps + (int64_t)blockIdx.x * 16 + 4 : nullptr};
+    rs_tail(st, lds, tr, to);
+}
+
+hipError_t launch_step_quad(const StepArgs<float>& st, uint64_t* stamps, hipStream_t s) {
+    static bool attr_tab[64] = {};                    // hipFuncSetAttribute holds for one device: one flag per ordinal
+    int dev_ = 0;
+    (void)hipGetDevice(&dev_);
+    bool& attr_set = attr_tab[dev_ & 63];
+    constexpr int kPixelBytes = (kRsPix + 4 * RsPix::kFloats) * 4, kAnalyticBytes = kRsPix * 4;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)step_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPixelBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int64_t tiles = (st.n + kTile - 1) / kTile;
+    hipLaunchKernelGGL(step_quad_kernel, dim3((unsigned)(tiles / 4)), dim3(512), (size_t)(st.detector ? kPixelBytes : kAnalyticBytes), s,
+                       st, stamps);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------- the one-step kernel with the policy on the 6-term bf16 split
 // rollout_step_kernel<0> with fpv_policy_split.hip's arithmetic in phase 1 (hover task): the split image of one net is 121 KB, so
 // the workgroup stages pi, evaluates pi and samples for its 256 drones, stages V over it, evaluates V, and then steps the same

@@ -394,10 +394,28 @@ __global__ void tick_fill_kernel(uint64_t* tick, int64_t tiles, uint64_t v) {
 int64_t g_pair_max_tiles = 512;   // step_kernel_pair up to 32 768 drones: P and H waves then land on different SIMDs
                                   // (measured: -14 % at 4 096, -5 % at 32 768, tie at 65 536, +30 % at 131 072)
 
+// step_quad_kernel (fpv_rollstep.hip): four tiles per 512-thread workgroup, a physics and a helper wave per tile that share the
+// pixel detector's rows (fp32, motor noise, tile count a multiple of 4).  It pays with the pixel detector while the grid is at
+// most one workgroup per CU — us per launch, default dispatch -> this kernel (tools/step_quad_sweep.py,
+// profiles/r03_step_quad_sweep.json): 16 384 drones 16.0 -> 15.5, 32 768 17.5 -> 16.0, 65 536 19.3 -> 17.2 (fused 21.1 -> 17.8);
+// 131 072 26.7 -> 31.2 (100 KB of LDS per workgroup: one workgroup per CU); with the analytic detector it loses at every size
+// (65 536: 12.2 -> 13.1).  Same bits either way.
+int64_t g_quad_min_tiles = 128, g_quad_max_tiles = 1024;      // (8 192, 65 536] drones
+static bool use_quad(int64_t tiles, bool noise, bool f32, int detector) {
+    return f32 && noise && detector != 0 && tiles % 4 == 0 && tiles > g_quad_min_tiles && tiles <= g_quad_max_tiles;
+}
+
 template <typename T>
 hipError_t launch_step(const StepArgs<T>& a_in, bool noise, hipStream_t s, bool* merged) {
     StepArgs<T> a = a_in;
     const int64_t tiles = (a.n + kTile - 1) / kTile;
+    if constexpr (sizeof(T) == 4) {
+        if (use_quad(tiles, noise, true, a.detector)) {
+            a.mg_ticket = nullptr;
+            if (merged) *merged = false;
+            return launch_step_quad(a, nullptr, s);
+        }
+    }
     const bool fused = a.done || a.ret || a.partials;
     // the in-launch statistics merge exists in the four-tiles-per-workgroup variant; the reducer holds <= 1 024 rows' worth
     // of sums per thread-way comfortably (tiles / 4 <= 4 096)
@@ -433,8 +451,9 @@ hipError_t launch_step(const StepArgs<T>& a_in, bool noise, hipStream_t s, bool*
     return hipGetLastError();
 }
 // rows of extras.partials that a fused fp32 step of n drones writes (mirrors the dispatch above)
-int64_t step_partial_rows(int64_t n, bool noise) {
+int64_t step_partial_rows(int64_t n, bool noise, bool pixel) {
     const int64_t tiles = (n + kTile - 1) / kTile;
+    if (use_quad(tiles, noise, true, pixel ? 1 : 0)) return tiles / 4;
     if (noise && g_pair_max_tiles > 0 && tiles <= g_pair_max_tiles) return tiles;
     return tiles % 4 == 0 ? tiles / 4 : tiles;
 }

@@ -17,6 +17,10 @@ extern "C" {
  * stores the observation tile); that pays while the helper wave finds a SIMD of its own.  Larger handles use the
  * single-wave kernel.  0 disables the pair kernel.  Results are bit-identical either way. */
 int fpv_set_pair_threshold(int64_t max_drones);
+/* The same for the four-tiles-per-workgroup kernel with a physics and a helper wave per tile (step_quad_kernel): handles with more
+ * than min_drones and at most max_drones drones (fp32, motor noise, a multiple of 256) step through it; it takes precedence over
+ * the wave-pair kernel.  (0, 0) switches it off. */
+int fpv_set_quad_range(int64_t min_drones, int64_t max_drones);
 
 /* Launches an empty kernel on `stream`: the floor of this library's launch path, for calibrating event timings. */
 int fpv_noop(void* stream);

@@ -98,6 +98,58 @@ def test_handle_churn_does_not_leak():
     assert free0 - torch.cuda.mem_get_info()[0] < 64 * 2 ** 20           # nothing accumulates across create/destroy
 
 
+@pytest.mark.parametrize("n", [65536, 12288 - 40])
+def test_quad_kernel_is_bit_identical_to_the_other_launch_shapes(n):
+    """step_quad_kernel (four tiles per workgroup, physics + helper wave per tile sharing the pixel detector's rows: the default
+    for fp32 pixel-detector handles of 8 192 < n <= 65 536 drones) against the single-wave and the wave-pair kernel: fpv_step and
+    fpv_step_fused, auto-resets and ledger included, a ragged last tile in the second size; the partial rows are per workgroup
+    of four tiles in one and per tile / four tiles in the others: same totals."""
+    from fpv_drone_rl_agent_amd import _lib as L
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.synthetic import synthetic_states
+    lib = L.load()
+    st0 = synthetic_states(n, seed=4).astype(np.float32)
+    st0[::5, 34] = 399
+    outs = []
+    try:
+        for quad, pair in (((0, 1 << 40), 32768), ((0, 0), 0), ((0, 0), 1 << 30)):
+            lib.fpv_set_quad_range(*quad)
+            lib.fpv_set_pair_threshold(pair)
+            eng = FpvEngine(n, 0, seed=9, ledger_capacity=4 * n)
+            assert eng.detector == "pixel"
+            eng.set_state(torch.from_numpy(st0))
+            g = torch.Generator(device="cuda").manual_seed(0)
+            done = torch.zeros(n, dtype=torch.uint8, device="cuda"); ret = torch.zeros(n, device="cuda")
+            part = torch.zeros((eng.partial_rows, 44), dtype=torch.float64, device="cuda")
+            rews, sums = [], []
+            for t in range(6):
+                a = torch.rand(n, 4, device="cuda", generator=g) * 2 - 1
+                if t % 2:
+                    eng.step_fused(a, done=done, ret=ret, partials=part)
+                    sums.append(part.sum(dim=0).clone())
+                else:
+                    eng.step(a)
+                rews.append(eng.reward.clone())
+            led = eng.ledger_read()
+            outs.append({"state": eng.get_state().clone(), "obs": eng.obs.clone(), "rew": torch.stack(rews), "ret": ret.clone(), "done": done.clone(),
+                         "term": eng.terminated.clone(), "trunc": eng.truncated.clone(), "sums": torch.stack(sums), "rows": eng.partial_rows,
+                         "led": led})
+            eng.close()
+    finally:
+        lib.fpv_set_quad_range(8192, 65536)
+        lib.fpv_set_pair_threshold(32768)
+    tiles = (n + 63) // 64
+    assert outs[0]["rows"] == tiles // 4 and outs[2]["rows"] == tiles
+    assert outs[0]["led"]["count"] > n // 10
+    for other in outs[1:]:
+        for k in ("state", "obs", "rew", "ret", "done", "term", "trunc"):
+            assert torch.equal(outs[0][k], other[k]), k
+        assert torch.allclose(outs[0]["sums"], other["sums"], rtol=1e-12, atol=1e-9)
+        assert outs[0]["led"]["count"] == other["led"]["count"]
+        for k in ("idx", "info", "tag", "ep_return", "obs"):
+            assert np.array_equal(outs[0]["led"][k], other["led"][k]), k
+
+
 def test_pair_and_single_wave_kernels_are_bit_identical():
     """fpv_set_pair_threshold only changes the schedule (physics wave + helper wave), never the results."""
     from fpv_drone_rl_agent_amd import _lib as L

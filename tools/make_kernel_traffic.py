@@ -8,6 +8,7 @@ s = json.load(open(f"profiles/{tag}_summary.json"))
 f, w = s["pmc_raw_KB_per_launch"]["FETCH_SIZE"], s["pmc_raw_KB_per_launch"]["WRITE_SIZE"]
 want = {"fpv::rollout_step_kernel": "rollout_step_kernel",
         "fpv::policy_forward_kernel": "policy_forward_kernel<512>",
+        "fpv::step_quad_kernel": "step_quad_kernel",
         "fpv::step_kernel<float,true,true>": "step_kernel<float, true, true",
         "fpv::step_kernel<float,true,false>": "step_kernel<float, true, false",
         "fpv::gae_kernel": "fpv::gae_kernel",
