@@ -50,6 +50,10 @@ int main(int argc, char** argv) {
      * (served when n is a multiple of 256) */
     const int one_kernel = (argc > 4 ? atoi(argv[4]) : 1) == 1 && n % 256 == 0;
     const float gamma = 0.99f, lam = 0.95f;
+    if (fpv_version() != FPV_ABI_VERSION) {          /* struct layouts differ between versions: refuse another library build */
+        fprintf(stderr, "libfpv_env.so is ABI version %d, this host was compiled against %d\n", fpv_version(), FPV_ABI_VERSION);
+        return 3;
+    }
     hipStream_t s;
     HK(hipSetDevice(0));
     HK(hipStreamCreate(&s));
