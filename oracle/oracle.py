@@ -28,8 +28,8 @@ TERM, TRUNC, OOB, FLOOR = 1, 2, 4, 8
 
 def build(force: bool = False) -> str:
     """Compile oracle/fpv_oracle.c with gcc (make).  Returns the .so path."""
-    src = os.path.join(_HERE, "fpv_oracle.c")
-    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("fpv_oracle.c", "fpv_oracle.h", "fpv_cpu.c")]
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libfpv_oracle.so"],
                               stdout=subprocess.DEVNULL)
     return _LIB
