@@ -157,6 +157,9 @@ def load(build_if_missing: bool = True):
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it brings its own copy of the HIP runtime, and a process must run on ONE — a library that pulled in the system's
+    # copy before torch loads its own leaves the second one without a device ("no ROCm-capable device is detected")
+    import torch  # noqa: F401
     lib_path = LIB_PATH_EXPERIMENTS if EXPERIMENTS else LIB_PATH
     if not os.path.exists(lib_path):
         if not build_if_missing:
