@@ -538,16 +538,6 @@ __global__ __launch_bounds__(256) void ledger_scan_kernel(LedgerScanArgs a) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t slots = a.tiles * a.rows;
     const uint32_t tick0 = (uint32_t)(a.tick[0] - (uint64_t)a.T);
-    const double* nrm = nullptr;
-    if (a.snapshots && a.table) {
-        for (int e = threadIdx.x; e < a.T * a.obs_words; e += 256) {
-            const int tt = e / a.obs_words, w = e - tt * a.obs_words;
-            nrm_lds[2 * e] = a.snapshots[(int64_t)tt * a.stride + w];
-            nrm_lds[2 * e + 1] = 1.0 / sqrt(a.snapshots[(int64_t)tt * a.stride + a.obs_words + w] + (double)a.eps);
-        }
-        nrm = nrm_lds;
-        __syncthreads();
-    }
     double sr = 0.0, sl = 0.0;
     int nv = 0, episodes = 0, flags = 0;
     // Two rounds of independent loads instead of kScanPerThread dependent ones: every slot's tile count first, then — with the
@@ -606,6 +596,19 @@ __global__ __launch_bounds__(256) void ledger_scan_kernel(LedgerScanArgs a) {
     // that is always valid before the first is used.  (Entry after entry, round after round, this was 35 us at 65 536 yaw drones,
     // where ~3 300 episodes per 20-step rollout end by truncation.)  mean and 1 / sqrt(var + eps) of every step come from the
     // table in LDS (above) when it fits.
+    // The per-step normaliser table is built only by a workgroup that has such entries (a 65 536-drone hover rollout of an
+    // untrained policy has next to none: episodes end by termination), and behind the statistics pass, whose loads it would
+    // otherwise stand in front of.
+    const double* nrm = nullptr;
+    if (a.snapshots && a.table && __syncthreads_or(wave_total)) {
+        for (int e = threadIdx.x; e < a.T * a.obs_words; e += 256) {
+            const int tt = e / a.obs_words, w = e - tt * a.obs_words;
+            nrm_lds[2 * e] = a.snapshots[(int64_t)tt * a.stride + w];
+            nrm_lds[2 * e + 1] = 1.0 / sqrt(a.snapshots[(int64_t)tt * a.stride + a.obs_words + w] + (double)a.eps);
+        }
+        nrm = nrm_lds;
+        __syncthreads();
+    }
     if (wave_total) {                                                  // uniform
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
