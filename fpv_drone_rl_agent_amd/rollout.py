@@ -30,6 +30,7 @@ from __future__ import annotations
 
 import os
 import struct
+import sys
 
 import torch
 
@@ -449,12 +450,25 @@ class RolloutCollector:
         torch.cuda.synchronize(self.device)
         self._tick0 += self.T if self._persistent else 1
         keep = self._slot
-        for slot in (0, 1):
-            self._slot = slot
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._all_steps()
-            self._graphs[slot] = g
+        multi = D.world_size() > 1
+        try:
+            for slot in (0, 1):
+                self._slot = slot
+                g = torch.cuda.CUDAGraph()
+                # several ranks: the collective library's watchdog thread polls events while this thread captures; thread-local
+                # capture mode keeps another thread's calls from invalidating the capture (nothing collective is captured here)
+                with torch.cuda.graph(g, **({"capture_error_mode": "thread_local"} if multi else {})):
+                    self._all_steps()
+                self._graphs[slot] = g
+        except Exception as exc:
+            if not multi:
+                raise
+            # RCCL has not run this code before the driver's first multi-GPU job: a rank whose capture fails goes on with eager
+            # launches (the rollout has no collective inside the graph, so ranks need not agree on this) and says so once
+            self._graphs = [None, None]
+            self.use_graph = False
+            print(f"fpv rollout (rank {D.rank()}): HIP-graph capture failed ({exc!r}); collecting with eager launches",
+                  file=sys.stderr, flush=True)
         self._slot = keep
 
     def set_policy_gemm(self, gemm: str) -> None:
