@@ -189,6 +189,7 @@ class RolloutCollector:
         self._stats_ready = [torch.cuda.Event() for _ in range(2)]
         self._stats_done = [torch.cuda.Event() for _ in range(2)]
         self._done_stream = [None, None]                 # the stream each _stats_done was last recorded on
+        self._capture_mode = None                        # None: "global" with one rank, "thread_local" with several (_capture)
         self._stats_last = 0
         # several ranks: VecNormalize's statistics ride in the same payload ({adv stats[3], obs_rms[2 O + 1], ret_rms[3]}); every
         # rank starts a rollout from the statistics of the union of all ranks' samples so far (fpv_rank_merge) — kept here as the base
@@ -457,7 +458,8 @@ class RolloutCollector:
                 g = torch.cuda.CUDAGraph()
                 # several ranks: the collective library's watchdog thread polls events while this thread captures; thread-local
                 # capture mode keeps another thread's calls from invalidating the capture (nothing collective is captured here)
-                with torch.cuda.graph(g, **({"capture_error_mode": "thread_local"} if multi else {})):
+                mode = self._capture_mode or ("thread_local" if multi else "global")
+                with torch.cuda.graph(g, capture_error_mode=mode):
                     self._all_steps()
                 self._graphs[slot] = g
         except Exception as exc:
