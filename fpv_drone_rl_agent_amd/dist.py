@@ -20,7 +20,8 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not td.is_initialized():
+    rehearse = world == 1 and os.environ.get("FPV_REHEARSE_RANKS", "") == "1"     # several_ranks(): the N > 1 arrangement with G = 1
+    if (world > 1 or rehearse) and not td.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -38,6 +39,16 @@ def world_size() -> int:
     return td.get_world_size() if td.is_available() and td.is_initialized() else 1
 
 
+def several_ranks() -> bool:
+    """True when the multi-rank arrangement of the rollout applies: more than one rank — or, for rehearsals on one GPU, an
+    initialised process group of ONE rank with FPV_REHEARSE_RANKS=1 in the environment: the collector then takes every step of
+    the N > 1 path (side stream, the real collective, advantage statistics from the gathered payload, rank merge of the
+    VecNormalize statistics) with G = 1, whose results must equal the one-rank path's (tools/rccl_rehearsal.py)."""
+    if world_size() > 1:
+        return True
+    return td.is_available() and td.is_initialized() and os.environ.get("FPV_REHEARSE_RANKS", "") == "1"
+
+
 def rank() -> int:
     return td.get_rank() if td.is_available() and td.is_initialized() else 0
 
@@ -47,7 +58,7 @@ def allgather_payload(payload: torch.Tensor) -> torch.Tensor:
     if payload.dtype != torch.float64 or payload.dim() != 1:
         raise ValueError("payload must be a 1-D float64 tensor")
     w = world_size()
-    if w == 1:
+    if w == 1 and not several_ranks():
         return payload.unsqueeze(0)
     if td.get_backend() == "gloo" and payload.is_cuda:
         # rehearsal mode (several ranks on one GPU box over gloo): stage the few words through the host

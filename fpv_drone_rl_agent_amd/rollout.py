@@ -42,8 +42,8 @@ from .policy import ActorCritic
 
 
 class _Batch(dict):
-    """collect()'s result.  "adv_mean" / "adv_std" come from the collective on the collector's side stream: reading
-    them orders the current stream after it (everything else is ready in main-stream order)."""
+    """collect()'s result.  "adv_mean" / "adv_std" come out behind the collective: reading them orders the current stream after
+    it when it ran on another stream (FPV_POST_STREAM=side); everything else is ready in main-stream order."""
 
     def __init__(self, col, items):
         super().__init__(items)
@@ -160,7 +160,7 @@ class RolloutCollector:
                 self._rs_partials = torch.zeros((2, N // 256, 2 * O + 4), dtype=torch.float64, device=dev)
         # What the host / the collective read after a rollout — [0:8] ledger status words (fused policy), [8:11] {count, sum A,
         # sum A^2} of the advantages — exists twice, and so does the captured graph: rollouts alternate between the two, so the
-        # side stream reads rollout r's words while rollout r + 1 already runs, with no copy and no wait between them
+        # host (and a side stream, if asked for) reads rollout r's words while rollout r + 1 already runs, with no copy and no wait between them
         # (a slot is written again two rollouts later).  self._slot selects the pair in use (see the properties below).
         self._post = [torch.zeros((16,), dtype=torch.float64, device=dev) for _ in range(2)]
         self._slot = 0
@@ -180,9 +180,8 @@ class RolloutCollector:
             self._status_np = [t.numpy() for t in self._status_host]      # the same pinned words
             self._status_event = [torch.cuda.Event() for _ in range(2)]
             self._status_pending = [False, False]
-        # the collective and the advantage statistics run on a side stream: nothing on the main stream waits for them
-        # until a consumer asks (the batch's "adv_mean" / "adv_std" items), so consecutive rollouts stay back to back
-        # and ranks are not forced into lock-step every n_steps
+        # FPV_POST_STREAM=side: the collective and the advantage statistics on a side stream (the arrangement of rounds 1-2;
+        # measured slower than following the rollout on its own stream: see collect())
         self._side = torch.cuda.Stream(dev)
         self._stats_k = [t[8:11] for t in self._post]
         self._adv_ms = [torch.zeros((2,), dtype=torch.float64, device=dev) for _ in range(2)]
@@ -411,13 +410,13 @@ class RolloutCollector:
         # one rank: the advantage mean / std come out of the GAE launch itself (with several ranks: after the all-gather)
         ops.gae(self.buf_rew, self.buf_val, self.buf_start, self.last_val, self.episode_start, self.gamma,
                 self.lam, advantages=self.adv, returns=self.ret, stats=self.stats,
-                mean_std=self._adv_ms[self._slot] if D.world_size() == 1 else None)
+                mean_std=self._adv_ms[self._slot] if not D.several_ranks() else None)
 
     # ------------------------------------------------------------------ public API
     def start(self) -> None:
         """VecNormalize.reset(): reset every drone, fold the first observation into the statistics."""
         self.engine.reset()
-        multi = D.world_size() > 1 and self.norm_obs
+        multi = D.several_ranks() and self.norm_obs
         if multi:
             self._base_obs_rms.copy_(self.obs_norm.rms)
         self._normalise_obs(self.engine.obs, self.cur_obs)
@@ -451,7 +450,7 @@ class RolloutCollector:
         torch.cuda.synchronize(self.device)
         self._tick0 += self.T if self._persistent else 1
         keep = self._slot
-        multi = D.world_size() > 1
+        multi = D.several_ranks()
         try:
             for slot in (0, 1):
                 self._slot = slot
@@ -497,12 +496,13 @@ class RolloutCollector:
         main = torch.cuda.current_stream(self.device)
         if self._done_stream[k] is not None and self._done_stream[k] != main:
             main.wait_event(self._stats_done[k])            # this slot's words were last read two rollouts ago: no stall
-        multi = D.world_size() > 1 and (self.norm_obs or self.norm_reward)
+        multi = D.several_ranks() and (self.norm_obs or self.norm_reward)
         if multi:
-            # the previous rollout's merged statistics are written by the side stream: this rollout starts from them, and they
+            # the previous rollout's merged statistics (written behind its collective): this rollout starts from them, and they
             # are the base its own samples are measured against (taken before the graphs' warm-up step, whose samples the
             # statistics absorb like any other)
-            main.wait_event(self._stats_done[self._stats_last])
+            if self._done_stream[self._stats_last] is not None and self._done_stream[self._stats_last] != main:
+                main.wait_event(self._stats_done[self._stats_last])
             self._base_obs_rms.copy_(self.obs_norm.rms)
             self._base_ret_rms.copy_(self.rew_norm.rms)
         if self.use_graph and self._graph is None:
@@ -529,14 +529,16 @@ class RolloutCollector:
             ops.gae(self.buf_rew, self.buf_val, self.buf_start, self.last_val, self.episode_start, self.gamma,
                     self.lam, advantages=self.adv, returns=self.ret, stats=self.stats)
         self._rollouts += 1
-        # What follows the rollout reads this slot's words where the rollout left them.  Several ranks: on the side stream, so
-        # that the main stream never waits for the collective.  One rank: there is no collective, and handing the two tiny
-        # operations to another stream costs more in cross-stream event latency than they take (measured at 65 536 drones:
-        # 65.6 vs 67.0 us per step with one 20-step rollout per timed region, 63.0 vs 63.6 in steady state), so they follow
-        # the rollout on the main stream (FPV_POST_STREAM=side restores the side stream).
+        # What follows the rollout reads this slot's words where the rollout left them, on the rollout's own stream — with several
+        # ranks too (round 3).  A side stream for the collective keeps the main stream free until somebody reads the statistics,
+        # but the next rollout needs the merged VecNormalize statistics and the first minibatch the advantages' mean / std, and
+        # each of the two hand-overs between streams costs 10-25 us of event latency: measured at 65 536 drones, one rank,
+        # 65.6 vs 67.0 us per step with one 20-step rollout per timed region; in the N > 1 arrangement rehearsed with one rank
+        # over RCCL (FPV_REHEARSE_RANKS=1) 66.7 vs 68.5 us per step in steady state, 69.5 vs 71.4 with one 20-step rollout per
+        # region.  FPV_POST_STREAM=side restores the side stream.
         # Every event recorded between two graph launches is a packet the second launch queues behind: on one stream the rollout
         # needs exactly one (the host waits on it for the status words), where it used to record three.
-        post = self._side if (D.world_size() > 1 or os.environ.get("FPV_POST_STREAM", "") == "side") else main
+        post = self._side if os.environ.get("FPV_POST_STREAM", "") == "side" else main
         with torch.cuda.stream(post):
             if post is not main:
                 self._stats_ready[k].record(main)           # the rollout is complete on the main stream here
@@ -549,7 +551,7 @@ class RolloutCollector:
                     self._status_host[k].copy_(self._post[k][0:8], non_blocking=True)
                 self._status_event[k].record(post)          # (the one event left costs ~0.2 us per step at 32-step rollouts)
                 self._status_pending[k] = True
-            if not (self.fused_policy and D.world_size() == 1):     # (one rank, fused tail: fpv_gae has written mean / std already)
+            if not (self.fused_policy and not D.several_ranks()):     # (one rank, fused tail: fpv_gae has written mean / std already)
                 payload = self._stats_k[k]
                 if multi:                                           # VecNormalize's statistics ride in the same payload
                     payload = torch.cat([self._stats_k[k], self.obs_norm.rms, self.rew_norm.rms])

@@ -22,4 +22,5 @@ cp "$(ls $O/prof_s20/*/*kernel_stats.csv | head -1)" profiles/r03_kernel_stats_s
 { echo "# PPO update (tools/microbench_ppo.py): HIP events, then rocprofv3 kernel statistics of the same script"; cat $O/ppo_events.json; echo;
   head -12 "$(ls $O/prof_ppo/*/*kernel_stats.csv | head -1)"; } > profiles/r03_ppo_update_profile.txt
 tail -3 $O/tests.txt > profiles/r03_gpu_tests_tail.txt
+[ -f $O/bench_rehearsed_ranks.json ] && last $O/bench_rehearsed_ranks.json > profiles/r03_bench_line_rehearsed_ranks.json
 ls -la profiles/r03_* | awk '{print $5, $9}'

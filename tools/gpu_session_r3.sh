@@ -12,6 +12,7 @@ python bench.py --steps 20 --warmup 5 > $O/bench_s20.json 2> $O/bench_s20.err
 python bench.py --detector analytic --no-cpu-baseline --no-split-extra --no-host-mode > $O/bench_analytic.json 2> $O/bench_analytic.err
 python bench.py --two-launch --no-cpu-baseline --no-split-extra --no-host-mode > $O/bench_two.json 2> $O/bench_two.err
 python bench.py --task yaw --no-cpu-baseline --no-host-mode > $O/bench_yaw.json 2> $O/bench_yaw.err
+FPV_REHEARSE_RANKS=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29581 python bench.py --no-cpu-baseline --no-split-extra --no-host-mode > $O/bench_rehearsed_ranks.json 2> $O/bench_rehearsed_ranks.err
 python tools/rollout_phases.py > $O/phases_step.json 2> /dev/null
 DETECTOR=analytic python tools/rollout_phases.py > $O/phases_step_analytic.json 2> /dev/null
 make -C examples/c_host > /dev/null 2>&1

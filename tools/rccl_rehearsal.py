@@ -44,6 +44,39 @@ for mode in ("global", "thread_local"):
     out[f"capture_{mode}"] = ok
     out[f"episodes_{mode}"] = col.episodes["count"] if ok is True else None
     eng.close()
+# ---- the N > 1 arrangement of the collector itself with G = 1 (FPV_REHEARSE_RANKS=1): side stream, the REAL collective on the
+# payload, advantage statistics from the gathered row, base snapshots and rank merge of the VecNormalize statistics — against the
+# one-rank arrangement from the same seeds.  One rank's batch merged into the base is the same statistics up to fp64 rounding.
+def run(rehearse):
+    os.environ["FPV_REHEARSE_RANKS"] = "1" if rehearse else "0"
+    torch.manual_seed(3)
+    eng = FpvEngine(16384, 0, seed=2)
+    col = RolloutCollector(eng, ActorCritic(log_std_init=-1.0).cuda(), n_steps=16, policy_seed=5)
+    col.start()
+    res = []
+    for _ in range(4):
+        b = col.collect()
+        col.wait_stats()
+        torch.cuda.synchronize()
+        res.append({"adv": b["advantages"].clone(), "obs": b["obs"].clone(), "mean": float(b["adv_mean"]), "std": float(b["adv_std"]),
+                    "obs_rms": col.obs_norm.rms.clone(), "ret_rms": col.rew_norm.rms.clone(), "episodes": col.episodes["count"]})
+    several = D.several_ranks()
+    eng.close()
+    return res, several
+
+
+try:
+    (a, sa), (b, sb) = run(True), run(False)
+    out["rehearsed_path_is_the_multi_rank_one"] = bool(sa and not sb)
+    out["episodes_equal"] = all(x["episodes"] == y["episodes"] and x["episodes"] > 0 for x, y in zip(a, b))
+    out["advantages_max_abs_diff"] = max(float((x["adv"] - y["adv"]).abs().max()) for x, y in zip(a, b))
+    out["obs_max_abs_diff"] = max(float((x["obs"] - y["obs"]).abs().max()) for x, y in zip(a, b))
+    out["adv_mean_std_max_rel_diff"] = max(max(abs(x["mean"] - y["mean"]) / max(1e-12, abs(y["mean"])), abs(x["std"] - y["std"]) / y["std"])
+                                           for x, y in zip(a, b))
+    out["statistics_max_rel_diff"] = max(float(((x[k] - y[k]).abs() / y[k].abs().clamp_min(1e-6)).max()) for x, y in zip(a, b)
+                                         for k in ("obs_rms", "ret_rms"))
+except Exception as exc:  # noqa: BLE001
+    out["multi_rank_path_with_one_rank"] = repr(exc)
 td.barrier()
 td.destroy_process_group()
 print(json.dumps(out))
