@@ -164,12 +164,16 @@ __global__ void rank_merge_kernel(const double* __restrict__ gathered, int world
     const int c = threadIdx.x;
     const bool obs_ch = c < d && base_obs != nullptr, ret_ch = c == d && base_ret != nullptr;
     if (!obs_ch && !ret_ch) return;
-    const double m0 = obs_ch ? base_obs[c] : base_ret[0], v0 = obs_ch ? base_obs[d + c] : base_ret[1];
-    const double c0 = obs_ch ? base_obs[2 * d] : base_ret[2];
+    // (branches, not selects of two loads: either statistics may be left out, and the compiler is free to issue both loads of a
+    // select — one of them through a null pointer; seen once as a fault at address 0 while this kernel was being changed)
+    double m0, v0, c0;
+    if (obs_ch) { m0 = base_obs[c]; v0 = base_obs[d + c]; c0 = base_obs[2 * d]; }
+    else { m0 = base_ret[0]; v0 = base_ret[1]; c0 = base_ret[2]; }
     double mean = m0, var = v0, count = c0;
+    const int ic = obs_ch ? c : 0, iv = obs_ch ? d + c : 1, in = obs_ch ? 2 * d : 2;       // this thread's words of a gathered row
     for (int r = 0; r < world; ++r) {
         const double* row = gathered + (int64_t)r * stride + 3 + (obs_ch ? 0 : 2 * d + 1);
-        const double m1 = obs_ch ? row[c] : row[0], v1 = obs_ch ? row[d + c] : row[1], c1 = obs_ch ? row[2 * d] : row[2];
+        const double m1 = row[ic], v1 = row[iv], c1 = row[in];
         const double cb = c1 - c0;
         if (!(cb > 0.0)) continue;                       // this rank added nothing
         const double mb = (m1 * c1 - m0 * c0) / cb, db = mb - m0;
