@@ -116,9 +116,9 @@ __device__ __forceinline__ void step_merge_tail(const Args& p, const double* row
     const bool do_obs = tid < O && p.mg_obs_rms != nullptr, do_ret = tid == 2 * O && p.mg_ret_rms != nullptr;
     double nm = 0.0, nv = 0.0, tot = 0.0;
     if (do_obs || do_ret) {
-        const double cnt = do_obs ? p.mg_obs_rms[2 * O] : p.mg_ret_rms[2];
-        const double mean = do_obs ? p.mg_obs_rms[tid] : p.mg_ret_rms[0];
-        const double var = do_obs ? p.mg_obs_rms[O + tid] : p.mg_ret_rms[1];
+        double cnt, mean, var;                          // (branches, not selects of two loads: either pointer may be null)
+        if (do_obs) { cnt = p.mg_obs_rms[2 * O]; mean = p.mg_obs_rms[tid]; var = p.mg_obs_rms[O + tid]; }
+        else { cnt = p.mg_ret_rms[2]; mean = p.mg_ret_rms[0]; var = p.mg_ret_rms[1]; }
         const double bm = (do_obs ? xch[tid] : xch[2 * O]) / bc;
         double bv = (do_obs ? xch[O + tid] : xch[2 * O + 1]) / bc - bm * bm;
         if (bv < 0.0) bv = 0.0;
