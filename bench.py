@@ -555,7 +555,7 @@ def main() -> None:
                                     "done-ledger timeout bootstrap, GAE) + advantage-stat all-gather every n_steps"),
                        "drones_per_gpu": n, "total_drones": n * world, "n_steps": T,
                        "hip_graph": not args.no_graph, "kernels_per_step": 1 if col._one_launch else 2, "detector": "analytic" if yaw else args.detector, "policy": "MlpPolicy pi/vf [128,128] tanh" + ("" if yaw else " (39 049 params), exact-fp32 MFMA"),
-                       "episodes_in_last_rollout": episodes, **({"rehearsal": "FPV_REHEARSE_RANKS=1: the collector's N > 1 arrangement (side stream, the real all-gather over a single-rank RCCL group, advantage statistics from the gathered payload, rank merge of the VecNormalize statistics) with ONE rank"} if (world == 1 and D.several_ranks()) else {})},
+                       "episodes_in_last_rollout": episodes, **({"rehearsal": "FPV_REHEARSE_RANKS=1: the collector's N > 1 arrangement (the real all-gather over a single-rank RCCL group behind every rollout, advantage statistics from the gathered payload, rank merge of the VecNormalize statistics) with ONE rank"} if (world == 1 and D.several_ranks()) else {})},
             "roofline": roofline,
         }
         if roofline_env is not None:
