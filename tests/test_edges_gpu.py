@@ -150,6 +150,27 @@ def test_quad_kernel_is_bit_identical_to_the_other_launch_shapes(n):
             assert np.array_equal(outs[0]["led"][k], other["led"][k]), k
 
 
+@pytest.mark.parametrize("n,detector,rows", [(8192, "pixel", 128), (8448, "pixel", 33), (65536, "pixel", 256), (65792, "pixel", 257),
+                                             (65536, "analytic", 256), (32768, "analytic", 512), (4160, "pixel", 65)])
+def test_partial_rows_follow_the_launch_shape(n, detector, rows):
+    """fpv_partial_rows mirrors launch_step's dispatch at its boundaries (wave-pair kernel: a row per tile up to 32 768 drones;
+    step_quad_kernel: a row per four tiles for pixel-detector handles of 8 192 < n <= 65 536; else a row per four tiles when the
+    tile count divides, per tile when not) — and a fused step writes exactly those rows: the rest of an oversized table stays
+    untouched, the written rows add up to the drones' moment sums."""
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    eng = FpvEngine(n, 0, seed=1, detector=detector)
+    assert eng.partial_rows == rows
+    part = torch.full((rows + 8, 44), -7.0, dtype=torch.float64, device="cuda")
+    done = torch.zeros(n, dtype=torch.uint8, device="cuda"); ret = torch.zeros(n, device="cuda")
+    eng.step_fused(torch.rand(n, 4, device="cuda") * 2 - 1, done=done, ret=ret, partials=part)
+    torch.cuda.synchronize()
+    assert (part[rows:] == -7.0).all() and (part[:rows, 40] != -7.0).all()
+    o = eng.obs.double()
+    assert torch.allclose(part[:rows, :20].sum(dim=0), o.sum(dim=0), rtol=1e-9, atol=1e-6)
+    assert torch.allclose(part[:rows, 20:40].sum(dim=0), (o * o).sum(dim=0), rtol=1e-9, atol=1e-6)
+    eng.close()
+
+
 def test_pair_and_single_wave_kernels_are_bit_identical():
     """fpv_set_pair_threshold only changes the schedule (physics wave + helper wave), never the results."""
     from fpv_drone_rl_agent_amd import _lib as L
