@@ -493,6 +493,7 @@ class RolloutCollector:
             self.start()
         eng = self.engine
         k = self._slot = self._rollouts % 2
+        late_error = None
         main = torch.cuda.current_stream(self.device)
         if self._done_stream[k] is not None and self._done_stream[k] != main:
             main.wait_event(self._stats_done[k])            # this slot's words were last read two rollouts ago: no stall
@@ -519,7 +520,10 @@ class RolloutCollector:
                 self._graph.replay()
             else:
                 self._all_steps()
-            self._parse_status(raw)
+            try:
+                self._parse_status(raw)
+            except RuntimeError as exc:         # raised at the end of this call, once the collector's own bookkeeping is consistent
+                late_error = exc
         else:
             eng.ledger_clear()
             self._all_steps()
@@ -569,6 +573,8 @@ class RolloutCollector:
         self._done_stream[k] = post
         self._stats_last = k
         self._tick0 += self.T
+        if late_error is not None:              # a flag of the rollout two back (ledger overflow, ...): its data was invalid
+            raise late_error
         return _Batch(self, {"obs": self.buf_obs, "actions": self.buf_act, "values": self.buf_val, "log_probs": self.buf_logp,
                              "advantages": self.adv, "returns": self.ret, "adv_mean": self._adv_ms[k][0],
                              "adv_std": self._adv_ms[k][1]})

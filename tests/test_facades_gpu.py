@@ -280,6 +280,16 @@ def test_collector_turns_a_ledger_overflow_into_an_error():
     col.collect()
     with pytest.raises(RuntimeError, match="ledger overflow"):
         col.episodes
+    # unread, the flag surfaces from collect() when the slot comes round again (two rollouts later) — at the END of that call, with
+    # the collector's own bookkeeping advanced, so that the caller can go on (or stop) with a consistent object
+    st[:, 34] = 399.0
+    eng.set_state(st)
+    col.collect()                                                       # slot 1: overflows again, nobody reads it
+    col.collect()                                                       # slot 0: holds rollout 0's words, already read above
+    r = col._rollouts
+    with pytest.raises(RuntimeError, match="ledger overflow"):
+        col.collect()                                                   # slot 1 comes round: rollout 1's flag
+    assert col._rollouts == r + 1 and col.engine.get_tick() == 8 * (r + 1)
     eng.close()
 
 
