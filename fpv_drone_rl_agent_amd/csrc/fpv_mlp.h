@@ -34,8 +34,22 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // pack kernel) carries that factor in the hidden layers' weights and biases, which takes one multiply out of every tanh —
 // vector instructions do not overlap the fp32 MFMA stream, so each one is launch time.
 constexpr float kTanhPrescale = 2.8853900817779268f;
+// FPV_TANH_FOLD: tanh(x) = 1 - 2 r with r = 1 / (1 + e^{2x}), and the layer that consumes tanh's output is affine in it:
+// W (1 - 2 r) + b = (b + sum_k W_k) - 2 W r.  The image then carries -2 W and b + sum_k W_k for the second hidden layer and the
+// heads (policy_pack_kernel: the sum in double, the factor 2 exact), the kernels hand r from layer to layer, and every tanh is
+// three vector instructions instead of four — 256 fewer per wave, on a pipe that the matrix products share with them.  The chain
+// stays a k-ordered fp32 fma chain; its partial sums start at b + sum W instead of b (the same magnitude for any weights whose
+// row sums are not far above their row norms), so the results differ from the unfolded form at rounding level only
+// (tests/test_policy_gpu.py holds both to the same bounds against an fp64 evaluation).
+#ifndef FPV_TANH_FOLD
+#define FPV_TANH_FOLD 1
+#endif
 __device__ __forceinline__ float fast_tanh_prescaled(float z) {
+#if FPV_TANH_FOLD
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));          // r; the consumer's image holds -2 W and b + sum W
+#else
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));
+#endif
 }
 
 // bias image [m][h][16] -> accumulator tiles

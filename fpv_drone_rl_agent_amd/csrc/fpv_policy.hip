@@ -45,9 +45,14 @@ __global__ void policy_pack_kernel(PolicyParams p, float* __restrict__ img) {
         } else if (o < kOffB2) {                // W2p[m][kt][r4][lane][rr] = W2[m*32 + i][kt*32 + row(4 r4 + rr, h)]
             const int q = o - kOffW2, rr = q % 4, lane = (q / 4) % 64, r4 = (q / 256) % 4, kt = (q / 1024) % 4, m = q / 4096;
             v = w2[(m * 32 + (lane & 31)) * kHid + kt * 32 + tile_row(4 * r4 + rr, lane >> 5)];
+            if (FPV_TANH_FOLD) v *= -2.0f;      // layer 2 consumes r1 = (1 - tanh) / 2 (fpv_mlp.h)
         } else {
             const int q = o - kOffB2, r = q % 16, h = (q / 16) % 2, m = q / 32;
-            v = b2[m * 32 + tile_row(r, h)];
+            const int j = m * 32 + tile_row(r, h);
+            double b = (double)b2[j];
+            if (FPV_TANH_FOLD)
+                for (int k = 0; k < kHid; ++k) b += (double)w2[j * kHid + k];
+            v = (float)b;
         }
         v *= kTanhPrescale;                     // both hidden layers end in tanh: fast_tanh_prescaled (fpv_mlp.h)
     } else {
@@ -55,11 +60,23 @@ __global__ void policy_pack_kernel(PolicyParams p, float* __restrict__ img) {
         if (q < 512) {                          // Wa[h][kt][r][o]
             const int o = q % 4, r = (q / 4) % 16, kt = (q / 64) % 4, h = q / 256;
             v = o < p.act_dim ? p.wa[o * kHid + kt * 32 + tile_row(r, h)] : 0.0f;
+            if (FPV_TANH_FOLD) v *= -2.0f;      // the heads consume r2
         } else if (q < 640) {                   // Wv[h][kt][r]
             const int z = q - 512, r = z % 16, kt = (z / 16) % 4, h = z / 64;
             v = p.wv[kt * 32 + tile_row(r, h)];
-        } else if (q < 644) v = q - 640 < p.act_dim ? p.ba[q - 640] : 0.0f;
-        else if (q == 644) v = p.bv[0];
+            if (FPV_TANH_FOLD) v *= -2.0f;
+        } else if (q < 644) {
+            const int o = q - 640;
+            double b = o < p.act_dim ? (double)p.ba[o] : 0.0;
+            if (FPV_TANH_FOLD && o < p.act_dim)
+                for (int k = 0; k < kHid; ++k) b += (double)p.wa[o * kHid + k];
+            v = (float)b;
+        } else if (q == 644) {
+            double b = (double)p.bv[0];
+            if (FPV_TANH_FOLD)
+                for (int k = 0; k < kHid; ++k) b += (double)p.wv[k];
+            v = (float)b;
+        }
         else if (q >= 648 && q < 652) v = q - 648 < p.act_dim ? p.log_std[q - 648] : 0.0f;
         else if (q >= 652 && q < 656) v = q - 652 < p.act_dim ? expf(p.log_std[q - 652]) : 0.0f;
         else if (q == 656) {                    // -sum log_std - act_dim * 0.5 ln 2 pi
