@@ -5,6 +5,7 @@
  * SURVEY.md §8c (tests/test_oracle_kat.py).
  */
 #include "fpv_oracle.h"
+#include "cv_restate.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -179,14 +180,15 @@ int fpv_oracle_camera(const double pos[3], const double quat[4], double center[2
 }
 
 /* ------------------------------------------------------------------ pixel detector (SPEC §6b)
- * hover.py:157-222 on a 128 x 128 rendering of the panel, restated without a renderer and without OpenCV (neither is
- * on disk: PARITY UNPINNED for cv2's contour rules).  Coverage: a pixel is red when its centre (i + 0.5, j + 0.5) lies in
- * the projected front face.  From the row spans [a_j, b_j]: the border rule (:180-185), cv2.boundingRect's integer w / h
- * (:209-213), cv2.contourArea of the 8-connected outer contour = the polygon through the boundary pixels (:206), its
- * arcLength, and a stand-in for approxPolyDP's four vertices (:189-203): the covered pixel nearest to each projected
- * corner, accepted when every vertex lies farther than epsilon = 0.04 * arcLength from the diagonal of the other two.
- * The reference's own constants pin the convention: from the reset pose this gives w / h = 20 / 13 = 1.538 and
- * area = 207 / 16384 = 0.01263, i.e. hover.py:50-51's target_ratio = 1.53 and target_area = 0.013. */
+ * hover.py:157-222 on a 128 x 128 rendering of the panel.  The renderer (pybullet) is not on disk, so the mask is stated
+ * directly: a pixel is red when its centre (i + 0.5, j + 0.5) lies in the projected front face.  From the mask on this is
+ * the reference's own sequence of calls — the border test (:180-185), cv2.findContours(RETR_EXTERNAL,
+ * CHAIN_APPROX_SIMPLE) (:187), max by cv2.contourArea (:189), epsilon = 0.04 * cv2.arcLength (:190), cv2.approxPolyDP
+ * (:191), "four vertices or invisible" (:193), the mean of the four vertices (:197-203), contourArea / 16384 (:206),
+ * cv2.boundingRect's w / h (:209-213) — through the restatement of those calls in cv_restate.c (opencv-python is absent:
+ * PARITY UNPINNED for cv2 and for the renderer).  The reference's own constants pin the conventions: from the reset pose
+ * this gives w / h = 20 / 13 = 1.538 and area = 207 / 16384 = 0.01263, i.e. hover.py:50-51's target_ratio = 1.53 and
+ * target_area = 0.013. */
 static int row_span(const double u[4], const double v[4], const double slope[4], int j, int* a, int* b) {
     double y = j + 0.5, xl = 0.0, xr = 0.0;
     int n = 0;
@@ -208,9 +210,10 @@ static int row_span(const double u[4], const double v[4], const double slope[4],
     return 1;
 }
 
-/* dbg (may be NULL): spans[128][2] (a, b; -1 for empty rows), then 8 vertex coordinates, arcLength, contour area */
-static int camera_pixel(const double pos[3], const double quat[4], double center[2], double* area, double* ratio,
-                        double* dbg) {
+/* the red mask of the view from (pos, quat), drawn into an all-zero mask[j * 128 + i]; returns 0 when a corner lies behind
+ * the camera (nothing is drawn then).  y0 .. y1: the rows that received red pixels (y0 > y1: none).
+ * spans (may be NULL): [128][2] = (a, b) per row, -1 for rows without a red pixel */
+static int panel_mask(const double pos[3], const double quat[4], uint8_t* mask, double* spans, int* y0, int* y1) {
     static const double CY[4] = {1.0, -1.0, -1.0, 1.0};
     static const double CZ[4] = {-1.0, -1.0, 1.0, 1.0};
     double R[3][3];
@@ -218,7 +221,8 @@ static int camera_pixel(const double pos[3], const double quat[4], double center
     double c = cos(CAM_TILT_DEG * M_PI / 180.0), s = sin(CAM_TILT_DEG * M_PI / 180.0);
     double u[4], v[4];
     int ok = 1;
-    center[0] = center[1] = 0.0; *area = 0.0; *ratio = 0.0;
+    *y0 = 128; *y1 = -1;
+    if (spans) for (int i = 0; i < 256; ++i) spans[i] = -1.0;
     for (int j = 0; j < 4; ++j) {
         double dw[3] = {PANEL_X - pos[0], CY[j] - pos[1], PANEL_ZC + CZ[j] - pos[2]};
         double db[3];
@@ -242,79 +246,88 @@ static int camera_pixel(const double pos[3], const double quat[4], double center
     double flo = ceil(vmin - 0.5), fhi = floor(vmax - 0.5);
     if (flo < 0.0) flo = 0.0;
     if (fhi > 127.0) fhi = 127.0;
-    if (!(flo <= fhi)) return 0;
-    int jlo = (int)flo, jhi = (int)fhi;
-    if (dbg) for (int i = 0; i < 256; ++i) dbg[i] = -1.0;
-    /* pass over the rows: bounding box, contour area and length, border rule, 8-connectivity */
-    int j0 = -1, jn = -1, amin = 128, bmax = -1, pa = 0, pb = 0, border = 0, broken = 0;
-    int straight = 0, diag = 0;                                /* unit and diagonal steps of the outer contour */
-    double apx = 0.0;
-    for (int j = jlo; j <= jhi; ++j) {
+    if (!(flo <= fhi)) return 1;
+    for (int j = (int)flo; j <= (int)fhi; ++j) {
         int a, b;
         if (!row_span(u, v, slope, j, &a, &b)) continue;               /* (a sliver between two pixel centres) */
-        if (dbg) { dbg[2 * j] = a; dbg[2 * j + 1] = b; }
-        if (j0 >= 0 && jn != j - 1) broken = 1;                 /* an empty row inside the blob */
-        if (j0 < 0) { j0 = j; straight += b - a; }               /* the top row's run */
-        else {
-            if (a > pb + 1 || b < pa - 1) broken = 1;           /* not 8-connected to the row above */
-            double ml = (a > pa ? a : pa) - (a != pa ? 0.5 : 0.0);
-            double mr = (b < pb ? b : pb) + (b != pb ? 0.5 : 0.0);
-            if (mr > ml) apx += mr - ml;
-            int da = a > pa ? a - pa : pa - a, db = b > pb ? b - pb : pb - b;
-            /* per side: one straight step down if the end stays, else one diagonal step and |delta| - 1 along the row */
-            if (da == 0) straight += 1; else { diag += 1; straight += da - 1; }
-            if (db == 0) straight += 1; else { diag += 1; straight += db - 1; }
-        }
-        if (a == 0 || b == 127 || j == 0 || j == 127) border = 1;      /* hover.py:180-185 */
-        if (a < amin) amin = a;
-        if (b > bmax) bmax = b;
-        jn = j; pa = a; pb = b;
+        if (spans) { spans[2 * j] = a; spans[2 * j + 1] = b; }
+        memset(mask + 128 * j + a, 1, (size_t)(b - a + 1));
+        if (j < *y0) *y0 = j;
+        *y1 = j;
     }
-    if (j0 < 0 || broken || border) return 0;
-    straight += pb - pa;                                                /* the bottom row's run */
-    double diag_len = 1.4142135623730951 * (double)diag;
-    double len = (double)straight + diag_len;                           /* cv2.arcLength of the 8-connected contour */
-    /* the four vertices: covered pixel nearest to each projected corner (rows within one of the corner's own) */
-    int vx[4], vy[4];
-    for (int k = 0; k < 4; ++k) {
-        double fr = floor(v[k]);                                        /* row whose centre is nearest to v: round(v - 0.5) */
-        int jc = (int)(fr < (double)j0 ? j0 : (fr > (double)jn ? jn : fr));
-        double best = 1e300;
-        for (int dj = -1; dj <= 1; ++dj) {
-            int j = jc + dj, a, b;
-            if (j < j0 || j > jn) continue;
-            row_span(u, v, slope, j, &a, &b);
-            double fx = floor(u[k]);
-            int x = (int)(fx < (double)a ? a : (fx > (double)b ? b : fx));
-            double dx = x + 0.5 - u[k], dy = j + 0.5 - v[k], d2 = dx * dx + dy * dy;
-            if (d2 < best) { best = d2; vx[k] = x; vy[k] = j; }
-        }
-    }
-    if (dbg) {
-        for (int k = 0; k < 4; ++k) { dbg[256 + 2 * k] = vx[k]; dbg[257 + 2 * k] = vy[k]; }
-        dbg[264] = len; dbg[265] = apx;
-    }
-    /* approxPolyDP's 4-vertex gate: Douglas-Peucker starts from the two farthest points of the contour (the longer
-     * diagonal) and adds a vertex on either side only if it lies farther than eps from that chord */
-    double eps = 0.04 * len;
-    {
-        double d02 = (double)((vx[2] - vx[0]) * (vx[2] - vx[0]) + (vy[2] - vy[0]) * (vy[2] - vy[0]));
-        double d13 = (double)((vx[3] - vx[1]) * (vx[3] - vx[1]) + (vy[3] - vy[1]) * (vy[3] - vy[1]));
-        int p = d02 >= d13 ? 0 : 1, q = p + 2;                           /* the longer diagonal's ends */
-        double ex = vx[q] - vx[p], ey = vy[q] - vy[p], el = sqrt(ex * ex + ey * ey);
-        if (!(el > 0.0)) return 0;
-        double lim = eps * el;                                           /* distance > eps as |cross product| > eps |chord| */
-        for (int k = p + 1; k < p + 4; k += 2) {
-            int m = k & 3;
-            double cr = fabs(ex * (vy[m] - vy[p]) - ey * (vx[m] - vx[p]));
-            if (!(cr > lim)) return 0;
-        }
-    }
-    center[0] = 0.25 * (double)(vx[0] + vx[1] + vx[2] + vx[3]) / 64.0 - 1.0;      /* hover.py:197-203 */
-    center[1] = 0.25 * (double)(vy[0] + vy[1] + vy[2] + vy[3]) / 64.0 - 1.0;
-    *area = apx / 16384.0;                                                           /* :206 */
-    *ratio = (double)(bmax - amin + 1) / (double)(jn - j0 + 1);                      /* :209-213 */
     return 1;
+}
+
+/* hover.py:157-222 from the mask on, for a mask whose red pixels all lie in rows y0 .. y1 (the scan of findContours is
+ * confined to those rows: the rows above and below hold nothing to find).  dbg (may be NULL, FPV_ORACLE_PIXEL_DBG doubles):
+ * [256..263] the four vertices, [264] arcLength, [265] contourArea, [266] len(approx), [267] len(contours), [268] points of the
+ * chosen contour, then the contour's points (x, y) from [272] (at most 512 of them) */
+static int detect_rows(const uint8_t* mask, int y0, int y1, double center[2], double* area, double* ratio, double* dbg) {
+    enum { CAP_PTS = 4 * 128 * 128, CAP_C = 128 * 128 / 2 + 1 };
+    static __thread cvr_point pts[CAP_PTS];
+    static __thread int32_t start[CAP_C + 1];
+    static __thread cvr_point approx[CAP_PTS];
+    center[0] = center[1] = 0.0; *area = 0.0; *ratio = 0.0;
+    if (y0 > y1) { if (dbg) dbg[267] = 0; return 0; }                              /* no red pixel at all */
+    int red_at_edges = 0;                                                          /* hover.py:180-185 */
+    for (int i = 0; i < 128; ++i)
+        if (mask[i] || mask[127 * 128 + i]) red_at_edges = 1;
+    for (int j = y0; j <= y1; ++j)
+        if (mask[128 * j] || mask[128 * j + 127]) red_at_edges = 1;
+    int nc = cvr_find_contours_external(mask + 128 * y0, 128, y1 - y0 + 1, pts, CAP_PTS, start, CAP_C);      /* :187 */
+    if (dbg) dbg[267] = nc;
+    if (nc <= 0 || red_at_edges) return 0;                                                      /* :188 */
+    for (int i = 0; i < start[nc]; ++i) pts[i].y += y0;
+    int best = 0;                                                                               /* :189 max(): first maximum */
+    double best_area = cvr_contour_area(pts + start[0], start[1] - start[0]);
+    for (int c = 1; c < nc; ++c) {
+        double a = cvr_contour_area(pts + start[c], start[c + 1] - start[c]);
+        if (a > best_area) { best_area = a; best = c; }
+    }
+    const cvr_point* contour = pts + start[best];
+    int n = start[best + 1] - start[best];
+    double len = cvr_arc_length_closed(contour, n);
+    double epsilon = 0.04 * len;                                                                /* :190 */
+    int na = cvr_approx_poly_dp_closed(contour, n, epsilon, approx);                            /* :191 */
+    if (dbg) {
+        dbg[264] = len; dbg[265] = best_area; dbg[266] = na; dbg[268] = n;
+        for (int i = 0; i < n && i < 512; ++i) { dbg[272 + 2 * i] = contour[i].x; dbg[273 + 2 * i] = contour[i].y; }
+    }
+    if (na != 4) return 0;                                                                      /* :193 */
+    if (dbg) for (int k = 0; k < 4; ++k) { dbg[256 + 2 * k] = approx[k].x; dbg[257 + 2 * k] = approx[k].y; }
+    double mx = (double)(approx[0].x + approx[1].x + approx[2].x + approx[3].x) / 4.0;          /* :197-198 np.mean */
+    double my = (double)(approx[0].y + approx[1].y + approx[2].y + approx[3].y) / 4.0;
+    /* :200-203: / (128 / 2) - 1, then np.array(..., dtype=np.float32).  The four vertices are integers below 128, so the
+     * value is a multiple of 1 / 256 in [-1, 1): the single-precision rounding is exact (kept as the reference has it) */
+    center[0] = (double)(float)(mx / 64.0 - 1.0);
+    center[1] = (double)(float)(my / 64.0 - 1.0);
+    *area = best_area / (128.0 * 128.0);                                                        /* :206 */
+    int32_t r[4];
+    cvr_bounding_rect(contour, n, r);                                                           /* :209 */
+    *ratio = r[3] > 0 ? (double)r[2] / (double)r[3] : 0.0;                                      /* :210-213 */
+    return 1;
+}
+
+int fpv_oracle_detect_mask(const uint8_t* mask, double center[2], double* area, double* ratio, double* dbg) {
+    int y0 = 128, y1 = -1;
+    for (int j = 0; j < 128; ++j)
+        for (int i = 0; i < 128; ++i)
+            if (mask[128 * j + i]) { if (j < y0) y0 = j; y1 = j; break; }
+    return detect_rows(mask, y0, y1, center, area, ratio, dbg);
+}
+
+static int camera_pixel(const double pos[3], const double quat[4], double center[2], double* area, double* ratio,
+                        double* dbg) {
+    static __thread uint8_t mask[128 * 128];
+    static __thread int dirty0 = 0, dirty1 = -1;               /* rows of `mask` that the previous call left red */
+    if (dbg) for (int i = 0; i < FPV_ORACLE_PIXEL_DBG; ++i) dbg[i] = -1.0;
+    center[0] = center[1] = 0.0; *area = 0.0; *ratio = 0.0;
+    if (dirty0 <= dirty1) memset(mask + 128 * dirty0, 0, (size_t)(128 * (dirty1 - dirty0 + 1)));
+    dirty0 = 0; dirty1 = -1;
+    int y0, y1;
+    if (!panel_mask(pos, quat, mask, dbg, &y0, &y1)) return 0;
+    dirty0 = y0; dirty1 = y1;
+    return detect_rows(mask, y0, y1, center, area, ratio, dbg);
 }
 
 int fpv_oracle_camera_pixel(const double pos[3], const double quat[4], double center[2], double* area,
@@ -322,9 +335,10 @@ int fpv_oracle_camera_pixel(const double pos[3], const double quat[4], double ce
     return camera_pixel(pos, quat, center, area, ratio, NULL);
 }
 
-/* test hook: the same, also returning the row spans, the four vertices, arcLength and the contour area in pixels */
+/* test hook: the same, also returning the row spans, the four vertices, arcLength, the contour area in pixels and the
+ * chosen contour itself (layout above) */
 int fpv_oracle_camera_pixel_debug(const double pos[3], const double quat[4], double center[2], double* area,
-                                  double* ratio, double dbg[266]) {
+                                  double* ratio, double dbg[FPV_ORACLE_PIXEL_DBG]) {
     return camera_pixel(pos, quat, center, area, ratio, dbg);
 }
 

@@ -77,9 +77,13 @@ int fpv_oracle_camera(const double pos[3], const double quat[4], double center[2
 /* SPEC §6b: the same through the 128 x 128 pixel rules of hover.py:157-222 (cv2's rules restated: parity unpinned) */
 int fpv_oracle_camera_pixel(const double pos[3], const double quat[4], double center[2], double* area,
                             double* ratio);
-/* test hook: dbg = row spans [128][2] (-1 = empty), 4 vertices (x, y), arcLength, contour area [px^2] */
+/* test hook: dbg = row spans [128][2] (-1 = empty), [256..263] the 4 vertices (x, y), [264] arcLength, [265] contourArea [px^2],
+ * [266] len(approx), [267] len(contours), [268] points of the chosen contour, [272 ...] those points (x, y), at most 512 */
+#define FPV_ORACLE_PIXEL_DBG (272 + 1024)
 int fpv_oracle_camera_pixel_debug(const double pos[3], const double quat[4], double center[2], double* area,
-                                  double* ratio, double dbg[266]);
+                                  double* ratio, double dbg[FPV_ORACLE_PIXEL_DBG]);
+/* hover.py:180-213 from a 128 x 128 mask (0 / 1 bytes) on: border test, findContours, max contourArea, approxPolyDP, features */
+int fpv_oracle_detect_mask(const uint8_t* mask, double center[2], double* area, double* ratio, double* dbg);
 /* SPEC §7 / hover.py:274-332.  Returns reward, writes info bits. */
 double fpv_oracle_reward(const double pos[3], const double euler[3], double omega_z,
                          const double center[2], double area, double ratio, int visible,

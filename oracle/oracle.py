@@ -28,7 +28,7 @@ TERM, TRUNC, OOB, FLOOR = 1, 2, 4, 8
 
 def build(force: bool = False) -> str:
     """Compile oracle/fpv_oracle.c with gcc (make).  Returns the .so path."""
-    srcs = [os.path.join(_HERE, f) for f in ("fpv_oracle.c", "fpv_oracle.h", "fpv_cpu.c")]
+    srcs = [os.path.join(_HERE, f) for f in ("fpv_oracle.c", "fpv_oracle.h", "fpv_cpu.c", "cv_restate.c", "cv_restate.h")]
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libfpv_oracle.so"],
                               stdout=subprocess.DEVNULL)
@@ -129,16 +129,85 @@ def camera(pos, quat, detector="pixel"):
     return int(vis), c, area.value, ratio.value
 
 
-def camera_pixel_debug(pos, quat):
-    """(visible, center, area, ratio, spans {row: (a, b)}, vertices [4][2], arcLength, contour area in pixels)."""
+PIXEL_DBG = 272 + 1024
+
+
+def camera_pixel_debug(pos, quat, full=False):
+    """(visible, center, area, ratio, spans {row: (a, b)}, vertices [4][2], arcLength, contour area in pixels); with full=True
+    also a dict {approx: len(approx), contours: len(contours), contour: [(x, y), ...] of the chosen contour}."""
     pos, quat = _f64(pos), _f64(quat)
     c = np.zeros(2)
-    dbg = np.full(266, -1.0)
+    dbg = np.full(PIXEL_DBG, -1.0)
     area, ratio = C.c_double(), C.c_double()
     lib().fpv_oracle_camera_pixel_debug.restype = C.c_int
     vis = lib().fpv_oracle_camera_pixel_debug(_dp(pos), _dp(quat), _dp(c), C.byref(area), C.byref(ratio), _dp(dbg))
     spans = {j: (int(dbg[2 * j]), int(dbg[2 * j + 1])) for j in range(128) if dbg[2 * j] >= 0}
-    return int(vis), c, area.value, ratio.value, spans, dbg[256:264].reshape(4, 2).astype(int), dbg[264], dbg[265]
+    out = (int(vis), c, area.value, ratio.value, spans, dbg[256:264].reshape(4, 2).astype(int), dbg[264], dbg[265])
+    if not full:
+        return out
+    n = int(dbg[268])
+    more = dict(approx=int(dbg[266]), contours=int(dbg[267]),
+                contour=[(int(dbg[272 + 2 * i]), int(dbg[273 + 2 * i])) for i in range(max(min(n, 512), 0))], points=n)
+    return out + (more,)
+
+
+class _Pt(C.Structure):
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32)]
+
+
+def detect_mask(mask):
+    """hover.py:180-213 on a 128 x 128 mask (nonzero = red).  (visible, center, area, ratio)."""
+    m = np.ascontiguousarray((np.asarray(mask) != 0).astype(np.uint8))
+    assert m.shape == (128, 128)
+    c = np.zeros(2)
+    area, ratio = C.c_double(), C.c_double()
+    lib().fpv_oracle_detect_mask.restype = C.c_int
+    vis = lib().fpv_oracle_detect_mask(m.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(c), C.byref(area), C.byref(ratio), None)
+    return int(vis), c, area.value, ratio.value
+
+
+def cv_find_contours(mask):
+    """cv2.findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) restated (oracle/cv_restate.c): list of [(x, y), ...]."""
+    m = np.ascontiguousarray((np.asarray(mask) != 0).astype(np.uint8))
+    h, w = m.shape
+    cap = 4 * h * w + 16
+    pts = (_Pt * cap)()
+    start = (C.c_int32 * (h * w // 2 + 2))()
+    lib().cvr_find_contours_external.restype = C.c_int
+    nc = lib().cvr_find_contours_external(m.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int(w), C.c_int(h), pts, C.c_int(cap), start,
+                                          C.c_int(h * w // 2 + 1))
+    assert nc >= 0
+    return [[(pts[i].x, pts[i].y) for i in range(start[c], start[c + 1])] for c in range(nc)]
+
+
+def _pts(points):
+    arr = (_Pt * max(len(points), 1))()
+    for i, (x, y) in enumerate(points):
+        arr[i].x, arr[i].y = int(x), int(y)
+    return arr
+
+
+def cv_arc_length(points):
+    lib().cvr_arc_length_closed.restype = C.c_double
+    return float(lib().cvr_arc_length_closed(_pts(points), C.c_int(len(points))))
+
+
+def cv_contour_area(points):
+    lib().cvr_contour_area.restype = C.c_double
+    return float(lib().cvr_contour_area(_pts(points), C.c_int(len(points))))
+
+
+def cv_bounding_rect(points):
+    r = (C.c_int32 * 4)()
+    lib().cvr_bounding_rect(_pts(points), C.c_int(len(points)), r)
+    return tuple(int(v) for v in r)
+
+
+def cv_approx_poly_dp(points, eps):
+    dst = (_Pt * max(len(points), 1))()
+    lib().cvr_approx_poly_dp_closed.restype = C.c_int
+    n = lib().cvr_approx_poly_dp_closed(_pts(points), C.c_int(len(points)), C.c_double(eps), dst)
+    return [(dst[i].x, dst[i].y) for i in range(n)]
 
 
 def reward(pos, euler, omega_z, center, area, ratio, visible, action, prev_action, step_count,

@@ -1,10 +1,11 @@
-"""Generates tests/golden/hover_step_v1.npz (analytic detector, SPEC §6) and hover_step_v2.npz (the pixel detector of
-SPEC §6b, the product's default since round 3) from the CPU oracle (oracle/fpv_oracle.c).
+"""Generates tests/golden/hover_step_v1.npz (analytic detector, SPEC §6) and hover_step_v3.npz (the pixel detector of
+SPEC §6b, the product's default since round 3; v3 = round 4, with cv2.findContours / approxPolyDP restated in full — v2 held
+round 3's nearest-covered-pixel vertex rule and is gone) from the CPU oracle (oracle/fpv_oracle.c).
 
 The reference ships no golden vectors and its PyFlyt/pybullet step cannot run here,
 so these vectors pin the BUILD's spec (docs/SPEC.md), not PyFlyt: parity with PyFlyt is unpinned.
 They freeze the oracle's outputs so that a later edit of either the oracle or the HIP kernels that
-changes results is caught.  Run from the repo root:  python tests/golden/make_golden.py [v1|v2]   (default: v2;
+changes results is caught.  Run from the repo root:  python tests/golden/make_golden.py [v1|v3]   (default: v3;
 v1 was written in round 1 and is kept as committed)
 """
 import os
@@ -17,8 +18,8 @@ sys.path.insert(0, ROOT)
 from oracle import oracle as orc  # noqa: E402
 
 
-def main(version="v2"):
-    detector = {"v1": "analytic", "v2": "pixel"}[version]
+def main(version="v3"):
+    detector = {"v1": "analytic", "v3": "pixel"}[version]
     orc.build()
     out = {}
     # (a) one noisy step from 256 synthetic states with episode-end edge cases

@@ -1,4 +1,4 @@
-"""Committed golden vectors (tests/golden/hover_step_v1.npz / _v2.npz, made by tests/golden/make_golden.py from
+"""Committed golden vectors (tests/golden/hover_step_v1.npz / _v3.npz, made by tests/golden/make_golden.py from
 the oracle): the oracle must keep reproducing them (CPU), and the HIP path must match them (GPU).
 They pin the build's SPEC; parity with PyFlyt/pybullet is unpinned."""
 import os
@@ -9,8 +9,9 @@ import pytest
 from tests import parity
 
 _DIR = os.path.join(os.path.dirname(__file__), "golden")
-# v1: the analytic detector (round 1); v2: the pixel detector of SPEC §6b — the default since round 3
-GOLD = {"analytic": np.load(os.path.join(_DIR, "hover_step_v1.npz")), "pixel": np.load(os.path.join(_DIR, "hover_step_v2.npz"))}
+# v1: the analytic detector (round 1); v3: the pixel detector of SPEC §6b (the default since round 3) with cv2's contour calls
+# restated in full (round 4)
+GOLD = {"analytic": np.load(os.path.join(_DIR, "hover_step_v1.npz")), "pixel": np.load(os.path.join(_DIR, "hover_step_v3.npz"))}
 DETECTORS = ["pixel", "analytic"]
 
 
