@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libfpv_env.so")
 LIB_PATH_EXPERIMENTS = os.path.join(_HERE, "libfpv_env_experiments.so")
 SOURCES = ["fpv_step.hip", "fpv_yaw.hip", "fpv_rollout.hip", "fpv_policy.hip", "fpv_policy_split.hip", "fpv_rollstep.hip", "fpv_ppo.hip", "fpv_capi.hip"]
 EXPERIMENT_SOURCES = ["fpv_policy_w16.hip"]
-HEADERS = ["fpv_dynamics.h", "fpv_internal.h", "fpv_mlp.h", "fpv_policy_image.h", "fpv_step_parts.h", "fpv_yaw_parts.h", "fpv_pixel_tile.h",
+HEADERS = ["fpv_dynamics.h", "fpv_internal.h", "fpv_mlp.h", "fpv_policy_image.h", "fpv_step_parts.h", "fpv_yaw_parts.h", "fpv_pixel_tile.h", "fpv_polydp.h",
            "fpv_policy_split.h", os.path.join("..", "..", "include", "fpv_env.h"), os.path.join("..", "..", "include", "fpv_env_debug.h"),
            os.path.join("..", "..", "include", "fpv_env_experiments.h")]
 

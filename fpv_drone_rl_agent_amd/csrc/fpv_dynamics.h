@@ -437,25 +437,19 @@ __device__ __forceinline__ bool camera_features(const Drone<T>& d, T& cx, T& cy,
 
 // ---------------------------------------------------------------- pixel detector (SPEC §6b)
 // hover.py:157-222 on a 128 x 128 rendering of the panel, without a renderer: a pixel is red when its centre
-// (i + 0.5, j + 0.5) lies in the projected front face.  One pass over the blob's rows gives cv2.boundingRect's integer
-// w / h (:209-213), cv2.contourArea and arcLength of the outer contour (the polygon through the boundary pixels, :206) and
-// the border rule (:180-185); the four approxPolyDP vertices (:189-203) are the covered pixels nearest to the projected
-// corners, accepted when the two off the longer diagonal lie farther than 0.04 arcLength from it.  OpenCV's rules are
-// restated from their documentation (cv2 is not on disk): parity unpinned; pinned by hover.py:50-51's own constants
-// (reset pose: 20 / 13 = 1.538, 207 / 16384 = 0.0126) and compared with a full Douglas-Peucker restatement in
-// tests/test_detector_cpu.py.
+// (i + 0.5, j + 0.5) lies in the projected front face.  This header holds the per-row part: the span of red pixels of an image
+// row, the border rule (:180-185) and the walk that reduces consecutive rows to exact small integers; fpv_pixel_tile.h spreads
+// the rows of a 64-drone tile over its lanes and fpv_polydp.h works the contour calls (:187-213) from the spans.
 //
-// Shape of the computation (round 3).  Everything a row contributes is an exact small integer (or half-integer) in T, so
-// the pass is written as a RUN of consecutive rows reduced to thirteen numbers (PixelRun) that concatenate exactly
-// (pixel_merge): a wave may walk all rows of its drones, or two waves may each walk a part of them (fpv_rollstep.hip:
-// the physics wave and its helper) and merge — same integers either way, hence the same features bit for bit.
+// Everything a row contributes is an exact small integer in T, so the walk is written as a RUN of consecutive rows reduced to
+// thirteen numbers (PixelRun); runs walked by different lanes add up exactly (sums, minima, maxima), hence the same features bit
+// for bit however the rows are split.
 //   crossings of row y = j + 0.5: edge k crosses iff (v_k <= y) != (v_{k+1} <= y) — the rule of SPEC §6b as it stands;
 //   the four compares feed scalar XORs, a non-crossing edge contributes a NaN that v_min3 / v_max3 ignore;
-//   contour area   = W - (w_first + w_last) / 2 - S / 2 + H / 2
-//   contour length = w_first + w_last + S + 2 (n - 1) - 2 H + sqrt(2) H
+//   cv2.contourArea = W - (w_first + w_last) / 2 - S / 2 + H / 2 for an 8-connected run of rows
+//   axis-parallel steps of its border = w_first + w_last + S + 2 (n - 1) - 2 H, diagonal steps = H
 // with W = sum of widths (b - a), S = sum of |a - a'| + |b - b'| over consecutive rows, H = number of span ends that
-// moved; both closed forms equal SPEC §6b item 5's per-pair sums for 8-connected rows (a blob that is not 8-connected is
-// invisible anyway) and are checked against the explicit contour in tests/test_detector_cpu.py.
+// moved (checked against the explicit contour in tests/test_detector_cpu.py).
 template <typename T>
 struct PixelRun {
     T n;          // non-empty rows
@@ -568,8 +562,8 @@ __device__ __forceinline__ void pixel_run_clear(PixelRun<T>& r) {
 }
 
 // rows jfirst .. jlast (exact integers in T; none when jfirst > jlast) of this lane's quadrilateral
-// tab (may be null): span table, entry idx + (j - jfirst) <- a | b << 8 for the non-empty rows below cap (read back by the vertex
-// search of pixel_finish instead of evaluating those rows again).
+// tab (may be null): span table, entry idx + (j - jfirst) <- a | b << 8 (0x00FF, i.e. a > b, for a row without red pixels) for the
+// rows below cap (read back by the contour phase, fpv_polydp.h, instead of evaluating those rows again).
 // linked: (pa0, pb0) is the span of row jfirst - 1, which belongs to the blob but to another run: when row jfirst is not empty its
 // pair with that row is counted here (S, H, viol), so that runs walked by different lanes need no merging beyond sums and
 // minima / maxima of their fields (fpv_rollstep.hip).
@@ -580,8 +574,9 @@ __device__ __forceinline__ void pixel_walk(const T (&u)[4], const T (&v)[4], con
     pixel_run_clear(r);
     for (T j = jfirst; j <= jlast; j += T(1), ++idx) { // per-lane trip count: a wave iterates max(rows), not the union of ranges
         T fa, fb;
-        if (!row_span(u, v, slope, j + T(0.5), fa, fb)) continue;   // (a sliver between two pixel centres)
-        if (tab && idx < cap) tab[idx] = (uint16_t)(int)(fb * T(256) + fa);
+        const bool have = row_span(u, v, slope, j + T(0.5), fa, fb);
+        if (tab && idx < cap) tab[idx] = have ? (uint16_t)(int)(fb * T(256) + fa) : (uint16_t)0x00FFu;
+        if (!have) continue;                                        // (a sliver between two pixel centres)
         if (r.n == T(0)) {
             const bool link = linked && j == jfirst;
             r.j0 = j; r.a0 = fa; r.b0 = fb; r.pa = link ? pa0 : fa; r.pb = link ? pb0 : fb;
@@ -595,93 +590,6 @@ __device__ __forceinline__ void pixel_walk(const T (&u)[4], const T (&v)[4], con
         r.amin = min_(r.amin, fa); r.bmax = max_(r.bmax, fb);
         r.pa = fa; r.pb = fb; r.jn = j;
     }
-}
-
-// p <- p followed by h (h's rows lie below p's)
-template <typename T>
-__device__ __forceinline__ void pixel_merge(PixelRun<T>& p, const PixelRun<T>& h) {
-    const bool hp = p.n > T(0), hh = h.n > T(0), both = hp && hh;
-    const T da = abs_(h.a0 - p.pa), db = abs_(h.b0 - p.pb);
-    const T link = max_(h.a0 - p.pb, p.pa - h.b0);
-    PixelRun<T> o;
-    o.n = p.n + h.n;                                  // a gap between the runs shows as jn - j0 + 1 != n
-    o.j0 = hp ? p.j0 : h.j0; o.a0 = hp ? p.a0 : h.a0; o.b0 = hp ? p.b0 : h.b0;
-    o.jn = hh ? h.jn : p.jn; o.pa = hh ? h.pa : p.pa; o.pb = hh ? h.pb : p.pb;
-    o.W = p.W + h.W;
-    o.S = p.S + h.S + (both ? da + db : T(0));
-    o.H = p.H + h.H + (both ? min_(da, T(1)) + min_(db, T(1)) : T(0));
-    o.viol = max_(max_(p.viol, h.viol), both ? link : T(-1000));
-    o.amin = min_(p.amin, h.amin); o.bmax = max_(p.bmax, h.bmax);
-    p = o;
-}
-
-// the gates and features of SPEC §6b items 3-7 from the blob's run; span3(jc, a, b) yields the spans of rows jc - 1, jc, jc + 1
-// for a row j0 <= jc <= jn (what it returns for a row outside j0 .. jn is not used)
-__device__ __forceinline__ float med3_(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
-__device__ __forceinline__ double med3_(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
-template <typename T, typename Span3Fn>
-__device__ __forceinline__ bool pixel_finish(const PixelRun<T>& r, const T (&u)[4], const T (&v)[4], Span3Fn span3,
-                                             T& cx, T& cy, T& area, T& ratio) {
-    cx = T(0); cy = T(0); area = T(0); ratio = T(0);
-    const T h = r.jn - r.j0 + T(1);
-    if (!(r.n > T(0)) || h != r.n || r.viol > T(1)) return false;             // empty, an empty row inside, not 8-connected
-    if (r.amin == T(0) || r.bmax == T(127) || r.j0 == T(0) || r.jn == T(127)) return false;   // hover.py:180-185
-    const T w0 = r.b0 - r.a0, wn = r.pb - r.pa;
-    const T apx = r.W - T(0.5) * (w0 + wn) - T(0.5) * r.S + T(0.5) * r.H;
-    const T straight = w0 + wn + r.S + T(2) * (r.n - T(1)) - T(2) * r.H;
-    const T diag = T(1.4142135623730951) * r.H;
-    const T len = straight + diag;
-    T vx[4], vy[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const T jc = med3_(floor_(v[k]), r.j0, r.jn);                          // the blob's row nearest to the corner's
-        const T fx = floor_(u[k]);
-        T a[3], b[3];
-        span3(jc, a, b);
-        // candidates in the order jc - 1, jc, jc + 1, the first minimum wins (rows outside the blob do not take part)
-        const T ey0 = jc - T(0.5) - v[k], ey1 = jc + T(0.5) - v[k], ey2 = jc + T(1.5) - v[k];
-        const T x0 = med3_(fx, a[0], b[0]), x1 = med3_(fx, a[1], b[1]), x2 = med3_(fx, a[2], b[2]);
-        const T ex0 = x0 + T(0.5) - u[k], ex1 = x1 + T(0.5) - u[k], ex2 = x2 + T(0.5) - u[k];
-        const T d0 = jc > r.j0 ? ex0 * ex0 + ey0 * ey0 : T(1e30), d1 = ex1 * ex1 + ey1 * ey1;
-        const T d2 = jc < r.jn ? ex2 * ex2 + ey2 * ey2 : T(1e30);
-        T best = d0; vx[k] = x0; vy[k] = jc - T(1);
-        if (d1 < best) { best = d1; vx[k] = x1; vy[k] = jc; }
-        if (d2 < best) { best = d2; vx[k] = x2; vy[k] = jc + T(1); }
-    }
-    const T eps = T(0.04) * len;
-    {
-        const T e02x = vx[2] - vx[0], e02y = vy[2] - vy[0], e13x = vx[3] - vx[1], e13y = vy[3] - vy[1];
-        const T d02 = e02x * e02x + e02y * e02y, d13 = e13x * e13x + e13y * e13y;
-        const bool first = d02 >= d13;                                         // the longer diagonal's ends p, q = p + 2
-        const T px = first ? vx[0] : vx[1], py = first ? vy[0] : vy[1];
-        const T ex = first ? e02x : e13x, ey = first ? e02y : e13y, el = sqrt_(first ? d02 : d13);
-        if (!(el > T(0))) return false;
-        const T m1x = first ? vx[1] : vx[2], m1y = first ? vy[1] : vy[2];      // vertices p + 1 and p + 3
-        const T m3x = first ? vx[3] : vx[0], m3y = first ? vy[3] : vy[0];
-        // distance from the chord > eps, as |cross product| > eps * |chord| (SPEC §6b item 6)
-        const T lim = eps * el;
-        const T cr1 = abs_(ex * (m1y - py) - ey * (m1x - px)), cr3 = abs_(ex * (m3y - py) - ey * (m3x - px));
-        if (!(cr1 > lim) || !(cr3 > lim)) return false;
-    }
-    cx = ((vx[0] + vx[1]) + (vx[2] + vx[3])) * T(1.0 / 256.0) - T(1);          // hover.py:197-203: mean / 64 - 1 (exact scalings)
-    cy = ((vy[0] + vy[1]) + (vy[2] + vy[3])) * T(1.0 / 256.0) - T(1);
-    area = apx * T(1.0 / 16384.0);                                             // :206
-    ratio = div_(r.bmax - r.amin + T(1), h);                                   // :209-213
-    return true;
-}
-
-template <typename T>
-__device__ __forceinline__ bool camera_features_pixel(const Drone<T>& d, T& cx, T& cy, T& area, T& ratio) {
-    T u[4], v[4], slope[4], jlo, jhi;
-    bool ok = pixel_setup(d, u, v, slope, jlo, jhi);
-    if (pixel_touches_border(u, v, slope, jlo, jhi)) { ok = false; jlo = T(1); jhi = T(0); }    // invisible either way: no walk
-    PixelRun<T> r;
-    pixel_walk(u, v, slope, jlo, jhi, r);
-    const bool vis = pixel_finish(r, u, v, [&](T jc, T (&a)[3], T (&b)[3]) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) row_span(u, v, slope, jc + T(q) - T(0.5), a[q], b[q]);
-    }, cx, cy, area, ratio);
-    return ok && vis;
 }
 
 // obs[0:7] of hover.py:224-235: finite-difference Euler rates over agent_dt and the quaternion of the Euler angles
@@ -722,16 +630,6 @@ __device__ __forceinline__ void observe_with(Drone<T>& d, T roll, T pitch, T yaw
 #pragma unroll
     for (int j = 0; j < 7; ++j) o[j] = att[j];
     observe_features(d, a0, a1, a2, a3, o, vis, cx, cyy, area, ratio);
-}
-
-// The same with the camera features computed here by the handle's detector.  Returns visible.
-template <typename T>
-__device__ __forceinline__ bool observe(Drone<T>& d, T roll, T pitch, T yaw, T a0, T a1, T a2, T a3,
-                                        T (&o)[kObsWords], int detector = 0) {
-    T cx, cyy, area, ratio;
-    const bool vis = detector ? camera_features_pixel(d, cx, cyy, area, ratio) : camera_features(d, cx, cyy, area, ratio);
-    observe_with(d, roll, pitch, yaw, a0, a1, a2, a3, o, vis, cx, cyy, area, ratio);
-    return vis;
 }
 
 // stage a wave's [64][W] observation tile through LDS and write it out row-major (W a multiple of 4)

@@ -59,10 +59,10 @@ static_assert((kRsXch * 4) % 8 == 0 && (kRsSum * 4) % 8 == 0, "fp64 areas must b
 static_assert(kRsSum + 2 * 4 * kPartialWords <= 2 * kNetFloats, "phase-2 exchange must fit in the weight image's space");
 // Pixel detector (hover.py:157-222, SPEC §6b): the blob's rows as work items of the tile's two waves (fpv_pixel_tile.h).  Per tile,
 // above the rest of the phase-2 map: corner block, accumulators, item list and a span table that holds every row a tile can have.
-using RsPix = PixTile<2 * kTile, kTile * 128>;
+using RsPix = PixTile<float, 2 * kTile, kTile * 128>;
 constexpr int kRsPix = kRsSum + 2 * 4 * kPartialWords;
 static_assert((kRsPix * 4) % 16 == 0, "16-byte areas must be 16-byte aligned");
-static_assert(kRsPix + 4 * RsPix::kFloats <= 2 * kNetFloats, "the pixel detector's exchange must fit in the weight image's space");
+static_assert(kRsPix + 4 * RsPix::kWords <= 2 * kNetFloats, "the pixel detector's exchange must fit in the weight image's space");
 
 // Workgroup barrier that publishes LDS only: waits for this wave's LDS operations, not for its global stores.  __syncthreads()
 // drains vmcnt too, and in these kernels every barrier would then wait out the ~1-2 us of the rollout-buffer / ledger / flag
@@ -256,8 +256,8 @@ struct TailOut {
     bool store_state;        // the physics wave stores its tile's state and tick itself, ahead of barrier 6 (one-step kernel)
     uint64_t* stamps;        // diagnostic: s_memrealtime values of tile 0's waves, or null: [0..3] physics wave: pairs done, observed,
                              // barrier 6, 7; pixel detector: [4] corners projected, border pre-check done, [5] item list posted (before
-                             // barrier P), [6] P passed, [7] own items done, [8] barrier Q passed, [9] features done; helper wave:
-                             // [10] attitude converted (before barrier P), [11] its items done
+                             // barrier P), [6] P passed, [7] own items done, [8] barrier Q passed, [9] own contours done (before
+                             // barrier R); helper wave: [10] attitude converted (before barrier P), [11] its items done
 };
 
 // Physics-wave registers that live across steps in the persistent kernel; the one-step kernel loads / stores them around
@@ -269,7 +269,7 @@ struct TileRegs {
     float tmpl_lane;
 };
 
-// Called by all 512 threads after the clipped actions are in LDS (kRsAct) and a workgroup barrier.  Contains eight (eleven with the
+// Called by all 512 threads after the clipped actions are in LDS (kRsAct) and a workgroup barrier.  Contains eight (twelve with the
 // pixel detector) workgroup barriers on every path.  On return the four observation tiles (+ returns) are still in LDS (kRsTile).
 // (Measured and not kept: a two-party LDS arrival counter per tile in place of the workgroup barriers between a tile's two waves —
 // no waiting for the slowest of the four tiles at every hand-off, but each hand-off then costs an LDS poll: 68.45 vs 68.63 us per
@@ -286,7 +286,7 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
     T(*nz)[8][kTile] = reinterpret_cast<T(*)[8][kTile]>(lds + kRsNoise + tl * (2 * 8 * kTile));
     Vec4<T>* tl_lds = reinterpret_cast<Vec4<T>*>(lds + kRsTile + tl * kRsTileFloats);
     double* bsum = reinterpret_cast<double*>(lds + kRsSum);
-    float* pix = lds + kRsPix + tl * RsPix::kFloats;   // pixel detector: this tile's corner block, accumulators, item list, span table
+    float* pix = lds + kRsPix + tl * RsPix::kWords;   // pixel detector: this tile's corner block, accumulators, item list, span table
 
     if (helper) {
         // ---- noise producer: pair k is published before barrier k (fpv_step.hip, step_kernel_pair)
@@ -313,9 +313,11 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
             }
             if (o_.stamps && threadIdx.x == 256) o_.stamps[10] = __builtin_amdgcn_s_memrealtime();
             lds_barrier();                                 // barrier P: corner block and item list of this tile are in LDS
-            pixel_work_items<2 * kTile, kTile * 128>(pix, kTile + lane);
+            pixel_work_items<float, 2 * kTile, kTile * 128>(pix, kTile + lane);
             if (o_.stamps && threadIdx.x == 256) o_.stamps[11] = __builtin_amdgcn_s_memrealtime();
             lds_barrier();                                 // barrier Q: every item's run is in LDS
+            pixel_tile_contours<float, 2 * kTile, kTile * 128>(pix, kTile + lane);
+            lds_barrier();                                 // barrier R: every blob's contour result is in LDS
         }
         lds_barrier();   // barrier 6: the physics wave has staged the observation tile (and the returns)
         const int64_t rows_left = s.n - tile * kTile;
@@ -376,32 +378,34 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
         // panel at all: one lane walking its own drone's rows keeps the wave busy for the tallest blob while most lanes idle
         // (measured: 35 rows per tile against 7.8 per drone), and the helper wave has nothing to do until barrier 6.  So the rows
         // become work items of BOTH waves: this wave projects the corners, drops the blobs that touch the image border (exact
-        // pre-check), cuts every other drone's rows into chunks of four and posts the items — the helper converts the attitude
+        // pre-check), cuts every other drone's rows into chunks and posts the items — the helper converts the attitude
         // (Euler angles, obs[0:7]) meanwhile; the 128 lanes each walk an item, adding its run to the drone's accumulators and
-        // leaving the rows' spans; this wave then searches the four vertices in the span table and applies the gates.
+        // leaving the rows' spans; then the eight 16-lane groups of the two waves work the surviving blobs' contours
+        // (cv2.arcLength, cv2.approxPolyDP: fpv_polydp.h) and this wave reads its drones' results.
         f32x4* att = reinterpret_cast<f32x4*>(nz);        // the noise slots are free once pair 5 has been read
         att[lane] = f32x4{d.qx, d.qy, d.qz, d.qw};
         att[kTile + lane] = f32x4{d.er, d.ep, d.eyaw, 0.f};
         lds_barrier();                                     // barrier P0: the helper converts the attitude from here on
-        T u[4], v[4], sl[4], jlo, jhi;
-        const bool ok = pixel_tile_setup<2 * kTile, kTile * 128>(d, pix, lane, u, v, sl, jlo, jhi);
+        T jlo, jhi;
+        pixel_tile_setup<float, 2 * kTile, kTile * 128>(d, pix, lane, jlo, jhi);
         if (o_.stamps && threadIdx.x == 0) o_.stamps[4] = __builtin_amdgcn_s_memrealtime();
-        pixel_post_items<2 * kTile, kTile * 128>(pix, lane, (int)jlo, (int)jhi);
+        pixel_post_items<float, 2 * kTile, kTile * 128>(pix, lane, (int)jlo, (int)jhi);
         if (o_.stamps && threadIdx.x == 0) o_.stamps[5] = __builtin_amdgcn_s_memrealtime();
         lds_barrier();                                     // barrier P
         if (o_.stamps && threadIdx.x == 0) o_.stamps[6] = __builtin_amdgcn_s_memrealtime();
-        pixel_work_items<2 * kTile, kTile * 128>(pix, lane);
+        pixel_work_items<float, 2 * kTile, kTile * 128>(pix, lane);
         if (o_.stamps && threadIdx.x == 0) o_.stamps[7] = __builtin_amdgcn_s_memrealtime();
         lds_barrier();                                     // barrier Q
         if (o_.stamps && threadIdx.x == 0) o_.stamps[8] = __builtin_amdgcn_s_memrealtime();
+        pixel_tile_contours<float, 2 * kTile, kTile * 128>(pix, lane);
+        if (o_.stamps && threadIdx.x == 0) o_.stamps[9] = __builtin_amdgcn_s_memrealtime();
+        lds_barrier();                                     // barrier R
         {
             const f32x4 t0 = att[lane], t1 = att[kTile + lane], t2 = att[2 * kTile + lane];
             roll = t0.x; pitch = t0.y; yaw = t0.z;
             o[0] = t0.w; o[1] = t1.x; o[2] = t1.y; o[3] = t1.z; o[4] = t1.w; o[5] = t2.x; o[6] = t2.y;
         }
-        vis = pixel_tile_features<2 * kTile, kTile * 128>(pix, lane, u, v, sl, jlo, ok, cam_x, cam_y, cam_area, cam_ratio);
-
-        if (o_.stamps && threadIdx.x == 0) o_.stamps[9] = __builtin_amdgcn_s_memrealtime();
+        vis = pixel_tile_features<float, 2 * kTile, kTile * 128>(pix, lane, cam_x, cam_y, cam_area, cam_ratio);
     } else {
         euler_from_quat(d.qx, d.qy, d.qz, d.qw, roll, pitch, yaw);
         T o7[7];
@@ -699,7 +703,7 @@ hipError_t launch_step_quad(const StepArgs<float>& st, uint64_t* stamps, hipStre
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
     bool& attr_set = attr_tab[dev_ & 63];
-    constexpr int kPixelBytes = (kRsPix + 4 * RsPix::kFloats) * 4, kAnalyticBytes = kRsPix * 4;
+    constexpr int kPixelBytes = (kRsPix + 4 * RsPix::kWords) * 4, kAnalyticBytes = kRsPix * 4;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)step_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPixelBytes);
         if (e != hipSuccess) return e;
@@ -727,7 +731,7 @@ struct RollStepSplitArgs {
     StepArgs<float> st;
     uint64_t* stamps;
 };
-constexpr int kRsSplitLdsBytes = (kRsPix + 4 * RsPix::kFloats) * 4 > kSplitLdsBytes ? (kRsPix + 4 * RsPix::kFloats) * 4 : kSplitLdsBytes;
+constexpr int kRsSplitLdsBytes = (kRsPix + 4 * RsPix::kWords) * 4 > kSplitLdsBytes ? (kRsPix + 4 * RsPix::kWords) * 4 : kSplitLdsBytes;
 
 #pragma clang fp contract(fast)
 __global__ __launch_bounds__(512) void rollout_step_split_kernel(RollStepSplitArgs p) {

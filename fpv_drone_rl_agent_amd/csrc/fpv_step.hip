@@ -18,21 +18,15 @@
 
 namespace fpv {
 
-// Observation of hover.py:237-272 with the handle's detector.  fp32 handles walk the pixel detector's rows as work items of the
-// tile's wave (fpv_pixel_tile.h: `pix`, LDS of this wave); fp64 handles, which exist for trajectory-level parity runs, keep
-// the plain walk of one lane per drone.  The same features either way.
-using OneWavePix = PixTile<kTile, kPixCapOneWave>;
+// Observation of hover.py:237-272 with the handle's detector.  The pixel detector's rows and contours are worked by the tile's
+// wave together (fpv_pixel_tile.h: `pix`, LDS of this wave) — called by all 64 lanes, for fp32 and fp64 handles alike.
 template <typename T>
 __device__ __forceinline__ bool observe_tile(Drone<T>& d, T roll, T pitch, T yaw, T a0, T a1, T a2, T a3, T (&o)[kObsWords], int detector,
                                              float* pix, int lane) {
-    if constexpr (sizeof(T) == 4) {
-        T cx, cy, area, ratio;
-        const bool vis = detector ? camera_features_pixel_tile(d, pix, lane, cx, cy, area, ratio) : camera_features(d, cx, cy, area, ratio);
-        observe_with(d, roll, pitch, yaw, a0, a1, a2, a3, o, vis, cx, cy, area, ratio);
-        return vis;
-    } else {
-        return observe(d, roll, pitch, yaw, a0, a1, a2, a3, o, detector);
-    }
+    T cx, cy, area, ratio;
+    const bool vis = detector ? camera_features_pixel_tile(d, pix, lane, cx, cy, area, ratio) : camera_features(d, cx, cy, area, ratio);
+    observe_with(d, roll, pitch, yaw, a0, a1, a2, a3, o, vis, cx, cy, area, ratio);
+    return vis;
 }
 
 // ---------------------------------------------------------------- K1
@@ -42,9 +36,9 @@ __device__ __forceinline__ bool observe_tile(Drone<T>& d, T roll, T pitch, T yaw
 template <typename T, bool NOISE, bool FUSED, int TPB = 1>
 __global__ __launch_bounds__(kTile * TPB) void step_kernel(StepArgs<T> p) {
     // per wave: observation tile; fused variant: + 64 returns + a 64 x 2 fp64 exchange area (fp32 handles only).  The pixel
-    // detector's tile area (fp32 handles) is used before the observation exists: the two share the wave's LDS.
+    // detector's tile area is used before the observation exists: the two share the wave's LDS.
     constexpr int kLdsPerTile = kTile * kObsWords / 4 + (FUSED ? kTile / 4 + kTile : 0);
-    constexpr int kObsBytes = kLdsPerTile * (int)sizeof(Vec4<T>), kPixBytes = sizeof(T) == 4 ? OneWavePix::kFloats * 4 : 0;
+    constexpr int kObsBytes = kLdsPerTile * (int)sizeof(Vec4<T>), kPixBytes = OneWavePixT<T>::kWords * 4;
     constexpr int kWaveBytes = kObsBytes > kPixBytes ? kObsBytes : kPixBytes;
     __shared__ __attribute__((aligned(32))) unsigned char lds_raw[TPB * kWaveBytes];
     __shared__ double bsum[TPB > 1 ? TPB * kPartialWords : 1];
@@ -191,7 +185,7 @@ __global__ __launch_bounds__(2 * kTile) void step_kernel_pair(StepArgs<float> p)
     using T = float;
     __shared__ T nz[2][8][kTile];
     __shared__ Vec4<T> lds[kTile * kObsWords / 4 + (FUSED ? kTile / 4 : 0)];
-    __shared__ __attribute__((aligned(16))) float pix[OneWavePix::kFloats];     // pixel detector: the physics wave's tile area
+    __shared__ __attribute__((aligned(32))) float pix[OneWavePixT<float>::kWords];     // pixel detector: the physics wave's tile area
     const int lane = threadIdx.x & (kTile - 1);
     const bool helper = threadIdx.x >= kTile;
     const int64_t tile = blockIdx.x;
@@ -344,8 +338,9 @@ __global__ __launch_bounds__(kTile) void reset_kernel(Vec4<T>* state, const T* t
 // reset template = spawn state + noise-free motor warm-up + first observation (SPEC §8);
 // evaluated once at fpv_create with the same device functions the step uses.
 template <typename T>
-__global__ void template_kernel(T* tmpl, int detector) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(kTile) void template_kernel(T* tmpl, int detector) {
+    __shared__ __attribute__((aligned(32))) float pix[OneWavePixT<T>::kWords];
+    const int lane = threadIdx.x;                          // one wave; every lane evaluates the same spawn state, lane 0 writes
     Drone<T> d = {};
     d.pz = C<T>::z_rest;
     d.qw = T(1);
@@ -353,7 +348,8 @@ __global__ void template_kernel(T* tmpl, int detector) {
     for (int k = 0; k < 20; ++k) thr += C<T>::alpha * (C<T>::pwm_idle - thr);  // hover.py:109-110
     d.t0 = d.t1 = d.t2 = d.t3 = thr;
     T o[kObsWords];
-    observe(d, T(0), T(0), T(0), T(0), T(0), T(0), T(0), o, detector);         // hover.py:112-113
+    observe_tile(d, T(0), T(0), T(0), T(0), T(0), T(0), T(0), o, detector, pix, lane);     // hover.py:112-113
+    if (lane != 0) return;
     const T s[kStateWords] = {d.px, d.py, d.pz, d.steps, d.qx, d.qy, d.qz, d.qw, d.vx, d.vy, d.vz, d.ep_ret,
                               d.wx, d.wy, d.wz, d.prev_area, d.t0, d.t1, d.t2, d.t3, d.ix, d.iy, d.iz,
                               d.prev_ratio, d.ex, d.ey, d.ez, d.prev_cx, d.er, d.ep, d.eyaw, d.prev_cy,

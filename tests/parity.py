@@ -61,3 +61,40 @@ def rows_close(a, b, atol=0.0, rtol=0.0, max_bad_frac=0.02, what=""):
     bad = int((~ok).sum())
     assert bad <= max(2, int(max_bad_frac * ok.shape[0])), f"{what}: {bad} of {ok.shape[0]} rows outside the tolerance"
     return ok
+
+
+def adversarial_states(oracle, n, seed):
+    """Canonical [n, 36] states whose POSES stress the detector's contour calls (hover.py:187-203): a third of the drones close to
+    the panel's plane (edge-on slivers, blobs in several pieces), a third anywhere in front of it (blobs of up to ~120 rows), a third
+    far away (blobs of a few pixels), all aimed roughly at the panel, at rest.  Most of them are outside the flight dome: their
+    step terminates, and the terminal observation — with the camera features of that pose — is what the done ledger keeps."""
+    import math
+    rng = np.random.Generator(np.random.Philox(seed))
+    st = oracle.synthetic_states(n, seed=seed + 1)
+    st[:, 7:13] = 0.0                                       # at rest: the pose after the step is the pose set here, nearly
+    for i in range(n):
+        mode = i % 3
+        if mode == 0:
+            pos = np.array([rng.uniform(4.0, 4.97), rng.uniform(-3, 3), rng.uniform(3, 9)])
+        elif mode == 1:
+            pos = np.array([rng.uniform(-3, 4.9), rng.uniform(-4, 4), rng.uniform(0.5, 9)])
+        else:
+            pos = np.array([rng.uniform(-40, 4.0), rng.uniform(-10, 10), rng.uniform(0.5, 20)])
+        tgt = np.array([4.98, rng.uniform(-1.5, 1.5), rng.uniform(4.5, 7.5)])
+        d = tgt - pos
+        eul = np.array([rng.normal(0, 0.6), -math.atan2(d[2], math.hypot(d[0], d[1])) + math.radians(25) + rng.normal(0, 0.3),
+                        math.atan2(d[1], d[0]) + rng.normal(0, 0.3)])
+        st[i, 0:3] = pos
+        st[i, 3:7] = oracle.quat_from_euler(eul)
+        st[i, 23:26] = eul
+    return st
+
+
+def final_observations(obs, term, trunc, led_idx, led_obs):
+    """[n, O] observations OF THE STEP: the returned row for a drone that goes on, the ledger's terminal observation for one whose
+    episode ended (the returned row is then the reset observation, SB3 VecEnv semantics)."""
+    out = np.array(obs, np.float64, copy=True)
+    done = (np.asarray(term) | np.asarray(trunc)).astype(bool)
+    assert done.sum() == len(led_idx) and set(np.where(done)[0]) == set(int(i) for i in led_idx)
+    out[np.asarray(led_idx, np.int64)] = led_obs
+    return out

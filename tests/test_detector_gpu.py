@@ -106,3 +106,59 @@ def test_fp32_step_features_match_oracle_up_to_one_pixel_flips(oracle):
     good = ~bad & ~done
     assert np.abs(rew[good] - rew_r[good]).max() <= 2e-5 * max(1.0, np.abs(rew_r[good]).max())
     eng.close()
+
+
+def _step_with_ledger(oracle, eng, st0, act, tick, cfg, dtype):
+    """One step of `eng` and of the oracle from st0; returns (this step's observations incl. terminal ones, rewards) of both."""
+    from tests import parity
+    n = st0.shape[0]
+    ref = st0.astype(np.float64).copy()
+    led = oracle.Ledger(n)
+    obs_r, rew_r, term_r, trunc_r, _ = oracle.step_batch(cfg, ref, act.astype(np.float64), tick, ledger=led, nthreads=8)
+    fin_r = parity.final_observations(obs_r, term_r, trunc_r, led.rows()[0], led.rows()[3])
+    eng.set_state(torch.from_numpy(st0.astype(dtype)))
+    eng.set_tick(tick)
+    eng.ledger_clear()
+    obs, rew, term, trunc = eng.step(torch.from_numpy(act.astype(dtype)).cuda())
+    got = eng.ledger_read()
+    assert (term.cpu().numpy() == term_r).all() and (trunc.cpu().numpy() == trunc_r).all()
+    fin = parity.final_observations(obs.cpu().numpy(), term_r, trunc_r, got["idx"], got["obs"])
+    return fin, rew.cpu().numpy().astype(np.float64), fin_r, rew_r
+
+
+def test_fp64_contours_equal_the_oracle_on_adversarial_poses(oracle):
+    """cv2.findContours / arcLength / approxPolyDP as the kernels work them (16-lane groups over the span table, fpv_polydp.h)
+    against the oracle's restatement on the mask, on poses that produce blobs in several pieces, approximations with 1 .. 9
+    vertices and blobs from 1 to ~120 rows: every feature of every drone to 1e-12."""
+    from tests import parity
+    n = 8192
+    st0 = parity.adversarial_states(oracle, n, 41)
+    act = np.zeros((n, 4)); act[:, 3] = -0.01
+    cfg = oracle.make_cfg(noise_ratio=0.0, seed=5, detector="pixel")
+    eng = _engine(n, noise_ratio=0.0, seed=5, precision="f64")
+    fin, rew, fin_r, rew_r = _step_with_ledger(oracle, eng, st0, act, 3, cfg, np.float64)
+    seen = fin_r[:, 13] == 1
+    assert 0.25 * n < seen.sum() < 0.75 * n                        # both branches of hover.py:193 are exercised
+    assert (fin[:, 13] == fin_r[:, 13]).all()
+    assert np.abs(fin[:, 7:16] - fin_r[:, 7:16]).max() <= 1e-12
+    assert np.abs(rew - rew_r).max() <= 1e-9
+    eng.close()
+
+
+@pytest.mark.parametrize("n", [4096, 16384])
+def test_fp32_contours_equal_the_oracle_on_adversarial_poses(oracle, n):
+    """The same through the fp32 kernels — n = 4 096: step_kernel (one wave per tile, four lane groups, span table of 2 048 rows
+    with the rows beyond it evaluated again); n = 16 384: step_quad_kernel (two waves per tile, eight lane groups).  The contour
+    code is integer arithmetic on the spans, so a drone differs from the oracle only where fp32 rounding of the projected corners
+    moves a span end by a pixel: rare, and every other drone equal to 1e-6 in every feature."""
+    from tests import parity
+    st0 = parity.adversarial_states(oracle, n, 43).astype(np.float32)
+    act = np.zeros((n, 4), np.float32); act[:, 3] = -0.01
+    cfg = oracle.make_cfg(noise_ratio=0.02, seed=9, detector="pixel")
+    eng = _engine(n, noise_ratio=0.02, seed=9)
+    fin, rew, fin_r, rew_r = _step_with_ledger(oracle, eng, st0, act, 2, cfg, np.float32)
+    feat = [7, 8, 11, 13, 14]
+    bad = (np.abs(fin[:, feat] - fin_r[:, feat]) > 1e-6).any(axis=1)
+    assert 0.25 * n < (fin_r[:, 13] == 1).sum() < 0.75 * n
+    assert bad.sum() <= 0.004 * n, (int(bad.sum()), n)             # far-away blobs sit on fewer pixels: more of them flip than in a
+    eng.close()                                                    # hovering population (profiles/*pixel_flip_rate.json)
