@@ -437,29 +437,11 @@ __device__ __forceinline__ bool camera_features(const Drone<T>& d, T& cx, T& cy,
 
 // ---------------------------------------------------------------- pixel detector (SPEC §6b)
 // hover.py:157-222 on a 128 x 128 rendering of the panel, without a renderer: a pixel is red when its centre
-// (i + 0.5, j + 0.5) lies in the projected front face.  This header holds the per-row part: the span of red pixels of an image
-// row, the border rule (:180-185) and the walk that reduces consecutive rows to exact small integers; fpv_pixel_tile.h spreads
-// the rows of a 64-drone tile over its lanes and fpv_polydp.h works the contour calls (:187-213) from the spans.
-//
-// Everything a row contributes is an exact small integer in T, so the walk is written as a RUN of consecutive rows reduced to
-// thirteen numbers (PixelRun); runs walked by different lanes add up exactly (sums, minima, maxima), hence the same features bit
-// for bit however the rows are split.
+// (i + 0.5, j + 0.5) lies in the projected front face.  This header holds the per-row part — the projected corners, the span of
+// red pixels of an image row, the border rule ahead of everything else (:180-185); fpv_pixel_tile.h hands each blob to a lane
+// group, and fpv_polydp.h works the reference's contour calls (:187-213) from the blob's spans.
 //   crossings of row y = j + 0.5: edge k crosses iff (v_k <= y) != (v_{k+1} <= y) — the rule of SPEC §6b as it stands;
-//   the four compares feed scalar XORs, a non-crossing edge contributes a NaN that v_min3 / v_max3 ignore;
-//   cv2.contourArea = W - (w_first + w_last) / 2 - S / 2 + H / 2 for an 8-connected run of rows
-//   axis-parallel steps of its border = w_first + w_last + S + 2 (n - 1) - 2 H, diagonal steps = H
-// with W = sum of widths (b - a), S = sum of |a - a'| + |b - b'| over consecutive rows, H = number of span ends that
-// moved (checked against the explicit contour in tests/test_detector_cpu.py).
-template <typename T>
-struct PixelRun {
-    T n;          // non-empty rows
-    T j0, jn;     // first / last non-empty row
-    T a0, b0;     // span of the first non-empty row
-    T pa, pb;     // span of the last non-empty row
-    T W, S, H;    // see above
-    T viol;       // max over consecutive rows of (a - b'), (a' - b): > 1 means not 8-connected
-    T amin, bmax; // bounding box columns
-};
+//   the four compares feed scalar XORs, a non-crossing edge contributes a NaN that v_min3 / v_max3 ignore.
 
 // a / b to ~1 ulp without the IEEE division sequence (fp32); exact division in fp64
 __device__ __forceinline__ float div_(float a, float b) {
@@ -522,9 +504,12 @@ __device__ __forceinline__ bool pixel_setup(const Drone<T>& d, T (&u)[4], T (&v)
         slope[j] = dv != T(0) ? div_(u[m] - u[j], dv) : T(0);
     }
     const T vmin = min_(min_(v[0], v[1]), min_(v[2], v[3])), vmax = max_(max_(v[0], v[1]), max_(v[2], v[3]));
+    const T umin = min_(min_(u[0], u[1]), min_(u[2], u[3])), umax = max_(max_(u[0], u[1]), max_(u[2], u[3]));
     jlo = max_(ceil_(vmin - T(0.5)), T(0));
     jhi = min_(floor_(vmax - T(0.5)), T(127));
-    ok = ok && jlo <= jhi;
+    // a quadrilateral wholly to the left or to the right of the image covers no pixel centre: every crossing x lies in
+    // [umin, umax], and row_span's [ceil(xl - 1/2), floor(xr - 1/2)] clipped to [0, 127] is empty for xr < 1/2 or xl > 127 1/2
+    ok = ok && jlo <= jhi && umax >= T(0.5) && umin <= T(127.5);
     if (!ok) { jlo = T(1); jhi = T(0); }
     return ok;
 }
@@ -553,43 +538,6 @@ __device__ __forceinline__ bool pixel_touches_border(const T (&u)[4], const T (&
         touch = touch || (ne && (a == T(0) || b == T(127) || rows[q] == T(0) || rows[q] == T(127)));
     }
     return touch && jlo <= jhi;
-}
-
-template <typename T>
-__device__ __forceinline__ void pixel_run_clear(PixelRun<T>& r) {
-    r.n = T(0); r.j0 = T(0); r.jn = T(-1); r.a0 = r.b0 = r.pa = r.pb = T(0);
-    r.W = r.S = r.H = T(0); r.viol = T(-1000); r.amin = T(128); r.bmax = T(-1);
-}
-
-// rows jfirst .. jlast (exact integers in T; none when jfirst > jlast) of this lane's quadrilateral
-// tab (may be null): span table, entry idx + (j - jfirst) <- a | b << 8 (0x00FF, i.e. a > b, for a row without red pixels) for the
-// rows below cap (read back by the contour phase, fpv_polydp.h, instead of evaluating those rows again).
-// linked: (pa0, pb0) is the span of row jfirst - 1, which belongs to the blob but to another run: when row jfirst is not empty its
-// pair with that row is counted here (S, H, viol), so that runs walked by different lanes need no merging beyond sums and
-// minima / maxima of their fields (fpv_rollstep.hip).
-template <typename T>
-__device__ __forceinline__ void pixel_walk(const T (&u)[4], const T (&v)[4], const T (&slope)[4], T jfirst, T jlast, PixelRun<T>& r,
-                                           uint16_t* tab = nullptr, int idx = 0, int cap = 0, bool linked = false, T pa0 = T(0),
-                                           T pb0 = T(0)) {
-    pixel_run_clear(r);
-    for (T j = jfirst; j <= jlast; j += T(1), ++idx) { // per-lane trip count: a wave iterates max(rows), not the union of ranges
-        T fa, fb;
-        const bool have = row_span(u, v, slope, j + T(0.5), fa, fb);
-        if (tab && idx < cap) tab[idx] = have ? (uint16_t)(int)(fb * T(256) + fa) : (uint16_t)0x00FFu;
-        if (!have) continue;                                        // (a sliver between two pixel centres)
-        if (r.n == T(0)) {
-            const bool link = linked && j == jfirst;
-            r.j0 = j; r.a0 = fa; r.b0 = fb; r.pa = link ? pa0 : fa; r.pb = link ? pb0 : fb;
-        }
-        const T da = abs_(fa - r.pa), db = abs_(fb - r.pb);
-        r.viol = max_(r.viol, max_(fa - r.pb, r.pa - fb));
-        r.S += da; r.S += db;
-        r.H += min_(da, T(1)); r.H += min_(db, T(1));
-        r.W += fb - fa;
-        r.n += T(1);
-        r.amin = min_(r.amin, fa); r.bmax = max_(r.bmax, fb);
-        r.pa = fa; r.pb = fb; r.jn = j;
-    }
 }
 
 // obs[0:7] of hover.py:224-235: finite-difference Euler rates over agent_dt and the quaternion of the Euler angles

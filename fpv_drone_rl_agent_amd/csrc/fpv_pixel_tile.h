@@ -1,36 +1,35 @@
-// fpv_pixel_tile.h — the pixel detector (hover.py:157-222, SPEC §6b) of one 64-drone tile, worked by the tile's lanes together.
+// fpv_pixel_tile.h — the pixel detector (hover.py:157-222, SPEC §6b) of a POOL of 64-drone tiles: one blob, one group of lanes.
 //
-// A drone's blob is 0 .. ~45 image rows and a third of the drones see the panel at all: one lane walking its own drone's rows
-// keeps its wave busy for the tallest blob of the tile while most lanes idle (measured on bench.py's states: 35 rows per tile
-// against 7.8 per drone), and a wave issues one vector instruction per ~5 cycles whatever its ILP — the detector is bound by
-// instructions per lane.  So the work is cut twice:
+// What the reference does with the thresholded camera image — the border test, cv2.findContours, the largest contour,
+// cv2.arcLength, cv2.approxPolyDP, "four vertices or invisible", cv2.contourArea, cv2.boundingRect (hover.py:180-213) — is
+// integer work on a blob of 1 .. ~60 image rows that a fifth of the drones have at all.  One lane per drone would keep its wave
+// busy for the slowest blob of the tile while most lanes idle, and a wave issues one vector instruction per ~5 cycles whatever
+// its ILP.  A launch is as slow as its slowest workgroup, so what counts is the worst wave of ~1 000, not the average.  So:
 //
-//  ROWS -> ITEMS.  The lanes that own the drones project the corners, drop the blobs that touch the image border
-//  (pixel_touches_border: exact), cut the others' rows into chunks and post (drone, chunk) items through LDS; WORKERS lanes (the
-//  tile's wave, or its two waves in fpv_rollstep.hip) take one item each, add its PixelRun to the drone's integer accumulators
-//  with LDS atomics and leave every row's span (or "empty") in a table.  Every pair of consecutive rows is counted by exactly
-//  one item (an item that is not its drone's first evaluates the row above itself), so the accumulators need sums, minima and
-//  maxima only: exact integers, order-free.
+//  1. The lanes that own the drones project the panel's corners and drop the blobs that cannot be seen whole (behind the camera,
+//     beside the image, touching its border: pixel_touches_border is exact); corners, slopes and row range go to LDS.
+//  2. The waves of the pool — the tile's one wave in the stand-alone step kernels, all eight waves of the workgroup for its four
+//     tiles in fpv_rollstep.hip — each derive the same schedule from the row ranges: the tallest blobs first, 16 lanes (one DPP
+//     row) each — as many of them as one round of the pool's lanes has room for —, then the others, 8 lanes each; "octet" o of the schedule is worked by lanes 8 (o mod 8)
+//     .. of wave (o / 8) mod waves in round o / (8 waves).  A group evaluates its blob's rows into its private span table, then
+//     runs fpv_polydp.h's poly_blob on it: statistics and cv2's CHAIN_APPROX_SIMPLE contour in one pass over the table, the
+//     contour into registers, arcLength, Douglas-Peucker with its farthest-point sweeps spread over the group's lanes (DPP
+//     reductions), the clean-up pass.  The result (visible, vertex sums, 2 x contourArea, boundingRect) goes to the drone's
+//     result slot.
+//  3. The owner lanes turn their drones' results into obs[7:9, 11, 13, 14].
 //
-//  CONTOURS -> LANE GROUPS (round 4).  What the reference then does with the mask — cv2.findContours, the largest contour,
-//  cv2.arcLength, cv2.approxPolyDP, "four vertices or invisible" (hover.py:187-203) — is worked per surviving blob by a group of
-//  16 lanes (one DPP row): fpv_polydp.h runs approx.cpp's Douglas-Peucker over six slot points per row taken from the span table,
-//  its farthest-point searches spread over the group's lanes and reduced with four DPP steps.  Each wave lists the tile's
-//  candidates (blobs with rows that do not touch the border) itself from the accumulators, group G of the tile takes candidates
-//  G, G + groups, ...; the result (visible, vertex sums, 2 x contourArea, boundingRect) goes to the drone's result slot, which
-//  its owner lane turns into obs[7:9, 11, 13, 14].  Integers and a few doubles only: the same decisions for fp32 and fp64
-//  handles, and the CPU oracle's bit for bit given the same spans.
+// Integers and a few doubles only: fp32 and fp64 handles take the same decisions from the same spans, and the CPU oracle's bit
+// for bit.
 //
-// Per tile, `pix` points at PixTile<T, WORKERS, CAP>::kWords 4-byte words of LDS (32-byte aligned):
-//   corner block [4][64] Vec4<T>: u, v, edge slopes, {first span-table entry, jlo, jhi, rows per item} of every drone;
-//   accumulators [3][64] int4: {n, W, S, H}, {viol, amin, bmax, j0}, {jn};
-//   results [64] int4: {visible | w << 8 | h << 16, sum x | sum y << 16, 2 x contourArea, -};
-//   item list: WORKERS packed items (drone | chunk << 8), then the item count;
-//   candidate lists: 64 bytes per wave of the tile;
-//   span table: CAP u16 entries a | b << 8 per row (0x00FF: no red pixel), the tile's drones one after the other (rows beyond
-//   CAP are evaluated again where they are needed: CAP = 64 x 128 never overflows).
-// The caller orders the phases (post -> work -> contours -> features) with whatever makes LDS writes of one phase visible to the
-// next: a workgroup barrier between two waves, a wavefront fence within one.
+// LDS of a pool, `pool` = PixPool<T, TILES, WAVES>::kWords 4-byte words (32-byte aligned):
+//   per tile: corner block [4][64] Vec4<T> (u, v, edge slopes, {jlo, jhi, -, -} of every drone; jlo > jhi: nothing to do) and
+//   results [64] int4 ({visible | w << 8 | h << 16, sum x | sum y << 16, 2 x contourArea, -});
+//   cv2.arcLength's float32 length of a run of k = 0 .. 127 diagonal steps in units of 2^-23 (128 words);
+//   the schedule: one u16 per octet (drone | second half << 8 | 16 lanes << 9);
+//   per octet of lanes: span table (a | b << 8 per row, 0x00FF = no red pixel, framed by two empty rows) and contour list; a
+//   16-lane group uses the space of its two octets.
+// The caller orders the phases (setup -> contours -> features) with whatever makes LDS writes of one phase visible to the
+// next: a workgroup barrier between waves, a wavefront fence within one.
 #pragma once
 #include "fpv_dynamics.h"
 #include "fpv_polydp.h"
@@ -39,200 +38,179 @@ namespace fpv {
 
 typedef int pi32x4 __attribute__((ext_vector_type(4)));
 
-template <typename T, int WORKERS, int CAP>
-struct PixTile {
-    static constexpr int kAcc = 4 * kTile * 4 * (int)(sizeof(T) / 4);      // words from the tile's base
-    static constexpr int kRes = kAcc + 3 * kTile * 4;
-    static constexpr int kSlots = kRes + kTile * 4;
-    static constexpr int kCand = kSlots + WORKERS + 8;      // (items, the item count, padding to 32 bytes)
-    static constexpr int kTab = kCand + (WORKERS / kTile) * (kTile / 4);
-    static constexpr int kWords = kTab + CAP / 2;
-    static_assert((kAcc * 4) % 32 == 0 && (kTab * 4) % 16 == 0 && (kWords * 4) % 32 == 0 && CAP % 16 == 0 && WORKERS % kTile == 0,
-                  "aligned areas");
-};
-constexpr int kPixMinChunk = 2;                                 // rows per item at least
-constexpr uint16_t kPixNoRow = 0x00FFu;                         // span-table entry of a row without red pixels (a = 255 > b = 0)
+constexpr int kPolyPoints = 12;                                 // contour points per lane: 95 for an 8-lane group, 191 for a 16-lane one
 
-// Inclusive sum over the 64 lanes on the VALU (DPP row shifts, then the row broadcasts gfx9 keeps): lane 63 holds the total.
-__device__ __forceinline__ int wave_scan_inclusive(int x) {
-    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);    // row_shr:1
-    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);    // row_shr:2
-    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);    // row_shr:4
-    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);    // row_shr:8
-    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);    // row_bcast:15 -> rows 1, 3
-    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2, 3
-    return x;
+template <typename T, int TILES, int WAVES>
+struct PixPool {
+    static constexpr int kTileWords = 4 * kTile * 4 * (int)(sizeof(T) / 4) + kTile * 4;       // corner block + results
+    static constexpr int kRes = 4 * kTile * 4 * (int)(sizeof(T) / 4);                         // (inside a tile's block)
+    static constexpr int kRun = TILES * kTileWords;
+    static constexpr int kSched = kRun + 128;
+    static constexpr int kSchedWords = TILES * kTile;                                         // 2 octets per drone at most, u16 each
+    static constexpr int kOct = kSched + kSchedWords;
+    static constexpr int kTabWords = 34, kListWords = 4 * kPolyPoints;                        // per octet: 68 u16 of table, 8 kPolyPoints of list
+    static constexpr int kOctWords = kTabWords + kListWords;
+    static constexpr int kWords = (kOct + 8 * WAVES * kOctWords + 7) / 8 * 8;
+    static_assert((kTileWords * 4) % 32 == 0 && 2 * kTabWords * 2 >= 132, "aligned tiles; a 16-lane group's table holds 128 rows + frame");
+};
+
+__device__ __forceinline__ void pixel_wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// A group of 16 lanes = one DPP row.  All-reduce by a butterfly of lane permutations inside the row: neighbours, pairs of
-// neighbours (quad_perm), the two quads of a half row (row_half_mirror), the two half rows (row_mirror).  Every lane of the
-// row must be active (the callers' control flow is uniform over the group).
-struct DppGroup16 {
-    int l;
+// A group of 8 lanes (half a DPP row) or 16 (a row).  All-reduce by a butterfly of lane permutations that stay inside the half
+// row — neighbours, pairs of neighbours (quad_perm), the two quads (row_half_mirror) — plus, for 16 lanes, the two halves
+// (row_mirror).  The inclusive scan shifts by 1, 2, 4 (and 8) inside the ROW (row_shr) and masks what would come from outside the
+// group.  Every lane of the group must be active (the callers' control flow is uniform over the group).
+struct DppGroup {
+    int l;           // lane in the group
+    bool wide;       // 16 lanes
     __device__ __forceinline__ int lane() const { return l; }
-    __device__ __forceinline__ static constexpr int size() { return 16; }
+    __device__ __forceinline__ int size() const { return wide ? 16 : 8; }
     __device__ __forceinline__ uint32_t max_u32(uint32_t x) const {
         uint32_t y;
         y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xf, 0xf, false); x = x > y ? x : y;    // quad_perm:[1,0,3,2]
         y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xf, 0xf, false); x = x > y ? x : y;    // quad_perm:[2,3,0,1]
         y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xf, 0xf, false); x = x > y ? x : y;   // row_half_mirror
-        y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xf, false); x = x > y ? x : y;   // row_mirror
+        y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xf, 0xf, false); x = (wide && y > x) ? y : x;     // row_mirror
+        return x;
+    }
+    __device__ __forceinline__ int max_i32(int x) const {
+        int y;
+        y = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false); x = x > y ? x : y;
+        y = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false); x = x > y ? x : y;
+        y = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, false); x = x > y ? x : y;
+        y = __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, false); x = (wide && y > x) ? y : x;
         return x;
     }
     __device__ __forceinline__ int add_i32(int x) const {
         x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false);
         x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false);
         x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, false);
-        x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, false);
+        const int y = __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, false);
+        return x + (wide ? y : 0);
+    }
+    __device__ __forceinline__ int scan_add(int x) const {
+        int y;
+        y = __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false); x += l >= 1 ? y : 0;                // row_shr:1
+        y = __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false); x += l >= 2 ? y : 0;                // row_shr:2
+        y = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false); x += l >= 4 ? y : 0;                // row_shr:4
+        y = __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false); x += l >= 8 ? y : 0;                // row_shr:8 (l >= 8: a wide group)
         return x;
     }
+    __device__ __forceinline__ void fence() const { pixel_wave_fence(); }
 };
 
-// Owner lanes (one per drone): corners, slopes and row range of this lane's drone; blobs that touch the border get no rows.
-// Writes the corner block's first three vectors and clears the accumulators.  Returns ok (all corners in front of the camera,
-// some row of pixel centres inside, border untouched so far).
-template <typename T, int WORKERS, int CAP>
-__device__ __forceinline__ bool pixel_tile_setup(const Drone<T>& d, float* pix, int lane, T& jlo, T& jhi) {
-    T u[4], v[4], sl[4];
-    bool ok = pixel_setup(d, u, v, sl, jlo, jhi);
-    if (pixel_touches_border(u, v, sl, jlo, jhi)) { ok = false; jlo = T(1); jhi = T(0); }        // invisible: no rows to walk
-    Vec4<T>* cb = reinterpret_cast<Vec4<T>*>(pix);
+// Owner lanes (one per drone): corners, slopes and row range of this lane's drone into its tile's corner block; a blob that
+// touches the border, lies behind the camera, beside the image or between two rows of pixel centres gets the empty range (1, 0).
+// The owners of tile 0 also write the pool's run-length table.
+template <typename T, int TILES, int WAVES>
+__device__ __forceinline__ void pixel_tile_setup(const Drone<T>& d, float* pool, int tile, int lane) {
+    using P = PixPool<T, TILES, WAVES>;
+    T u[4], v[4], sl[4], jlo, jhi;
+    pixel_setup(d, u, v, sl, jlo, jhi);
+    if (pixel_touches_border(u, v, sl, jlo, jhi)) { jlo = T(1); jhi = T(0); }                    // invisible: no rows to look at
+    Vec4<T>* cb = reinterpret_cast<Vec4<T>*>(pool + tile * P::kTileWords);
     cb[lane] = Vec4<T>{u[0], u[1], u[2], u[3]};
     cb[kTile + lane] = Vec4<T>{v[0], v[1], v[2], v[3]};
     cb[2 * kTile + lane] = Vec4<T>{sl[0], sl[1], sl[2], sl[3]};
-    pi32x4* acc = reinterpret_cast<pi32x4*>(pix + PixTile<T, WORKERS, CAP>::kAcc);
-    acc[lane] = pi32x4{0, 0, 0, 0};                        // n, W, S, H
-    acc[kTile + lane] = pi32x4{-1000, 128, -1, 128};       // viol, amin, bmax, j0
-    acc[2 * kTile + lane] = pi32x4{-1, 0, 0, 0};           // jn
-    return ok;
-}
-
-// Owner lanes: cut the drone's rows [jlo, jhi] into chunks of ch rows — the fewest rows per item that let the WORKERS lanes take
-// all items in one round (items <= rows / ch + one per drone with rows) — and append the items (drone | chunk << 8) at this
-// lane's place in the list.  Leaves {first entry of the drone in the span table, jlo, jhi, ch} in the corner block.  A lane
-// without rows (jlo > jhi) appends nothing.
-template <typename T, int WORKERS, int CAP>
-__device__ __forceinline__ void pixel_post_items(float* pix, int lane, int ilo, int ihi) {
-    using P = PixTile<T, WORKERS, CAP>;
-    const int rows = max(ihi - ilo + 1, 0);
-    const int rows_incl = wave_scan_inclusive(rows);
-    const int tile_rows = __builtin_amdgcn_readlane(rows_incl, 63);
-    const int with_rows = __popcll(__ballot(rows > 0));
-    const int room = max(WORKERS - with_rows, 1);              // (WORKERS = 64 and every drone with rows: one item per drone)
-    const int ch = max(with_rows >= WORKERS ? 128 : kPixMinChunk, (tile_rows + room - 1) / room);      // uniform
-    // ceil(rows / ch) for 0 <= rows <= 128 without an integer division: floor((rows + ch - 1/2) / ch), the half keeps the
-    // quotient away from the integers by 1 / (2 ch), far more than the rounding of the reciprocal
-    const int items = (int)(((float)(rows + ch) - 0.5f) * (1.0f / (float)ch));
-    const int incl = wave_scan_inclusive(items);
-    uint32_t* slots = reinterpret_cast<uint32_t*>(pix + P::kSlots);
-    for (int k = 0, pos = incl - items; k < items; ++k, ++pos) slots[pos] = (uint32_t)lane | (uint32_t)k << 8;
-    if (lane == kTile - 1) slots[WORKERS] = (uint32_t)incl;
-    reinterpret_cast<Vec4<T>*>(pix)[3 * kTile + lane] = Vec4<T>{(T)(rows_incl - rows), (T)ilo, (T)ihi, (T)ch};
-}
-
-// Worker lanes (worker = 0 .. WORKERS - 1): walk the rows of this lane's item and add its run to the drone's accumulators.
-template <typename T, int WORKERS, int CAP>
-__device__ __forceinline__ void pixel_work_items(float* pix, int worker) {
-    using P = PixTile<T, WORKERS, CAP>;
-    const uint32_t* slots = reinterpret_cast<const uint32_t*>(pix + P::kSlots);
-    const Vec4<T>* cb = reinterpret_cast<const Vec4<T>*>(pix);
-    int* acc = reinterpret_cast<int*>(pix + P::kAcc);
-    uint16_t* tab = reinterpret_cast<uint16_t*>(pix + P::kTab);
-    const int total = (int)slots[WORKERS];
-    for (int item = worker; item < total; item += WORKERS) {   // (one round: the chunk size is chosen for it)
-        const uint32_t rec = slots[item];
-        const int d = (int)(rec & 63u), k = (int)(rec >> 8);
-        const Vec4<T> qu = cb[d], qv = cb[kTile + d], qs = cb[2 * kTile + d], qr = cb[3 * kTile + d];
-        const T u[4] = {qu.x, qu.y, qu.z, qu.w}, v[4] = {qv.x, qv.y, qv.z, qv.w}, sl[4] = {qs.x, qs.y, qs.z, qs.w};
-        const T jf = qr.y + (T)k * qr.w, jl = min_(jf + qr.w - T(1), qr.z);
-        const int idx = (int)qr.x + (int)(jf - qr.y);            // this item's first entry in the span table
-        T pa = T(0), pb = T(0);
-        const bool linked = k > 0 && row_span(u, v, sl, jf - T(0.5), pa, pb);        // the row above, if the blob has it
-        PixelRun<T> r;
-        pixel_walk(u, v, sl, jf, jl, r, tab, idx, CAP, linked, pa, pb);
-        if (r.n > T(0)) {
-            int* a = acc + 4 * d;
-            atomicAdd(a, (int)r.n); atomicAdd(a + 1, (int)r.W); atomicAdd(a + 2, (int)r.S); atomicAdd(a + 3, (int)r.H);
-            a += 4 * kTile;
-            atomicMax(a, (int)r.viol); atomicMin(a + 1, (int)r.amin); atomicMax(a + 2, (int)r.bmax); atomicMin(a + 3, (int)r.j0);
-            atomicMax(a + 4 * kTile, (int)r.jn);
-        }
+    cb[3 * kTile + lane] = Vec4<T>{jlo, jhi, T(0), T(0)};
+    if (tile == 0) {
+        uint32_t* run = reinterpret_cast<uint32_t*>(pool + P::kRun);
+        run[lane] = poly_run_length_q23(lane);
+        run[kTile + lane] = poly_run_length_q23(kTile + lane);
     }
 }
 
-// a drone's rows in the tile's span table (fpv_polydp.h's Span policy)
-template <typename T, int CAP>
-struct TileSpan {
-    const uint16_t* tab;       // the drone's first entry minus its first row
-    int cap_row;               // rows >= cap_row lie beyond the table
-    T u[4], v[4], sl[4];       // (CAP < 64 x 128 only) the drone's corners, for the rows beyond the table
-    __device__ __forceinline__ bool operator()(int row, int& a, int& b) const {
-        if (CAP >= kTile * 128 || row < cap_row) {
-            const uint32_t ab = tab[row];
-            a = (int)(ab & 255u); b = (int)(ab >> 8);
-            return a <= b;
-        }
-        T fa, fb;
-        const bool have = row_span(u, v, sl, (T)row + T(0.5), fa, fb);
-        a = have ? (int)fa : 255; b = have ? (int)fb : 0;
-        return have;
+// Every lane of the pool's waves (wv = 0 .. WAVES - 1), once the corner blocks are complete: the blobs.
+template <typename T, int TILES, int WAVES>
+__device__ __forceinline__ void pixel_pool_contours(float* pool, int wv, int lane) {
+    using P = PixPool<T, TILES, WAVES>;
+    // ---- the schedule, derived by every wave for itself (the waves write the same values to the same places).  Blobs of more
+    // than `big` rows get 16 lanes; `big` is the smallest of 16, 20, 24, 28, 36 with which one round serves every blob (8 WAVES
+    // octets), 36 when none does.
+    int rows[TILES], ncand = 0, n16 = 0, n20 = 0, n24 = 0, n28 = 0, n36 = 0;
+#pragma unroll
+    for (int k = 0; k < TILES; ++k) {
+        const Vec4<T> qr = reinterpret_cast<const Vec4<T>*>(pool + k * P::kTileWords)[3 * kTile + lane];
+        rows[k] = (int)qr.y - (int)qr.x + 1;
+        ncand += __popcll(__ballot(rows[k] > 0));
+        n16 += __popcll(__ballot(rows[k] > 16)); n20 += __popcll(__ballot(rows[k] > 20)); n24 += __popcll(__ballot(rows[k] > 24));
+        n28 += __popcll(__ballot(rows[k] > 28)); n36 += __popcll(__ballot(rows[k] > 36));
     }
-};
-
-// "this drone's blob has rows and does not touch the image border" (hover.py:180-185) from its accumulators
-__device__ __forceinline__ bool pixel_candidate(const pi32x4& a0, const pi32x4& a1, const pi32x4& a2) {
-    return a0.x > 0 && !(a1.y == 0 || a1.z == 127 || a1.w == 0 || a2.x == 127);
-}
-
-// Every worker lane, after every item of the tile is done: the contours (see the head of this file).
-template <typename T, int WORKERS, int CAP>
-__device__ __forceinline__ void pixel_tile_contours(float* pix, int worker) {
-    using P = PixTile<T, WORKERS, CAP>;
-    constexpr int kGroups = WORKERS / 16;
-    const int lane = worker & (kTile - 1), wv = worker / kTile;
-    const pi32x4* acc = reinterpret_cast<const pi32x4*>(pix + P::kAcc);
-    const Vec4<T>* cb = reinterpret_cast<const Vec4<T>*>(pix);
-    // this wave's list of the tile's candidates, in drone order (both waves of a tile derive the same list)
-    const bool cand = pixel_candidate(acc[lane], acc[kTile + lane], acc[2 * kTile + lane]);
-    const unsigned long long m = __ballot(cand);
-    const int ncand = __popcll(m);
-    uint8_t* list = reinterpret_cast<uint8_t*>(pix + P::kCand) + kTile * wv;
-    if (cand) list[__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)lane;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const DppGroup16 g{lane & 15};
-    pi32x4* res = reinterpret_cast<pi32x4*>(pix + P::kRes);
-    for (int r = worker >> 4; r < ncand; r += kGroups) {
-        const int d = (int)list[r];
-        const pi32x4 a0 = acc[d], a1 = acc[kTile + d], a2 = acc[2 * kTile + d];
-        const Vec4<T> qr = cb[3 * kTile + d];
-        TileSpan<T, CAP> span;
-        const int rowbase = (int)qr.x, ilo = (int)qr.y;
-        span.tab = reinterpret_cast<const uint16_t*>(pix + P::kTab) + (rowbase - ilo);
-        span.cap_row = CAP - rowbase + ilo;
-        if (CAP < kTile * 128) {
-            const Vec4<T> qu = cb[d], qv = cb[kTile + d], qs = cb[2 * kTile + d];
-            span.u[0] = qu.x; span.u[1] = qu.y; span.u[2] = qu.z; span.u[3] = qu.w;
-            span.v[0] = qv.x; span.v[1] = qv.y; span.v[2] = qv.z; span.v[3] = qv.w;
-            span.sl[0] = qs.x; span.sl[1] = qs.y; span.sl[2] = qs.z; span.sl[3] = qs.w;
+    const int room = 8 * WAVES - ncand;                          // octets left for second halves
+    const int big = n16 <= room ? 16 : (n20 <= room ? 20 : (n24 <= room ? 24 : (n28 <= room ? 28 : 36)));
+    int nbig = 0, nsmall = 0;
+    unsigned long long mbig[TILES], msmall[TILES];
+#pragma unroll
+    for (int k = 0; k < TILES; ++k) {
+        mbig[k] = __ballot(rows[k] > big);
+        msmall[k] = __ballot(rows[k] > 0 && rows[k] <= big);
+        nbig += __popcll(mbig[k]);
+        nsmall += __popcll(msmall[k]);
+    }
+    uint16_t* sched = reinterpret_cast<uint16_t*>(pool + P::kSched);
+    {
+        const unsigned long long below = (1ull << lane) - 1ull;
+        int bb = 0, sb = 2 * nbig;                               // first octet of tile k's big / small blobs
+#pragma unroll
+        for (int k = 0; k < TILES; ++k) {
+            const uint32_t id = (uint32_t)(k * kTile + lane);
+            if (rows[k] > big) {
+                const int o = bb + 2 * __popcll(mbig[k] & below);
+                sched[o] = (uint16_t)(id | 1u << 9);
+                sched[o + 1] = (uint16_t)(id | 1u << 8 | 1u << 9);
+            } else if (rows[k] > 0) {
+                sched[sb + __popcll(msmall[k] & below)] = (uint16_t)id;
+            }
+            bb += 2 * __popcll(mbig[k]);
+            sb += __popcll(msmall[k]);
         }
-        const int j0 = a1.w, jn = a2.x;
-        PolyBlob bl = {j0, jn, a0.y, a0.z, a0.w, a1.y, a1.z};
-        if (jn - j0 + 1 != a0.x || a1.x > 1) bl = poly_largest_component(span, j0, jn);      // several pieces: cv2 takes the largest
-        const PolyResult pr = poly_detect(g, span, bl);
-        if (g.lane() == 0) res[d] = pi32x4{pr.vis | pr.w << 8 | pr.h << 16, pr.sx | pr.sy << 16, pr.area2, 0};
+    }
+    pixel_wave_fence();
+    const int octets = 2 * nbig + nsmall;
+    const uint32_t* run = reinterpret_cast<const uint32_t*>(pool + P::kRun);
+    for (int base = wv * 8; base < octets; base += 8 * WAVES) {                                   // (uniform over the wave)
+        const int o = base + (lane >> 3);
+        if (o < octets) {
+            const uint32_t en = sched[o];
+            const int id = (int)(en & 255u), half = (int)((en >> 8) & 1u);
+            const DppGroup g{(lane & 7) + 8 * half, ((en >> 9) & 1u) != 0u};
+            float* blk = pool + (id >> 6) * P::kTileWords;
+            const int d = id & (kTile - 1);
+            const Vec4<T>* cb = reinterpret_cast<const Vec4<T>*>(blk);
+            // the group's scratch: that of its first octet (a 16-lane group's second octet lies right behind): table, then list
+            float* oct = pool + P::kOct + (wv * 8 + (lane >> 3) - half) * P::kOctWords;
+            uint16_t* tab = reinterpret_cast<uint16_t*>(oct) + 2;                                 // (tab[-1] and tab[rows] frame the rows)
+            uint16_t* lst = reinterpret_cast<uint16_t*>(oct + (g.wide ? 2 : 1) * P::kTabWords);
+            const Vec4<T> qu = cb[d], qv = cb[kTile + d], qs = cb[2 * kTile + d], qr = cb[3 * kTile + d];
+            const T u[4] = {qu.x, qu.y, qu.z, qu.w}, v[4] = {qv.x, qv.y, qv.z, qv.w}, sl[4] = {qs.x, qs.y, qs.z, qs.w};
+            const int jlo = (int)qr.x, nrows = (int)qr.y - jlo + 1;
+            for (int k = g.lane(); k < nrows; k += g.size()) {
+                T fa, fb;
+                const bool have = row_span(u, v, sl, (T)(jlo + k) + T(0.5), fa, fb);
+                tab[k] = have ? (uint16_t)(int)(fb * T(256) + fa) : (uint16_t)0x00FFu;
+            }
+            if (g.lane() == 0) { tab[-1] = (uint16_t)0x00FFu; tab[nrows] = (uint16_t)0x00FFu; }
+            pixel_wave_fence();
+            const PolyResult pr = poly_blob<kPolyPoints>(g, tab, lst, run, jlo, nrows);
+            if (g.lane() == 0)
+                reinterpret_cast<pi32x4*>(blk + P::kRes)[d] = pi32x4{pr.vis | pr.w << 8 | pr.h << 16, pr.sx | pr.sy << 16, pr.area2, 0};
+        }
+        pixel_wave_fence();                                    // (the next round reuses tables and lists)
     }
 }
 
 // Owner lanes, after the contours: obs[7:9, 11, 13, 14] of this lane's drone (hover.py:197-213, :245-248).  Returns visible.
-template <typename T, int WORKERS, int CAP>
-__device__ __forceinline__ bool pixel_tile_features(const float* pix, int lane, T& cx, T& cy, T& area, T& ratio) {
-    using P = PixTile<T, WORKERS, CAP>;
-    const pi32x4* acc = reinterpret_cast<const pi32x4*>(pix + P::kAcc);
-    const bool cand = pixel_candidate(acc[lane], acc[kTile + lane], acc[2 * kTile + lane]);
-    const pi32x4 r = reinterpret_cast<const pi32x4*>(pix + P::kRes)[lane];
-    const bool vis = cand && (r.x & 1) != 0;
+template <typename T, int TILES, int WAVES>
+__device__ __forceinline__ bool pixel_tile_features(const float* pool, int tile, int lane, T& cx, T& cy, T& area, T& ratio) {
+    using P = PixPool<T, TILES, WAVES>;
+    const float* blk = pool + tile * P::kTileWords;
+    const Vec4<T> mine = reinterpret_cast<const Vec4<T>*>(blk)[3 * kTile + lane];
+    const pi32x4 r = reinterpret_cast<const pi32x4*>(blk + P::kRes)[lane];
+    const bool vis = mine.x <= mine.y && (r.x & 1) != 0;
     cx = cy = area = ratio = T(0);
     if (vis) {
         cx = (T)(r.y & 0xFFFF) * T(1.0 / 256.0) - T(1);        // hover.py:197-203: mean of four integers / 64 - 1, exact (also in the
@@ -243,27 +221,17 @@ __device__ __forceinline__ bool pixel_tile_features(const float* pix, int lane, 
     return vis;
 }
 
-// One wave owns the tile and works its items itself (the stand-alone env-step kernels): LDS operations of a wave execute in
+// One wave owns its tile and works its blobs itself (the stand-alone env-step kernels): LDS operations of a wave execute in
 // program order, so between the phases only the compiler has to be kept from reordering them.
-__device__ __forceinline__ void pixel_wave_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-constexpr int kPixCapOneWave = 2048;                           // 4 KB of span table per tile: four tiles still share a workgroup
 template <typename T>
-using OneWavePixT = PixTile<T, kTile, kPixCapOneWave>;
+using OneWavePixT = PixPool<T, 1, 1>;
 template <typename T>
 __device__ __forceinline__ bool camera_features_pixel_tile(const Drone<T>& d, float* pix, int lane, T& cx, T& cy, T& area, T& ratio) {
-    T jlo, jhi;
-    pixel_tile_setup<T, kTile, kPixCapOneWave>(d, pix, lane, jlo, jhi);
-    pixel_post_items<T, kTile, kPixCapOneWave>(pix, lane, (int)jlo, (int)jhi);
+    pixel_tile_setup<T, 1, 1>(d, pix, 0, lane);
     pixel_wave_fence();
-    pixel_work_items<T, kTile, kPixCapOneWave>(pix, lane);
+    pixel_pool_contours<T, 1, 1>(pix, 0, lane);
     pixel_wave_fence();
-    pixel_tile_contours<T, kTile, kPixCapOneWave>(pix, lane);
-    pixel_wave_fence();
-    return pixel_tile_features<T, kTile, kPixCapOneWave>(pix, lane, cx, cy, area, ratio);
+    return pixel_tile_features<T, 1, 1>(pix, 0, lane, cx, cy, area, ratio);
 }
 
 }  // namespace fpv

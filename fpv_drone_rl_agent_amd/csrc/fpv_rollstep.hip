@@ -57,12 +57,13 @@ constexpr int kRsXch = kRsTile + 4 * kRsTileFloats;         // per tile: 128 dou
 constexpr int kRsSum = kRsXch + 4 * 256;                    // 4 x kPartialWords doubles
 static_assert((kRsXch * 4) % 8 == 0 && (kRsSum * 4) % 8 == 0, "fp64 areas must be 8-byte aligned");
 static_assert(kRsSum + 2 * 4 * kPartialWords <= 2 * kNetFloats, "phase-2 exchange must fit in the weight image's space");
-// Pixel detector (hover.py:157-222, SPEC §6b): the blob's rows as work items of the tile's two waves (fpv_pixel_tile.h).  Per tile,
-// above the rest of the phase-2 map: corner block, accumulators, item list and a span table that holds every row a tile can have.
-using RsPix = PixTile<float, 2 * kTile, kTile * 128>;
+// Pixel detector (hover.py:157-222, SPEC §6b): the blobs of the workgroup's four tiles are worked by lane groups of all eight waves
+// (fpv_pixel_tile.h).  Above the rest of the phase-2 map: per tile corner block and results, then the schedule and per octet of
+// lanes a span table and a contour list.
+using RsPix = PixPool<float, 4, 8>;
 constexpr int kRsPix = kRsSum + 2 * 4 * kPartialWords;
 static_assert((kRsPix * 4) % 16 == 0, "16-byte areas must be 16-byte aligned");
-static_assert(kRsPix + 4 * RsPix::kWords <= 2 * kNetFloats, "the pixel detector's exchange must fit in the weight image's space");
+static_assert(kRsPix + RsPix::kWords <= 2 * kNetFloats, "the pixel detector's exchange must fit in the weight image's space");
 
 // Workgroup barrier that publishes LDS only: waits for this wave's LDS operations, not for its global stores.  __syncthreads()
 // drains vmcnt too, and in these kernels every barrier would then wait out the ~1-2 us of the rollout-buffer / ledger / flag
@@ -255,9 +256,9 @@ struct TailOut {
     bool row_write_through;  // publish the row with sc1 stores + drain (read by other workgroups inside this launch)
     bool store_state;        // the physics wave stores its tile's state and tick itself, ahead of barrier 6 (one-step kernel)
     uint64_t* stamps;        // diagnostic: s_memrealtime values of tile 0's waves, or null: [0..3] physics wave: pairs done, observed,
-                             // barrier 6, 7; pixel detector: [4] corners projected, border pre-check done, [5] item list posted (before
-                             // barrier P), [6] P passed, [7] own items done, [8] barrier Q passed, [9] own contours done (before
-                             // barrier R); helper wave: [10] attitude converted (before barrier P), [11] its items done
+                             // barrier 6, 7; pixel detector: [4] corners projected, border pre-check done (before barrier P), [6] P
+                             // passed, [7] its groups' blobs done, [8] barrier R passed; helper wave: [10] attitude converted
+                             // (before barrier P), [11] its groups' blobs done
 };
 
 // Physics-wave registers that live across steps in the persistent kernel; the one-step kernel loads / stores them around
@@ -269,7 +270,7 @@ struct TileRegs {
     float tmpl_lane;
 };
 
-// Called by all 512 threads after the clipped actions are in LDS (kRsAct) and a workgroup barrier.  Contains eight (twelve with the
+// Called by all 512 threads after the clipped actions are in LDS (kRsAct) and a workgroup barrier.  Contains eight (eleven with the
 // pixel detector) workgroup barriers on every path.  On return the four observation tiles (+ returns) are still in LDS (kRsTile).
 // (Measured and not kept: a two-party LDS arrival counter per tile in place of the workgroup barriers between a tile's two waves —
 // no waiting for the slowest of the four tiles at every hand-off, but each hand-off then costs an LDS poll: 68.45 vs 68.63 us per
@@ -286,7 +287,7 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
     T(*nz)[8][kTile] = reinterpret_cast<T(*)[8][kTile]>(lds + kRsNoise + tl * (2 * 8 * kTile));
     Vec4<T>* tl_lds = reinterpret_cast<Vec4<T>*>(lds + kRsTile + tl * kRsTileFloats);
     double* bsum = reinterpret_cast<double*>(lds + kRsSum);
-    float* pix = lds + kRsPix + tl * RsPix::kWords;   // pixel detector: this tile's corner block, accumulators, item list, span table
+    float* pix = lds + kRsPix;                         // pixel detector: the workgroup's pool (fpv_pixel_tile.h)
 
     if (helper) {
         // ---- noise producer: pair k is published before barrier k (fpv_step.hip, step_kernel_pair)
@@ -299,9 +300,9 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
             slot[4][lane] = gb[0]; slot[5][lane] = gb[1]; slot[6][lane] = gb[2]; slot[7][lane] = gb[3];
             lds_barrier();
         }
-        if (s.detector) {                                  // uniform: the pixel detector's rows are work items of both waves
+        if (s.detector) {                                  // uniform: the pixel detector's blobs are spread over both waves
             lds_barrier();                                 // barrier P0: attitude and previous Euler angles of the tile's drones are in LDS
-            {   // This wave converts the attitude (Euler angles, obs[0:7]) while the physics wave prepares the detector's work items.
+            {   // This wave converts the attitude (Euler angles, obs[0:7]) while the physics wave projects the corners.
                 f32x4* att = reinterpret_cast<f32x4*>(nz);  // the noise slots are free once pair 5 has been read
                 const f32x4 q = att[lane], pe = att[kTile + lane];
                 T roll, pitch, yaw, o7[7];
@@ -312,13 +313,56 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
                 att[2 * kTile + lane] = f32x4{o7[5], o7[6], 0.f, 0.f};
             }
             if (o_.stamps && threadIdx.x == 256) o_.stamps[10] = __builtin_amdgcn_s_memrealtime();
-            lds_barrier();                                 // barrier P: corner block and item list of this tile are in LDS
-            pixel_work_items<float, 2 * kTile, kTile * 128>(pix, kTile + lane);
-            if (o_.stamps && threadIdx.x == 256) o_.stamps[11] = __builtin_amdgcn_s_memrealtime();
-            lds_barrier();                                 // barrier Q: every item's run is in LDS
-            pixel_tile_contours<float, 2 * kTile, kTile * 128>(pix, kTile + lane);
-            lds_barrier();                                 // barrier R: every blob's contour result is in LDS
         }
+    }
+    // ---------------- physics wave, first part: the sub-steps, then the corners of its drones' panels
+    Drone<T>& d = tr.d;
+    Vec4<T> act = Vec4<T>{T(0), T(0), T(0), T(-1)};
+    T ret_in = T(0);
+    if (!helper) {
+        const f32x4 av = reinterpret_cast<const f32x4*>(lds + kRsAct)[tl * kTile + lane];
+        if (live) act = Vec4<T>{av.x, av.y, av.z, av.w};
+        if (s.ret && live) ret_in = s.ret[i];
+        const T spx = act.x * T(30), spy = act.y * T(30), spz = act.z * T(-30);
+        const T thrust = clip_((act.w + T(1)) * T(0.5), T(0), T(1));
+        T pwm[4];
+#pragma unroll 1
+        for (int k = 0; k < kSubstepPairs; ++k) {
+            lds_barrier();   // barrier k: pair k's noise is in nz[k & 1]
+            T(*slot)[kTile] = nz[k & 1];
+            const T ga[4] = {slot[0][lane], slot[1][lane], slot[2][lane], slot[3][lane]};
+            const T gb[4] = {slot[4][lane], slot[5][lane], slot[6][lane], slot[7][lane]};
+            control_tick(d, spx, spy, spz, thrust, pwm);
+            physics_substep<T, true>(d, pwm, s.sigma, ga);
+            physics_substep<T, true>(d, pwm, s.sigma, gb);
+        }
+        if (o_.stamps && threadIdx.x == 0) o_.stamps[0] = __builtin_amdgcn_s_memrealtime();
+        if (s.detector) {
+            // Pixel detector (hover.py:157-222, SPEC §6b).  A drone's blob is 0 .. ~60 image rows and a fifth of the drones have one
+            // at all: one lane working its own drone's blob keeps the wave busy for the slowest one while most lanes idle, and the
+            // helper wave has nothing to do until barrier 6.  So the blobs of the workgroup's four tiles are spread over all EIGHT
+            // waves: this wave projects the corners and drops the blobs that cannot be seen whole (exact pre-check) — the helper
+            // converts the attitude (Euler angles, obs[0:7]) meanwhile; then every wave's lane groups (8 lanes, 16 for the tall
+            // blobs) take a blob each: its rows' spans, cv2's contour, cv2.arcLength, cv2.approxPolyDP (fpv_pixel_tile.h,
+            // fpv_polydp.h); this wave reads its drones' results.
+            f32x4* att = reinterpret_cast<f32x4*>(nz);        // the noise slots are free once pair 5 has been read
+            att[lane] = f32x4{d.qx, d.qy, d.qz, d.qw};
+            att[kTile + lane] = f32x4{d.er, d.ep, d.eyaw, 0.f};
+            lds_barrier();                                     // barrier P0: the helper converts the attitude from here on
+            pixel_tile_setup<float, 4, 8>(d, pix, tl, lane);
+            if (o_.stamps && threadIdx.x == 0) o_.stamps[4] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+    // ---------------- every wave: the blobs (one copy of this code for both kinds of wave)
+    if (s.detector) {
+        lds_barrier();                                         // barrier P: the four tiles' corner blocks are in LDS
+        if (o_.stamps && threadIdx.x == 0) o_.stamps[6] = __builtin_amdgcn_s_memrealtime();
+        pixel_pool_contours<float, 4, 8>(pix, wave, lane);
+        if (o_.stamps && (threadIdx.x & 255) == 0) o_.stamps[helper ? 11 : 7] = __builtin_amdgcn_s_memrealtime();
+        lds_barrier();                                         // barrier R: every blob's result is in LDS
+        if (o_.stamps && threadIdx.x == 0) o_.stamps[8] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (helper) {
         lds_barrier();   // barrier 6: the physics wave has staged the observation tile (and the returns)
         const int64_t rows_left = s.n - tile * kTile;
         // the moment sums come first: their in-wave exchange fences would otherwise wait out the tile's global stores
@@ -349,63 +393,19 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
         return;
     }
 
-    // ---------------- physics wave
-    Drone<T>& d = tr.d;
-    const f32x4 av = reinterpret_cast<const f32x4*>(lds + kRsAct)[tl * kTile + lane];
-    const Vec4<T> act = live ? Vec4<T>{av.x, av.y, av.z, av.w} : Vec4<T>{T(0), T(0), T(0), T(-1)};
-    T ret_in = T(0);
-    if (s.ret && live) ret_in = s.ret[i];
-    const T spx = act.x * T(30), spy = act.y * T(30), spz = act.z * T(-30);
-    const T thrust = clip_((act.w + T(1)) * T(0.5), T(0), T(1));
-    T pwm[4];
-#pragma unroll 1
-    for (int k = 0; k < kSubstepPairs; ++k) {
-        lds_barrier();   // barrier k: pair k's noise is in nz[k & 1]
-        T(*slot)[kTile] = nz[k & 1];
-        const T ga[4] = {slot[0][lane], slot[1][lane], slot[2][lane], slot[3][lane]};
-        const T gb[4] = {slot[4][lane], slot[5][lane], slot[6][lane], slot[7][lane]};
-        control_tick(d, spx, spy, spz, thrust, pwm);
-        physics_substep<T, true>(d, pwm, s.sigma, ga);
-        physics_substep<T, true>(d, pwm, s.sigma, gb);
-    }
-    if (o_.stamps && threadIdx.x == 0) o_.stamps[0] = __builtin_amdgcn_s_memrealtime();
+    // ---------------- physics wave, second part
     T roll, pitch, yaw;
     T o[kObsWords];
     bool vis;
     T cam_x, cam_y, cam_area, cam_ratio;
     if (s.detector) {
-        // Pixel detector (hover.py:157-222, SPEC §6b).  A drone's blob is 0 .. ~45 image rows and a third of the drones see the
-        // panel at all: one lane walking its own drone's rows keeps the wave busy for the tallest blob while most lanes idle
-        // (measured: 35 rows per tile against 7.8 per drone), and the helper wave has nothing to do until barrier 6.  So the rows
-        // become work items of BOTH waves: this wave projects the corners, drops the blobs that touch the image border (exact
-        // pre-check), cuts every other drone's rows into chunks and posts the items — the helper converts the attitude
-        // (Euler angles, obs[0:7]) meanwhile; the 128 lanes each walk an item, adding its run to the drone's accumulators and
-        // leaving the rows' spans; then the eight 16-lane groups of the two waves work the surviving blobs' contours
-        // (cv2.arcLength, cv2.approxPolyDP: fpv_polydp.h) and this wave reads its drones' results.
-        f32x4* att = reinterpret_cast<f32x4*>(nz);        // the noise slots are free once pair 5 has been read
-        att[lane] = f32x4{d.qx, d.qy, d.qz, d.qw};
-        att[kTile + lane] = f32x4{d.er, d.ep, d.eyaw, 0.f};
-        lds_barrier();                                     // barrier P0: the helper converts the attitude from here on
-        T jlo, jhi;
-        pixel_tile_setup<float, 2 * kTile, kTile * 128>(d, pix, lane, jlo, jhi);
-        if (o_.stamps && threadIdx.x == 0) o_.stamps[4] = __builtin_amdgcn_s_memrealtime();
-        pixel_post_items<float, 2 * kTile, kTile * 128>(pix, lane, (int)jlo, (int)jhi);
-        if (o_.stamps && threadIdx.x == 0) o_.stamps[5] = __builtin_amdgcn_s_memrealtime();
-        lds_barrier();                                     // barrier P
-        if (o_.stamps && threadIdx.x == 0) o_.stamps[6] = __builtin_amdgcn_s_memrealtime();
-        pixel_work_items<float, 2 * kTile, kTile * 128>(pix, lane);
-        if (o_.stamps && threadIdx.x == 0) o_.stamps[7] = __builtin_amdgcn_s_memrealtime();
-        lds_barrier();                                     // barrier Q
-        if (o_.stamps && threadIdx.x == 0) o_.stamps[8] = __builtin_amdgcn_s_memrealtime();
-        pixel_tile_contours<float, 2 * kTile, kTile * 128>(pix, lane);
-        if (o_.stamps && threadIdx.x == 0) o_.stamps[9] = __builtin_amdgcn_s_memrealtime();
-        lds_barrier();                                     // barrier R
+        f32x4* att = reinterpret_cast<f32x4*>(nz);
         {
             const f32x4 t0 = att[lane], t1 = att[kTile + lane], t2 = att[2 * kTile + lane];
             roll = t0.x; pitch = t0.y; yaw = t0.z;
             o[0] = t0.w; o[1] = t1.x; o[2] = t1.y; o[3] = t1.z; o[4] = t1.w; o[5] = t2.x; o[6] = t2.y;
         }
-        vis = pixel_tile_features<float, 2 * kTile, kTile * 128>(pix, lane, cam_x, cam_y, cam_area, cam_ratio);
+        vis = pixel_tile_features<float, 4, 8>(pix, tl, lane, cam_x, cam_y, cam_area, cam_ratio);
     } else {
         euler_from_quat(d.qx, d.qy, d.qz, d.qw, roll, pitch, yaw);
         T o7[7];
@@ -703,7 +703,7 @@ hipError_t launch_step_quad(const StepArgs<float>& st, uint64_t* stamps, hipStre
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
     bool& attr_set = attr_tab[dev_ & 63];
-    constexpr int kPixelBytes = (kRsPix + 4 * RsPix::kWords) * 4, kAnalyticBytes = kRsPix * 4;
+    constexpr int kPixelBytes = (kRsPix + RsPix::kWords) * 4, kAnalyticBytes = kRsPix * 4;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)step_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kPixelBytes);
         if (e != hipSuccess) return e;
@@ -731,7 +731,7 @@ struct RollStepSplitArgs {
     StepArgs<float> st;
     uint64_t* stamps;
 };
-constexpr int kRsSplitLdsBytes = (kRsPix + 4 * RsPix::kWords) * 4 > kSplitLdsBytes ? (kRsPix + 4 * RsPix::kWords) * 4 : kSplitLdsBytes;
+constexpr int kRsSplitLdsBytes = (kRsPix + RsPix::kWords) * 4 > kSplitLdsBytes ? (kRsPix + RsPix::kWords) * 4 : kSplitLdsBytes;
 
 #pragma clang fp contract(fast)
 __global__ __launch_bounds__(512) void rollout_step_split_kernel(RollStepSplitArgs p) {

@@ -60,14 +60,18 @@ else:
     edges = [s[:, 2], s[:, 4], s[:, 5], s[:, 6], s[:, 7]]
     out["env step, physics wave"] = {nm: round(float(np.median(edges[k + 1] - edges[k])), 2) for k, nm in enumerate(tn)}
     if eng.detector == "pixel":
-        # pixel detector, tile 0: physics wave [8] corners projected + border pre-check done, [9] item list posted (before barrier P),
-        # [10] P passed, [11] own items done, [12] barrier Q passed, [13] features done; helper wave [14] attitude converted, [15] items done
+        # pixel detector (round 4): wave 0 [8] corners projected + border pre-check done (before barrier P), [10] P passed, [11] its
+        # lane groups' blobs done, [12] barrier R passed; wave 4 (tile 0's helper) [14] attitude converted, [15] its groups' blobs done
         med = lambda a, b: round(float(np.median(s[:, b] - s[:, a])), 2)
-        out["pixel detector, physics wave"] = {"barrier P0 + corner projection + border pre-check": med(4, 8), "item list": med(8, 9),
-                                               "barrier P": med(9, 10), "its work items": med(10, 11),
-                                               "wait for the workgroup (barrier Q)": med(11, 12), "accumulators + vertices + gates": med(12, 13),
-                                               "observation + reward": med(13, 5)}
-        out["pixel detector, helper wave"] = {"pairs done -> attitude converted": med(4, 14), "its work items (from P)": med(10, 15)}
+        q = lambda a, b, p: round(float(np.percentile(s[:, b] - s[:, a], p)), 2)
+        out["pixel detector, wave 0"] = {"barrier P0 + corner projection + border pre-check": med(4, 8), "barrier P": med(8, 10),
+                                         "its lane groups' blobs (spans, contour, arcLength, approxPolyDP)": med(10, 11),
+                                         "the same, p90 / max over the workgroups": [q(10, 11, 90), q(10, 11, 100)],
+                                         "wait for the workgroup (barrier R)": med(11, 12),
+                                         "P passed -> R passed, median / p90 / max": [med(10, 12), q(10, 12, 90), q(10, 12, 100)],
+                                         "observation + reward": med(12, 5)}
+        out["pixel detector, wave 4"] = {"pairs done -> attitude converted": med(4, 14), "its lane groups' blobs (from P)": med(10, 15),
+                                         "the same, p90 / max over the workgroups": [q(10, 15, 90), q(10, 15, 100)]}
     out["workgroup"] = {"median_us": round(float(np.median(s[:, 3] - s[:, 0])), 2)}
     out["launch_first_start_to_last_end_us"] = round(float(s[:, 3].max() - s[:, 0].min()), 2)
     out["start_skew_us"] = round(float(s[:, 0].max() - s[:, 0].min()), 2)
