@@ -10,8 +10,8 @@
 //     beside the image, touching its border: pixel_touches_border is exact); corners, slopes and row range go to LDS.
 //  2. The waves of the pool — the tile's one wave in the stand-alone step kernels, all eight waves of the workgroup for its four
 //     tiles in fpv_rollstep.hip — each derive the same schedule from the row ranges: the tallest blobs first, 16 lanes (one DPP
-//     row) each — as many of them as one round of the pool's lanes has room for —, then the others, 8 lanes each; "octet" o of the schedule is worked by lanes 8 (o mod 8)
-//     .. of wave (o / 8) mod waves in round o / (8 waves).  A group evaluates its blob's rows into its private span table, then
+//     row) each — as many of them as one round of the pool's lanes has room for —, then the others, 8 lanes each; "octet" o of
+//     the schedule is worked by lanes 8 (o mod 8) .. of wave (o / 8) mod waves in round o / (8 waves).  A group evaluates its blob's rows into its private span table, then
 //     runs fpv_polydp.h's poly_blob on it: statistics and cv2's CHAIN_APPROX_SIMPLE contour in one pass over the table, the
 //     contour into registers, arcLength, Douglas-Peucker with its farthest-point sweeps spread over the group's lanes (DPP
 //     reductions), the clean-up pass.  The result (visible, vertex sums, 2 x contourArea, boundingRect) goes to the drone's
@@ -53,6 +53,17 @@ struct PixPool {
     static constexpr int kWords = (kOct + 8 * WAVES * kOctWords + 7) / 8 * 8;
     static_assert((kTileWords * 4) % 32 == 0 && 2 * kTabWords * 2 >= 132, "aligned tiles; a 16-lane group's table holds 128 rows + frame");
 };
+
+// Inclusive sum over the 64 lanes on the VALU (DPP row shifts, then the row broadcasts gfx9 keeps): lane 63 holds the total.
+__device__ __forceinline__ int wave_scan_inclusive(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);    // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);    // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);    // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);    // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);    // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2, 3
+    return x;
+}
 
 __device__ __forceinline__ void pixel_wave_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -130,16 +141,18 @@ __device__ __forceinline__ void pixel_pool_contours(float* pool, int wv, int lan
     using P = PixPool<T, TILES, WAVES>;
     // ---- the schedule, derived by every wave for itself (the waves write the same values to the same places).  Blobs of more
     // than `big` rows get 16 lanes; `big` is the smallest of 16, 20, 24, 28, 36 with which one round serves every blob (8 WAVES
-    // octets), 36 when none does.
-    int rows[TILES], ncand = 0, n16 = 0, n20 = 0, n24 = 0, n28 = 0, n36 = 0;
+    // octets), 36 when none does.  The six counts are summed over the wave as 10-bit fields of two words.
+    int rows[TILES], f0 = 0, f1 = 0;
 #pragma unroll
     for (int k = 0; k < TILES; ++k) {
         const Vec4<T> qr = reinterpret_cast<const Vec4<T>*>(pool + k * P::kTileWords)[3 * kTile + lane];
         rows[k] = (int)qr.y - (int)qr.x + 1;
-        ncand += __popcll(__ballot(rows[k] > 0));
-        n16 += __popcll(__ballot(rows[k] > 16)); n20 += __popcll(__ballot(rows[k] > 20)); n24 += __popcll(__ballot(rows[k] > 24));
-        n28 += __popcll(__ballot(rows[k] > 28)); n36 += __popcll(__ballot(rows[k] > 36));
+        f0 += (rows[k] > 0 ? 1 : 0) + (rows[k] > 16 ? 1 << 10 : 0) + (rows[k] > 20 ? 1 << 20 : 0);
+        f1 += (rows[k] > 24 ? 1 : 0) + (rows[k] > 28 ? 1 << 10 : 0) + (rows[k] > 36 ? 1 << 20 : 0);
     }
+    f0 = __builtin_amdgcn_readlane(wave_scan_inclusive(f0), 63);
+    f1 = __builtin_amdgcn_readlane(wave_scan_inclusive(f1), 63);
+    const int ncand = f0 & 1023, n16 = (f0 >> 10) & 1023, n20 = f0 >> 20, n24 = f1 & 1023, n28 = (f1 >> 10) & 1023;
     const int room = 8 * WAVES - ncand;                          // octets left for second halves
     const int big = n16 <= room ? 16 : (n20 <= room ? 20 : (n24 <= room ? 24 : (n28 <= room ? 28 : 36)));
     int nbig = 0, nsmall = 0;

@@ -423,28 +423,41 @@ __host__ __device__ __forceinline__ PolyResult poly_blob(const Grp& g, const uin
     const int shift = S - P;                                       // list position of point p >= baseL: p + shift
     uint32_t pt[TRC];
     int gi = 0, gf = 0;
-    {
-        // every read is issued before the first one is used (three LDS round trips in all, not three per block of W points)
-        uint32_t nx[TRC];
+    // every read of a half of the registers is issued before the first one is used: three LDS round trips per half, not three
+    // per block of W points; the second half only when some blob of the wave has that many points
 #pragma unroll
-        for (int t = 0; t < TRC; ++t) {
-            const int p = t * W + l;
-            int q = p + 1;
-            if (q >= P) q = 0;
-            const bool in = p < P;
-            pt[t] = list[in ? (p < baseL ? p : p + shift) : 0];
-            nx[t] = list[in ? (q < baseL ? q : q + shift) : 0];
-        }
-        uint32_t gv[TRC];
+    for (int t = 0; t < TRC; ++t) pt[t] = 0u;
 #pragma unroll
-        for (int t = 0; t < TRC; ++t) {
-            const int adx = iabs((int)(nx[t] & 255u) - (int)(pt[t] & 255u)), ady = iabs((int)(nx[t] >> 8) - (int)(pt[t] >> 8));
-            gv[t] = gtab[ady & (0 - (int)((adx == ady) & (adx != 0) & (int)(t * W + l < P)))];     // a run of |dy| diagonal steps
-        }
+    for (int h = 0; h < 2; ++h) {
+        constexpr int kHalf = (TRC + 1) / 2;
+        if (h == 0 || kHalf * W < P) {
+            uint32_t nx[kHalf], gv[kHalf];
 #pragma unroll
-        for (int t = 0; t < TRC; ++t) {
-            gi += (int)(gv[t] >> 23);
-            gf += (int)(gv[t] & 0x7FFFFFu);
+            for (int t = 0; t < kHalf; ++t) {
+                if (h * kHalf + t < TRC) {
+                    const int p = (h * kHalf + t) * W + l;
+                    int q = p + 1;
+                    if (q >= P) q = 0;
+                    const bool in = p < P;
+                    pt[h * kHalf + t] = list[in ? (p < baseL ? p : p + shift) : 0];
+                    nx[t] = list[in ? (q < baseL ? q : q + shift) : 0];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < kHalf; ++t) {
+                if (h * kHalf + t < TRC) {
+                    const uint32_t me = pt[h * kHalf + t];
+                    const int adx = iabs((int)(nx[t] & 255u) - (int)(me & 255u)), ady = iabs((int)(nx[t] >> 8) - (int)(me >> 8));
+                    gv[t] = gtab[ady & (0 - (int)((adx == ady) & (adx != 0) & (int)((h * kHalf + t) * W + l < P)))];   // a run of |dy| diagonal steps
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < kHalf; ++t) {
+                if (h * kHalf + t < TRC) {
+                    gi += (int)(gv[t] >> 23);
+                    gf += (int)(gv[t] & 0x7FFFFFu);
+                }
+            }
         }
     }
     gi = g.add_i32(gi);
