@@ -180,6 +180,34 @@ def plumbing_only(args) -> None:
         td.destroy_process_group()
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher around it (no RANK / WORLD_SIZE in the environment): this process makes NO
+    GPU call — it starts the N ranks as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port <free> bench.py <same arguments>` (the driver's own launch line), hands rank 0's one JSON line on to stdout and
+    returns the launcher's exit code.  The reference's counterpart is make_vec_env(..., n_envs=16, vec_env_cls=SubprocVecEnv)
+    (simulation/train_hover.py:41-42): worker processes started by the script itself."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver stack
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in proc.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    elif proc.returncode == 0:
+        print("bench.py: the ranks ended without a result line", file=sys.stderr)
+        return 4
+    return proc.returncode
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -207,6 +235,8 @@ def main() -> None:
     ap.add_argument("--two-launch", action="store_true",
                     help="policy forward and env step as two kernels per rollout step (the default is fpv_rollout_step: one)")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
 
     import torch
     import torch.distributed as td

@@ -159,13 +159,16 @@ __global__ void advantage_stats_kernel(const double* __restrict__ gathered, int 
 // (the inverse of RunningMeanStd.update_from_moments) — and the ranks' batches are merged into `base` in rank order with that
 // very update: every rank derives the same bits, and they are the moments of the union of all ranks' samples.
 // One thread per channel; gathered rows: [adv stats 3][obs mean d, var d, count][ret mean, var, count].
-__global__ void rank_merge_kernel(const double* __restrict__ gathered, int world, int stride, int d, const double* __restrict__ base_obs,
-                                  const double* __restrict__ base_ret, double* __restrict__ out_obs, double* __restrict__ out_ret) {
+// The bases may BE the outputs (in-place use): the four pointers are not restrict-qualified, every thread reads its base words
+// before any thread of the launch — one wave — stores.
+__global__ void rank_merge_kernel(const double* __restrict__ gathered, int world, int stride, int d, const double* base_obs,
+                                  const double* base_ret, double* out_obs, double* out_ret) {
     const int c = threadIdx.x;
     const bool obs_ch = c < d && base_obs != nullptr, ret_ch = c == d && base_ret != nullptr;
     if (!obs_ch && !ret_ch) return;
-    // (branches, not selects of two loads: either statistics may be left out, and the compiler is free to issue both loads of a
-    // select — one of them through a null pointer; seen once as a fault at address 0 while this kernel was being changed)
+    // (branches, not selects of two loads: either statistics may be left out.  Round 3 saw one fault at address 0 in this kernel while
+    // it was being changed — start() passes base_ret = null; the select form was the suspect, no ISA of the faulting build was
+    // kept, so the cause is unproven.  tests/test_rollout_ops_gpu.py calls the obs-only, ret-only and null-base forms directly.)
     double m0, v0, c0;
     if (obs_ch) { m0 = base_obs[c]; v0 = base_obs[d + c]; c0 = base_obs[2 * d]; }
     else { m0 = base_ret[0]; v0 = base_ret[1]; c0 = base_ret[2]; }

@@ -4,8 +4,8 @@ The default detector is the reference's pixel rules (docs/SPEC.md §6b, hover.py
 counts on a 128 x 128 grid.  The fp32 path carries ~1e-5 px of rounding in the projected corners (and in the fp32 state
 behind them), so an edge that passes that close to a pixel centre rasterises ONE pixel differently from the fp64 oracle: a
 one-pixel change of the bounding box, a few px^2 of contour, one pixel of one vertex, or the visibility decision itself when
-a gate sits on the boundary.  Such rows are rare (measured ~0.3 % of the drones that see the panel per step,
-profiles/r03_pixel_flip_rate.json) and cannot be avoided short of computing in fp64; `pixel_flips` finds them, bounds how
+a gate sits on the boundary.  Such rows are rare — measured 8 of 65 536 drones in one step, 0.012 %, none of them a visibility
+flip (profiles/r04_pixel_flip_rate.json; the budget below is 8 x that) — and cannot be avoided short of computing in fp64; `pixel_flips` finds them, bounds how
 many there are and how large the change is, and the callers hold every other row — and every word of the flipped rows that
 does not derive from the camera features — to the 1e-5 bar.
 """
@@ -20,9 +20,11 @@ def close(a, b, tol):
     return np.abs(a - b) <= tol * np.maximum(1.0, np.abs(b))
 
 
-def pixel_flips(obs, obs_ref, max_frac=0.01, tol=1e-5):
+def pixel_flips(obs, obs_ref, max_frac=0.001, tol=1e-5):
     """Rows whose camera features differ between the fp32 path and the oracle by more than `tol`.  Asserts that they are at most
-    `max_frac` of the rows (and at most 2 rows in small batches) and that each is a one-pixel effect."""
+    `max_frac` of the rows (and at most 2 rows in small batches) and that each is a one-pixel effect: a pixel more or less in the
+    contour, the bounding box or — since the vertices are cv2.approxPolyDP's, which may pick another contour point when a span end
+    moves — a vertex that moves along its edge by a few pixels (the centre is the mean of four vertices: 1 / 256 per pixel)."""
     obs, obs_ref = np.asarray(obs, np.float64), np.asarray(obs_ref, np.float64)
     bad = (np.abs(obs[:, FEATURE_OBS] - obs_ref[:, FEATURE_OBS]) > tol).any(axis=1)
     n = obs.shape[0]
@@ -31,7 +33,7 @@ def pixel_flips(obs, obs_ref, max_frac=0.01, tol=1e-5):
     if same_vis.any():
         assert np.abs(obs[same_vis, 11] - obs_ref[same_vis, 11]).max() <= 6 / 16384          # a few px^2 of contour
         assert np.abs(obs[same_vis, 14] - obs_ref[same_vis, 14]).max() <= 0.2                # one pixel of w or h
-        assert np.abs(obs[same_vis, 7:9] - obs_ref[same_vis, 7:9]).max() <= 2 / 128 + 1e-6   # one pixel of one vertex
+        assert np.abs(obs[same_vis, 7:9] - obs_ref[same_vis, 7:9]).max() <= 8 / 256 + 1e-6   # a vertex a few pixels along its edge
     return bad
 
 

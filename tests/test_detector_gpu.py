@@ -4,8 +4,8 @@ the oracle's restatement, through the C ABI.
 fp64 handle: every camera feature equal to 1e-12 (the integer decisions — row spans, bounding box, vertices, border and
 4-vertex gates — are the same arithmetic in the same order).  fp32 handle: the projected corners carry ~1e-5 px of
 rounding, so an edge that passes that close to a pixel centre rasterises one pixel differently; the test bounds how
-often (< 1 % of the drones) and by how much (one pixel in w / h, a few px^2 of area, one pixel of one vertex), and holds
-every other drone to the 1e-5 bar.
+often (< 0.1 % of the drones, no visibility flip: 8 x the measured 0.012 %) and by how much (one pixel in w / h, a few px^2 of
+area, a vertex a few pixels along its edge), and holds every other drone to the 1e-5 bar.
 """
 import numpy as np
 import pytest
@@ -95,13 +95,14 @@ def test_fp32_step_features_match_oracle_up_to_one_pixel_flips(oracle):
     with open(os.path.join(out, "pixel_flip_rate.json"), "w") as f:
         json.dump(rec, f, indent=1)
     print("pixel detector fp32 flip rate:", rec)
-    assert frac < 0.01, frac                                       # one-pixel rasterisation flips: rare
+    assert frac < 0.001, frac                                      # one-pixel rasterisation flips: measured 8 of 65 536 (1.2e-4); 8 x that
+    assert rec["visibility_flips"] == 0                            # ... and none of them changes the visibility decision here
     # ... and small: a visibility flip, or one pixel of w / h, a few px^2 of contour, one pixel of one vertex
     same_vis = bad & (obs[:, 13] == obs_r[:, 13])
     if same_vis.any():
         assert np.abs(obs[same_vis, 11] - obs_r[same_vis, 11]).max() <= 6 / 16384
         assert np.abs(obs[same_vis, 14] - obs_r[same_vis, 14]).max() <= 0.2
-        assert np.abs(obs[same_vis, 7:9] - obs_r[same_vis, 7:9]).max() <= 2 / 128 + 1e-6
+        assert np.abs(obs[same_vis, 7:9] - obs_r[same_vis, 7:9]).max() <= 8 / 256 + 1e-6      # a vertex a few pixels along its edge
     # everything else at the 1e-5 bar, rewards included
     good = ~bad & ~done
     assert np.abs(rew[good] - rew_r[good]).max() <= 2e-5 * max(1.0, np.abs(rew_r[good]).max())

@@ -129,3 +129,27 @@ def test_bench_launch_contract_under_torchrun_gloo():
     bad = subprocess.run(cmd[:-7] + ["--gpus", "4", "--steps", "20", "--warmup", "4", "--plumbing-only"], cwd=root,
                          capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "WORLD_SIZE=2" in (bad.stderr + bad.stdout)
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus 2` with a clean environment (no RANK / WORLD_SIZE): the parent touches no GPU, starts the two ranks
+    through torch.distributed.run itself, relays rank 0's ONE line and the ranks' exit code — what the reference does with
+    make_vec_env(..., n_envs=16, vec_env_cls=SubprocVecEnv) (simulation/train_hover.py:41-42).  GPU-free plumbing mode here; the
+    -m gpu twin runs real kernels (tests/test_facades_gpu.py)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                             "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "4",
+                          "--plumbing-only"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout                       # nothing but the one line on stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["total_drones"] == 2 * 65536 and rec["plumbing"]["gathered_rows"] == 2
+    # a failing rank fails the parent: --drones 0 is refused by the ranks' own argument check
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--n-steps", "0",
+                          "--plumbing-only"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0

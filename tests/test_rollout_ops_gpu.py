@@ -183,7 +183,18 @@ def test_rank_merge_kernel_matches_the_host_statement(oracle):
         ref_r = D.merge_rank_statistics(torch.from_numpy(b_r), torch.from_numpy(np.stack(rows))[:, 3 + 2 * d + 1:])
         assert torch.allclose(obs_rms.cpu(), ref_o, rtol=1e-13, atol=1e-13) and torch.allclose(ret_rms.cpu(), ref_r, rtol=1e-13, atol=1e-13)
         assert float(obs_rms[2 * d]) == base_o.count + 4 * 4 * 500
-        # in place (the collector's use): bases aliasing the outputs
+        # in place: bases that ARE the outputs (allowed: the kernel's four pointers are not restrict-qualified)
         o2, r2 = torch.from_numpy(b_o).cuda(), torch.from_numpy(b_r).cuda()
         ops.rank_merge(g, d, base_obs_rms=o2, base_ret_rms=r2, obs_rms=o2, ret_rms=r2)
         assert torch.equal(o2, obs_rms) and torch.equal(r2, ret_rms)
+        # one set of statistics only — the shapes RolloutCollector.start() uses (observation statistics of the reset observations,
+        # no return statistics yet: base_ret = null, the form that faulted at address 0 once in round 3) and its mirror
+        o3, r3 = torch.from_numpy(b_o).cuda(), torch.full((3,), -7.0, dtype=torch.float64, device="cuda")
+        ops.rank_merge(g, d, base_obs_rms=torch.from_numpy(b_o).cuda(), base_ret_rms=None, obs_rms=o3, ret_rms=None)
+        assert torch.equal(o3, obs_rms) and (r3 == -7.0).all()
+        o4, r4 = torch.full((2 * d + 1,), -7.0, dtype=torch.float64, device="cuda"), torch.from_numpy(b_r).cuda()
+        ops.rank_merge(g, d, base_obs_rms=None, base_ret_rms=torch.from_numpy(b_r).cuda(), obs_rms=None, ret_rms=r4)
+        assert torch.equal(r4, ret_rms) and (o4 == -7.0).all()
+        # an output without its base is an argument error, not a read through a null pointer
+        with pytest.raises(ValueError):
+            ops.rank_merge(g, d, base_obs_rms=None, base_ret_rms=torch.from_numpy(b_r).cuda(), obs_rms=o4, ret_rms=r4.clone())
