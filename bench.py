@@ -232,6 +232,7 @@ def main() -> None:
     ap.add_argument("--detector", choices=["analytic", "pixel"], default="pixel",
                     help="hover task camera features: the reference's 128x128 pixel rules (SPEC §6b, hover.py:157-222; the default and "
                          "the headline) or the continuous projection (§6)")
+    ap.add_argument("--no-f64-rollout", action="store_true", help="skip the extra rollout measurement on an fp64 engine (the reference's arithmetic type)")
     ap.add_argument("--two-launch", action="store_true",
                     help="policy forward and env step as two kernels per rollout step (the default is fpv_rollout_step: one)")
     args = ap.parse_args()
@@ -328,6 +329,32 @@ def main() -> None:
         col.set_policy_gemm("f32")
         col._one_launch = was_one
         col._graph = None
+
+    # ---- extra (not the headline): the same rollout with the env in the reference's own arithmetic type (float64 spaces,
+    # simulation/hover.py:61, :70): fp32 policy kernel + fpv_step_f64 + stand-alone normaliser kernels, no graph, host-synchronising
+    # timeout bootstrap (rollout.py).  A few rollouts only: it exists to be right, not to be fast. ----
+    f64_rollout_value = None
+    if not yaw and not args.no_f64_rollout:
+        eng64 = FpvEngine(n, dev, noise_ratio=0.02, seed=0, id_offset=rank * n, ledger_capacity=n * max(2, T // 8), detector=args.detector,
+                          precision="f64")
+        col64 = RolloutCollector(eng64, policy, n_steps=T)
+        col64.start()
+        eng64.set_state(torch.from_numpy(synthetic_states(n, seed=rank)).double())
+        col64.collect()
+        barrier()
+        t0 = time.perf_counter()
+        reps64 = 3
+        for _ in range(reps64):
+            col64.collect()
+        barrier()
+        el64 = time.perf_counter() - t0
+        if world > 1:
+            tm = torch.tensor([el64], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            td.all_reduce(tm, op=td.ReduceOp.MAX)
+            el64 = float(tm.item())
+        f64_rollout_value = n * world * T * reps64 / el64
+        eng64.close()
+        del col64, eng64
 
     # ---- rooflines: kernel-only passes in this process, HIP events on the launch stream (events cannot bracket a
     # node inside the replayed graph).  `roofline` is the kernel that dominates the timed region by time (the fused
@@ -604,6 +631,13 @@ def main() -> None:
             out.setdefault("extra", {})["value_f64_env"] = f64_value
             out["extra"]["value_f64_env_note"] = ("env-steps/s of fpv_step on an FPV_F64 handle (env step only, no policy, HIP events over "
                                                   f"{args.kernel_launches} launches): the reference's arithmetic type")
+        if f64_rollout_value is not None:
+            out.setdefault("extra", {})["value_rollout_f64_env"] = f64_rollout_value
+            out["extra"]["value_rollout_f64_env_note"] = ("env-steps/s of the SAME rollout with the env in the reference's arithmetic type (float64 "
+                                                          "spaces, simulation/hover.py:61, :70): fp32 policy kernel + fpv_step_f64 + stand-alone "
+                                                          "normaliser kernels, conversions at the seam, no HIP graph, host-synchronising timeout "
+                                                          "bootstrap; 3 rollouts, wall clock (tests/test_facades_gpu.py holds its env outputs to the "
+                                                          "oracle at 1e-9)")
         if world == 1 and not yaw and not args.no_host_mode:
             out.setdefault("extra", {})["cfg1_host_mode"] = host_mode_rate()
         if world == 1 and not args.no_cpu_baseline and not yaw:

@@ -25,6 +25,11 @@ Two step implementations:
     with each step's own statistics snapshot, which is arithmetically what VecNormalize does step by step.
   * unfused (`fused=False`): the same semantics through torch ops + the stand-alone normaliser
     kernels; kept as the readable reference of the fused path (tests compare both to the oracle).
+  * an fp64 engine (`FpvEngine(precision="f64")`): the configuration in the reference's own arithmetic type — its spaces are
+    float64 (simulation/hover.py:61, :70) and numpy / pybullet compute in double, while SB3's torch policy is float32.  The
+    policy kernel stays fp32; the env step is fpv_step_f64; observation, action and reward are converted at the seam; the
+    normaliser runs as its stand-alone kernels and the timeout bootstrap through the torch statement (host synchronisations:
+    this shape exists to be right, not to be fast).
 """
 from __future__ import annotations
 
@@ -39,6 +44,49 @@ from . import ops
 from .engine import FpvEngine
 from .ops_policy import FusedPolicy
 from .policy import ActorCritic
+
+
+def _hip_runtime():
+    """The HIP runtime this process already runs on (torch ships its own copy: a second dlopen by name could load another one)."""
+    import ctypes
+    path = None
+    with open("/proc/self/maps") as maps:
+        for line in maps:
+            if "libamdhip64" in line:
+                path = line.split()[-1]
+                break
+    return ctypes.CDLL(path or "libamdhip64.so")
+
+
+def _new_capture_stream(device):
+    """A stream of the collector's own to capture on.  torch.cuda.Stream() hands out one of 32 pooled streams per device in turn,
+    and torch.cuda.graph's default capture stream is one of them: a capture that fails leaves its stream "invalidated" for good
+    (hipStreamEndCapture does not bring it back on this stack), and sooner or later somebody is handed that stream again.  A stream
+    created here is nobody else's; after a failed capture it is simply abandoned."""
+    import ctypes
+    try:
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            rc = _hip_runtime().hipStreamCreateWithFlags(ctypes.byref(handle), ctypes.c_uint(1))       # hipStreamNonBlocking
+        if rc == 0 and handle.value:
+            return torch.cuda.ExternalStream(handle.value, device=device)
+    except (OSError, AttributeError):
+        pass
+    return torch.cuda.Stream(device)
+
+
+def _end_broken_capture(stream) -> None:
+    """A failed torch.cuda.graph capture leaves its stream capturing: end it (the call returns the error once more)."""
+    import ctypes
+    try:
+        hip = _hip_runtime()
+    except OSError:
+        return
+    graph = ctypes.c_void_p()
+    hip.hipStreamEndCapture(ctypes.c_void_p(stream.cuda_stream), ctypes.byref(graph))
+    if graph.value:
+        hip.hipGraphDestroy(graph)
+    hip.hipGetLastError()
 
 
 class _Batch(dict):
@@ -62,8 +110,11 @@ class RolloutCollector:
                  policy_gemm: str = "f32", overlap_critic: bool = False, merge_in_policy: bool = True,
                  fused_step: bool = True, merge_in_step: bool = False, one_launch: bool | None = None,
                  persistent: bool | None = None):
-        if engine.dtype != torch.float32:
-            raise ValueError("the rollout collector runs on an fp32 engine")
+        self._f64_env = engine.dtype == torch.float64
+        if self._f64_env:                                  # fp32 policy kernel + fpv_step_f64 + stand-alone normaliser kernels
+            if not fused:
+                raise ValueError("an fp64 engine is collected through the fused policy kernel (fused=True)")
+            fused_step, use_graph, one_launch, persistent, overlap_critic, merge_in_step = False, False, False, None, False, False
         from . import _lib as _L
         for flag, what in ((persistent, "persistent=True (the whole rollout as one launch)"),
                            (overlap_critic, "overlap_critic=True (the critic beside the env step)")):
@@ -101,6 +152,12 @@ class RolloutCollector:
         self.clipped = torch.zeros((N, A), dtype=f32, device=dev)
         self.last_val = torch.zeros((N,), dtype=f32, device=dev)
         self.snap = torch.zeros((T, max(44, 2 * O + 4)), dtype=torch.float64, device=dev)  # {obs_rms, ret_rms} after step t
+        if self._f64_env:
+            self._obs32 = torch.zeros((N, O), dtype=f32, device=dev)       # the env's fp64 outputs as the fp32 policy side sees them
+            self._rew32 = torch.zeros((N,), dtype=f32, device=dev)
+            self._clip64 = torch.zeros((N, A), dtype=torch.float64, device=dev)
+            self.env_obs = torch.zeros((T, N, O), dtype=torch.float64, device=dev)   # raw fp64 env outputs of the rollout, step by step
+            self.env_rew = torch.zeros((T, N), dtype=torch.float64, device=dev)
         self.fused = bool(fused)
         self._one_launch = self._one_launch_ok = False
         self._persistent = self._persistent_ok = False
@@ -236,6 +293,10 @@ class RolloutCollector:
         else:
             out.copy_(raw)
 
+    def _env_obs(self):
+        """The env's current observation as the fp32 policy side reads it."""
+        return self._obs32 if self._f64_env else self.engine.obs
+
     def _step(self, t: int) -> None:
         if self.fused:
             self._step_fused(t)
@@ -248,18 +309,27 @@ class RolloutCollector:
         """Fused policy kernel + the stand-alone env-step / normaliser kernels (`fused_step=False`: the reference of the
         in-kernel VecNormalize bookkeeping)."""
         eng = self.engine
-        self.fp.forward(eng.obs, rms=self.obs_norm.rms if self.norm_obs else None, tick=eng.tick_ptr,
+        obs, reward = self._env_obs(), (self._rew32 if self._f64_env else eng.reward)
+        self.fp.forward(obs, rms=self.obs_norm.rms if self.norm_obs else None, tick=eng.tick_ptr,
                         obs_n=self.buf_obs[t], action=self.buf_act[t], clipped=self.clipped, value=self.buf_val[t],
                         logp=self.buf_logp[t], clip_obs=self.obs_norm.clip, eps_norm=self.obs_norm.eps)
-        eng.step(self.clipped)
+        if self._f64_env:                                  # the seam: fp32 action in, fp64 observation / reward out
+            self._clip64.copy_(self.clipped)
+            eng.step(self._clip64)
+            self.env_obs[t].copy_(eng.obs)
+            self.env_rew[t].copy_(eng.reward)
+            self._obs32.copy_(eng.obs)
+            self._rew32.copy_(eng.reward)
+        else:
+            eng.step(self.clipped)
         torch.bitwise_or(eng.terminated, eng.truncated, out=self._starts[t + 1])
         if self.norm_obs:
-            self.obs_norm.update_only(eng.obs)
+            self.obs_norm.update_only(obs)
         self.snap[t, :2 * self.O + 1].copy_(self.obs_norm.rms)
         if self.norm_reward:
-            self.rew_norm(eng.reward, self._starts[t + 1], out=self.buf_rew[t])
+            self.rew_norm(reward, self._starts[t + 1], out=self.buf_rew[t])
         else:
-            self.buf_rew[t].copy_(eng.reward)
+            self.buf_rew[t].copy_(reward)
 
     def _step_fused(self, t: int) -> None:
         eng = self.engine
@@ -345,6 +415,12 @@ class RolloutCollector:
 
     def _all_steps(self) -> None:
         self._scan_prezeroed = False
+        if self._f64_env:
+            self.engine.ledger_clear()
+            self._starts[0].copy_(self._starts[self.T])
+            for t in range(self.T):
+                self._step(t)
+            return
         if self.fused_policy and self.N % 16 == 0:
             # ledger clear + episode-start carry + zeroing of the words the tail's ledger scan accumulates into: one kernel
             self.engine.rollout_begin(self._starts[0], self._starts[self.T], self._led_counters, self._led_sums)
@@ -416,14 +492,16 @@ class RolloutCollector:
     def start(self) -> None:
         """VecNormalize.reset(): reset every drone, fold the first observation into the statistics."""
         self.engine.reset()
+        if self._f64_env:
+            self._obs32.copy_(self.engine.obs)
         multi = D.several_ranks() and self.norm_obs
         if multi:
             self._base_obs_rms.copy_(self.obs_norm.rms)
-        self._normalise_obs(self.engine.obs, self.cur_obs)
+        self._normalise_obs(self._env_obs(), self.cur_obs)
         if multi:       # every rank's reset observations count: start from the statistics over all ranks' drones
             gathered = D.allgather_payload(torch.cat([self.obs_norm.rms.new_zeros(3), self.obs_norm.rms, self.rew_norm.rms]))
             ops.rank_merge(gathered, self.O, base_obs_rms=self._base_obs_rms, obs_rms=self.obs_norm.rms)
-            self._normalise_obs(self.engine.obs, self.cur_obs, update=False)
+            self._normalise_obs(self._env_obs(), self.cur_obs, update=False)
         self.rew_norm.ret.zero_()
         self._starts[self.T].fill_(1)
         self._tick0 = self.engine.get_tick()
@@ -451,25 +529,55 @@ class RolloutCollector:
         self._tick0 += self.T if self._persistent else 1
         keep = self._slot
         multi = D.several_ranks()
-        try:
-            for slot in (0, 1):
-                self._slot = slot
-                g = torch.cuda.CUDAGraph()
-                # several ranks: the collective library's watchdog thread polls events while this thread captures; thread-local
-                # capture mode keeps another thread's calls from invalidating the capture (nothing collective is captured here)
-                mode = self._capture_mode or ("thread_local" if multi else "global")
-                with torch.cuda.graph(g, capture_error_mode=mode):
-                    self._all_steps()
-                self._graphs[slot] = g
-        except Exception as exc:
-            if not multi:
+
+        home = torch.cuda.current_stream(self.device)
+
+        def capture_both(mode):
+            stream = _new_capture_stream(self.device)
+            graphs = []
+            try:
+                for slot in (0, 1):
+                    self._slot = slot
+                    graphs.append(torch.cuda.CUDAGraph())
+                    with torch.cuda.graph(graphs[-1], stream=stream, capture_error_mode=mode):
+                        self._all_steps()
+            except Exception:
+                # torch 2.10's CUDAGraph destructor aborts the process ("The graph should be registered to the state") when the
+                # capture it belongs to failed: such an object is never released
+                import ctypes
+                for g in graphs:
+                    ctypes.pythonapi.Py_IncRef(ctypes.py_object(g))
+                torch.cuda.set_stream(home)             # (its context manager does not leave the capture stream when capture_end raises)
+                _end_broken_capture(stream)
                 raise
-            # RCCL has not run this code before the driver's first multi-GPU job: a rank whose capture fails goes on with eager
-            # launches (the rollout has no collective inside the graph, so ranks need not agree on this) and says so once
+            return graphs
+
+        # several ranks: the collective library's watchdog thread polls events while this thread captures; thread-local capture
+        # mode keeps another thread's calls from invalidating the capture (nothing collective is captured here)
+        mode = self._capture_mode or os.environ.get("FPV_CAPTURE_MODE") or ("thread_local" if multi else "global")
+        try:
+            self._graphs = capture_both(mode)
+        except Exception as first:
+            # A capture can be invalidated by a runtime call that has nothing to do with the rollout — seen on this stack when a
+            # collector is captured right after others were dropped (the allocators' event bookkeeping; it goes away under
+            # call logging, and "relaxed" mode passes).  Nothing has executed: a capture only records.  So: drain the device and
+            # capture once more, in relaxed mode; only if that fails too, give up (one rank) or go on with eager launches (several
+            # ranks: the rollout has no collective inside the graph, so ranks need not agree on this).  The process keeps running
+            # either way — never re-exec.
             self._graphs = [None, None]
-            self.use_graph = False
-            print(f"fpv rollout (rank {D.rank()}): HIP-graph capture failed ({exc!r}); collecting with eager launches",
+            torch.cuda.synchronize(self.device)
+            print(f"fpv rollout (rank {D.rank()}): HIP-graph capture failed in {mode!r} mode ({first!r}); capturing again in 'relaxed' mode",
                   file=sys.stderr, flush=True)
+            try:
+                self._graphs = capture_both("relaxed")
+            except Exception as second:
+                self._graphs = [None, None]
+                torch.cuda.synchronize(self.device)
+                if not multi:
+                    raise second from first
+                self.use_graph = False
+                print(f"fpv rollout (rank {D.rank()}): the second capture failed too ({second!r}); collecting with eager launches",
+                      file=sys.stderr, flush=True)
         self._slot = keep
 
     def set_policy_gemm(self, gemm: str) -> None:
@@ -508,7 +616,14 @@ class RolloutCollector:
             self._base_ret_rms.copy_(self.rew_norm.rms)
         if self.use_graph and self._graph is None:
             self._capture()
-        if self.fused_policy:
+        if self._f64_env:
+            self._all_steps()
+            self.fp.forward(self._obs32, rms=self.obs_norm.rms if self.norm_obs else None, obs_n=self.cur_obs, value=self.last_val,
+                            deterministic=True, nets="v", clip_obs=self.obs_norm.clip, eps_norm=self.obs_norm.eps)
+            self._bootstrap_timeouts()
+            ops.gae(self.buf_rew, self.buf_val, self.buf_start, self.last_val, self.episode_start, self.gamma,
+                    self.lam, advantages=self.adv, returns=self.ret, stats=self.stats)
+        elif self.fused_policy:
             # What this slot's status words still hold is two rollouts old (no stall).  They are taken off the pinned words before
             # the launch — the rollout about to start overwrites them at its end — and turned into numbers / exceptions after it:
             # host work ahead of the launch is time the device sits idle when a caller synchronises after every rollout.
@@ -547,7 +662,7 @@ class RolloutCollector:
             if post is not main:
                 self._stats_ready[k].record(main)           # the rollout is complete on the main stream here
                 post.wait_event(self._stats_ready[k])
-            if self.fused_policy:
+            if self.fused_policy and not self._f64_env:
                 # the ledger scan has written the episode statistics / overflow flags into the pinned host words itself: a copy
                 # node here stood ~20 us between this rollout's last kernel and the next one's first.  (The persistent launch of
                 # the experiments library has one more status word, on the device: it keeps the copy.)
@@ -555,7 +670,7 @@ class RolloutCollector:
                     self._status_host[k].copy_(self._post[k][0:8], non_blocking=True)
                 self._status_event[k].record(post)          # (the one event left costs ~0.2 us per step at 32-step rollouts)
                 self._status_pending[k] = True
-            if not (self.fused_policy and not D.several_ranks()):     # (one rank, fused tail: fpv_gae has written mean / std already)
+            if self._f64_env or not (self.fused_policy and not D.several_ranks()):     # (one rank, fused tail: fpv_gae has written mean / std already)
                 payload = self._stats_k[k]
                 if multi:                                           # VecNormalize's statistics ride in the same payload
                     payload = torch.cat([self._stats_k[k], self.obs_norm.rms, self.rew_norm.rms])
@@ -566,7 +681,7 @@ class RolloutCollector:
                                    base_ret_rms=self._base_ret_rms if self.norm_reward else None,
                                    obs_rms=self.obs_norm.rms if self.norm_obs else None,
                                    ret_rms=self.rew_norm.rms if self.norm_reward else None)
-            if post is main and self.fused_policy:
+            if post is main and self.fused_policy and not self._f64_env:
                 self._stats_done[k] = self._status_event[k]     # recorded just above, at this point of this stream
             else:
                 self._stats_done[k].record(post)
@@ -630,7 +745,7 @@ class RolloutCollector:
     def episodes(self) -> dict:
         """Monitor-style statistics of the last collected rollout: {count, ep_len_mean, ep_rew_mean, truncated}.
         Waits for that rollout to finish (the only host synchronisation of the collector)."""
-        if self.fused_policy and self._rollouts:
+        if self.fused_policy and not self._f64_env and self._rollouts:
             self._check_status((self._rollouts - 1) % 2)
         return self._episodes_host
 
@@ -666,5 +781,5 @@ class RolloutCollector:
             tobs = torch.clamp((tobs.double() - mean) / torch.sqrt(var + self.obs_norm.eps), -self.obs_norm.clip,
                                self.obs_norm.clip).float()
         with torch.no_grad():
-            v = self.policy.value(tobs)
+            v = self.policy.value(tobs.float())
         self.buf_rew.index_put_((t_idx, d_idx), self.gamma * v, accumulate=True)

@@ -194,6 +194,53 @@ def test_rollout_collector_matches_oracle_replay(oracle, use_graph, fused):
     eng.close()
 
 
+def test_f64_engine_rollout_env_outputs_equal_the_oracle(oracle):
+    """The rollout in the reference's own arithmetic type: its spaces are float64 (simulation/hover.py:61, :70), numpy and pybullet
+    compute in double, SB3's torch policy in float32.  RolloutCollector on an fp64 engine = the fp32 policy kernel + fpv_step_f64
+    with the conversions at the seam.  Replayed through the oracle with the collector's own (clipped, fp32-valued) actions, the
+    env's raw outputs of every step agree to 1e-9 and the done masks exactly — over a 16-step rollout of 4 096 drones with motor
+    noise, episode ends and auto-resets inside; the collector's normalised buffers agree with the reference normaliser fed with
+    those outputs."""
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    from fpv_drone_rl_agent_amd.rollout import RolloutCollector
+    n, T, gamma = 4096, 16, 0.99
+    torch.manual_seed(5)
+    pol = ActorCritic().cuda()
+    eng = FpvEngine(n, 0, noise_ratio=0.02, seed=11, precision="f64")
+    col = RolloutCollector(eng, pol, n_steps=T, gamma=gamma)
+    col.start()
+    ref_norm = oracle.VecNormalizeRef(n, gamma=gamma)
+    _, obs_reset = oracle.reset_states(n)
+    ref_norm.reset(obs_reset)
+    st = oracle.synthetic_states(n, seed=19)
+    st[:200, 34] = np.random.default_rng(1).integers(390, 402, 200)      # truncations inside the rollout
+    st[200:300, 2] = 0.12; st[200:300, 9] = -1.0; st[200:300, 34] = 100  # floor terminations
+    eng.set_state(torch.from_numpy(st))
+    tick0 = eng.get_tick()
+    start0 = col.episode_start.cpu().numpy().copy()
+    out = col.collect()
+    torch.cuda.synchronize()
+    cfg = oracle.make_cfg(noise_ratio=0.02, seed=11)
+    acts = np.clip(col.buf_act.cpu().numpy(), -1.0, 1.0).astype(np.float64)      # what crossed the seam: fp32 values, held in fp64
+    env_obs, env_rew = col.env_obs.cpu().numpy(), col.env_rew.cpu().numpy()
+    starts, ends = start0, 0
+    for t in range(T):
+        assert (col.buf_start[t].cpu().numpy() == starts).all()
+        o_raw, r_raw, te, tr, _ = oracle.step_batch(cfg, st, acts[t], tick0 + t, nthreads=8)
+        assert np.abs(env_obs[t] - o_raw).max() <= 1e-9 and np.abs(env_rew[t] - r_raw).max() <= 1e-9
+        done = (te | tr) > 0
+        ends += int(done.sum())
+        o_n, _ = ref_norm.step(o_raw, r_raw, done)
+        if t + 1 < T:
+            assert np.abs(col.buf_obs[t + 1].cpu().numpy() - o_n).max() <= 1e-4      # fp32 normaliser on fp32-rounded observations
+        starts = done.astype(np.uint8)
+    assert ends > 250                                                  # episode ends and auto-resets were part of it
+    assert np.abs(eng.get_state().cpu().numpy() - st).max() <= 1e-9
+    assert torch.isfinite(out["advantages"]).all() and float(out["adv_std"]) > 0
+    eng.close()
+
+
 def test_ledger_scan_and_scatter_match_a_torch_restatement(oracle):
     """fpv_ledger_scan / fpv_ledger_scatter (SB3's timeout bootstrap, no host round trip) against the same rule
     written with torch indexing on the ledger read back to the host."""

@@ -443,3 +443,37 @@ def test_one_kernel_step_policy_half_keeps_fp32_accuracy_over_repeated_launches(
         assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1.0) < 0.01, trial
     print(gemm, "worst |V - V64|", worst_v, "worst |logp - logp64|", worst_lp)
     eng.close()
+
+
+def test_an_invalidated_capture_is_taken_again_and_changes_nothing():
+    """RolloutCollector._capture: a capture that a stray runtime call invalidates (here: a device synchronisation smuggled into the
+    first captured rollout) is repeated once in relaxed mode after draining the device — nothing has executed, a capture only
+    records — and the collector then returns the very batches of a collector whose capture went through at once."""
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    from fpv_drone_rl_agent_amd.rollout import RolloutCollector
+    n, T = 4096, 8
+    outs = []
+    for sabotage in (False, True):
+        torch.manual_seed(2)
+        pol = ActorCritic().cuda()
+        eng = FpvEngine(n, 0, seed=4, ledger_capacity=4 * n)
+        col = RolloutCollector(eng, pol, n_steps=T)
+        if sabotage:
+            plain, state = col._all_steps, {"calls": 0}
+
+            def spoiled():
+                state["calls"] += 1
+                if state["calls"] == 1 and torch.cuda.is_current_stream_capturing():
+                    torch.cuda.synchronize()               # not allowed while capturing: invalidates the capture
+                plain()
+            col._all_steps = spoiled
+        b = [col.collect() for _ in range(3)]
+        torch.cuda.synchronize()
+        assert col.use_graph and all(g is not None for g in col._graphs)
+        if sabotage:
+            assert state["calls"] >= 3                         # the spoiled attempt, then both slots again
+        outs.append({k: b[-1][k].clone() for k in ("obs", "actions", "values", "advantages", "returns")} | {"rms": col.obs_norm.rms.clone()})
+        eng.close()
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
