@@ -1,0 +1,32 @@
+#!/bin/bash
+# gpurun_out/session (tools/gpu_session.sh) -> the tracked summaries under profiles/, named <TAG>_* (default r04)
+set -e
+cd "$(dirname "$0")/.."
+TAG=${1:-r04}
+O=gpurun_out/session
+last() { tail -n 1 "$1"; }
+last $O/bench.json > profiles/${TAG}_bench_line.json
+last $O/bench_s20.json > profiles/${TAG}_bench_line_s20.json
+last $O/bench_analytic.json > profiles/${TAG}_bench_line_analytic.json
+last $O/bench_two.json > profiles/${TAG}_bench_line_two.json
+last $O/bench_yaw.json > profiles/${TAG}_bench_line_yaw.json
+last $O/bench_gpus2_gloo.json > profiles/${TAG}_bench_line_gpus2_gloo_one_gpu.json
+cp $O/phases_step.json profiles/${TAG}_rollout_step_phases.json
+cp $O/phases_step_analytic.json profiles/${TAG}_rollout_step_phases_analytic.json
+cp $O/c_host_one.json profiles/${TAG}_c_host.json
+cp gpurun_out/pixel_flip_rate.json profiles/${TAG}_pixel_flip_rate.json
+cp $O/step_sweep_pixel.json profiles/${TAG}_step_sweep_pixel.json
+cp $O/step_quad_sweep.json profiles/${TAG}_step_quad_sweep.json
+cp $O/fp32_vs_fp64_trajectory.json profiles/${TAG}_fp32_vs_fp64_trajectory.json
+python tools/summarize_prof.py ${TAG} $O/prof_hover $O/pmc_fetch $O/pmc_write > /dev/null
+python tools/make_kernel_traffic.py ${TAG} > /dev/null
+cp "$(ls $O/prof_s20/*/*kernel_stats.csv | head -1)" profiles/${TAG}_kernel_stats_s20.csv
+cp gpurun_out/pmc_k0/summary.json profiles/${TAG}_rollout_step_pmc_raw.json
+{ echo "# The boundary between rollouts (tools/trace_gaps.py on rocprofv3 kernel traces; durations under the profiler)"; echo;
+  echo "## one 20-step rollout per timed region (python bench.py --steps 20 --warmup 5 --repeats 12): last rollout, then medians"; echo '```'; cat $O/boundary_s20.txt; echo '```'; echo;
+  echo "## steady state (--steps 256 --warmup 32, 32-step rollouts back to back)"; echo '```'; cat $O/boundary_steady.txt; echo '```'; } > profiles/${TAG}_rollout_boundary.md
+{ echo "# PPO update (tools/microbench_ppo.py): HIP events, then rocprofv3 kernel statistics of the same script"; cat $O/ppo_events.json; echo;
+  head -12 "$(ls $O/prof_ppo/*/*kernel_stats.csv | head -1)"; } > profiles/${TAG}_ppo_update_profile.txt
+tail -3 $O/tests.txt > profiles/${TAG}_gpu_tests_tail.txt
+[ -f $O/bench_rehearsed_ranks.json ] && last $O/bench_rehearsed_ranks.json > profiles/${TAG}_bench_line_rehearsed_ranks.json
+ls -la profiles/${TAG}_* | awk '{print $5, $9}'
