@@ -74,7 +74,7 @@ class FpvPpoIo(C.Structure):
         ("old_logp", C.c_void_p), ("advantages", C.c_void_p), ("returns", C.c_void_p),
         ("clip_range", C.c_float), ("vf_coef", C.c_float), ("ent_coef", C.c_float), ("reserved0", C.c_float),
         ("weights", C.c_void_p * 13), ("grads", C.c_void_p * 13), ("stats", C.c_void_p),
-        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("storage", C.c_int32), ("reserved1", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("storage", C.c_int32), ("path", C.c_int32),
     ]
 
 

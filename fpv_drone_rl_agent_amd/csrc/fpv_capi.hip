@@ -783,13 +783,18 @@ int fpv_ppo_grad(fpv_policy* p, const fpv_ppo_io* io, void* stream) {
     if (((uintptr_t)io->obs | act_rows | (uintptr_t)io->workspace) & 15)
         return fail(FPV_ERR_ARG, "fpv_ppo_grad: row buffers and workspace must be 16-byte aligned");
     if (io->storage != 0 && io->storage != 1) return fail(FPV_ERR_ARG, "fpv_ppo_grad: storage must be 0 (fp32) or 1 (bf16)");
+    if (io->path < FPV_PPO_ONE_KERNEL || io->path > FPV_PPO_TWO_KERNELS_BF16X6)
+        return fail(FPV_ERR_ARG, "fpv_ppo_grad: path must be FPV_PPO_ONE_KERNEL, FPV_PPO_TWO_KERNELS or FPV_PPO_TWO_KERNELS_BF16X6");
+    if (io->path != FPV_PPO_TWO_KERNELS && io->storage == 1)
+        return fail(FPV_ERR_ARG, "fpv_ppo_grad: bf16 storage exists on the FPV_PPO_TWO_KERNELS path only (nothing is stored on the "
+                                 "one-kernel path; the bf16 x 6 products split fp32 operands)");
     const int64_t need = ppo_workspace_floats(io->rows, p->cus) * (int64_t)sizeof(float);
     if (io->workspace_bytes < need)
         return fail(FPV_ERR_ARG, "fpv_ppo_grad: workspace of %lld bytes, %lld needed (fpv_ppo_workspace_bytes)",
                     (long long)io->workspace_bytes, (long long)need);
     FPV_HIP(launch_ppo_grad(io->weights, io->grads, io->index, io->obs, io->actions, io->old_logp, io->advantages, io->returns,
                             io->rows, io->clip_range, io->vf_coef, io->ent_coef, io->stats, (float*)io->workspace, p->in_dim,
-                            p->act_dim, p->cus, io->storage, (hipStream_t)stream));
+                            p->act_dim, p->cus, io->storage, io->path, (hipStream_t)stream));
     return FPV_OK;
 }
 

@@ -11,6 +11,7 @@
 //                          every workgroup reduces a slab of rows, slabs are summed in fixed order by
 //   U3 ppo_reduce_kernel   -> the 13 gradient tensors + {pg loss, value loss, approx KL, clip fraction}.
 // fp32 throughout (v_mfma_f32_32x32x2_f32); no atomics: the result is bitwise reproducible for a given launch shape.
+#include "../../include/fpv_env.h"   // FPV_PPO_* path constants
 #include "fpv_mlp.h"
 
 #ifndef FPV_PPO_THREADS
@@ -556,6 +557,646 @@ __global__ __launch_bounds__(512) void ppo_wgrad_kernel(WgradArgs p) {
     }
 }
 
+// ---------------------------------------------------------------- U2 on the bf16 matrix pipe (fpv_ppo_io.path = FPV_PPO_TWO_KERNELS_BF16X6)
+// The same weight gradients with every fp32 operand cut into three bf16 pieces and the six piece products that matter per
+// product (fpv_policy_split.h's mfma6: w3 x1, w1 x3, w2 x2, w2 x1, w1 x2, w1 x1, small terms first; fp32 accumulation): the
+// 32x32x16 bf16 product takes 16 rows of the slab per instruction where the fp32 one takes 2, at 16 x the rate — 6 / 16 of the
+// matrix-pipe time.  A lane holds eight ROWS of one column per operand (k = 8 (lane >> 5) + j on both operands, so any
+// consistent numbering of the 16 rows will do): eight dword loads per fragment, 128 contiguous bytes per half-wave each.  Same
+// work split as above (wave w of a set: output rows 32 w .. of dW2 / dW1, columns 32 w .. of the head gradient), the two sets
+// take alternate 16-row groups, set 0 + set 1 through LDS, the same partial layout: U3 does not know which kernel ran.
+// fp32 storage only (a bf16-stored operand has one piece: that combination keeps the fp32-MFMA kernel).
+typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
+struct Pieces { pbf16x8 p1, p2, p3; };
+__device__ __forceinline__ Pieces pieces_of(const float (&v)[8]) {
+    Pieces o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 a = (__bf16)v[j];
+        const float r1 = v[j] - (float)a;
+        const __bf16 b = (__bf16)r1;
+        o.p1[j] = a; o.p2[j] = b; o.p3[j] = (__bf16)(r1 - (float)b);
+    }
+    return o;
+}
+__device__ __forceinline__ f32x16 mfma6_pieces(const Pieces& w, const Pieces& x, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p3, x.p1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p1, x.p3, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p2, x.p2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p2, x.p1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p1, x.p2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p1, x.p1, acc, 0, 0, 0);
+    return acc;
+}
+
+__global__ __launch_bounds__(512) void ppo_wgrad_split_kernel(WgradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float xch[];     // [4 waves][99][64 lanes]
+    const int net = blockIdx.y, slab = blockIdx.x;
+    const int lane = threadIdx.x & 63, w = (threadIdx.x >> 6) & 3, set = threadIdx.x >> 8;
+    const int i = lane & 31, kk = lane >> 5;
+    const int nh = net == 0 ? p.act_dim : 1;
+    const int64_t n0 = (int64_t)slab * p.rows_per_slab;
+    const int64_t n1 = n0 + p.rows_per_slab < p.rows ? n0 + p.rows_per_slab : p.rows;
+    const int len = (int)(n1 - n0);
+    const float* const mats = static_cast<const float*>(p.mats);
+    const float* H1 = mats + ((size_t)(net * 4 + 0) * p.rows + n0) * kHid + i;
+    const float* H2 = mats + ((size_t)(net * 4 + 1) * p.rows + n0) * kHid + 32 * w + i;
+    const float* D1 = mats + ((size_t)(net * 4 + 2) * p.rows + n0) * kHid + 32 * w + i;
+    const float* D2 = mats + ((size_t)(net * 4 + 3) * p.rows + n0) * kHid + 32 * w + i;
+    const float* XG = p.xg + n0 * p.in_dim + (i < p.in_dim ? i : p.in_dim - 1);
+    const float* AH = net == 0 ? p.dmu + n0 * 4 + (i < 4 ? i : 3) : p.dv + n0;
+    const int ah_stride = net == 0 ? 4 : 1;
+    const bool x_on = i < p.in_dim, ah_on = i < nh;
+
+    f32x16 w2[4], w1, hd;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        w2[0][r] = 0.f; w2[1][r] = 0.f; w2[2][r] = 0.f; w2[3][r] = 0.f; w1[r] = 0.f; hd[r] = 0.f;
+    }
+    float sb2 = 0.f, sb1 = 0.f, sbh = 0.f;
+#pragma unroll 1
+    for (int g0 = 16 * set; g0 < len; g0 += 32) {
+        // this lane's eight rows of the group (clamped for the loads, masked after them)
+        int rr[8];
+        bool ok[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = g0 + 8 * kk + j;
+            ok[j] = row < len;
+            rr[j] = ok[j] ? row : 0;
+        }
+        float a2[8], a1[8], ah[8], hh[8], x[8], b[4][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {                      // every request of the group before the first use
+            a2[j] = D2[rr[j] * kHid]; a1[j] = D1[rr[j] * kHid]; ah[j] = AH[rr[j] * ah_stride];
+            hh[j] = H2[rr[j] * kHid]; x[j] = XG[rr[j] * p.in_dim];
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) b[jt][j] = H1[rr[j] * kHid + 32 * jt];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            a2[j] = ok[j] ? a2[j] : 0.f; a1[j] = ok[j] ? a1[j] : 0.f; ah[j] = (ok[j] && ah_on) ? ah[j] : 0.f;
+            x[j] = x_on ? x[j] : 0.f;
+            sb2 += a2[j]; sb1 += a1[j]; sbh += ah[j];
+        }
+        const Pieces pa2 = pieces_of(a2);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) w2[jt] = mfma6_pieces(pa2, pieces_of(b[jt]), w2[jt]);
+        w1 = mfma6_pieces(pieces_of(a1), pieces_of(x), w1);
+        hd = mfma6_pieces(pieces_of(ah), pieces_of(hh), hd);
+    }
+
+    // ---- set 1 hands its sums to set 0 (as in ppo_wgrad_kernel)
+    float* mine = xch + (size_t)w * 99 * 64 + lane;
+    if (set == 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) mine[(jt * 16 + r) * 64] = w2[jt][r];
+            mine[(64 + r) * 64] = w1[r];
+            mine[(80 + r) * 64] = hd[r];
+        }
+        mine[96 * 64] = sb2; mine[97 * 64] = sb1; mine[98 * 64] = sbh;
+    }
+    __syncthreads();
+    if (set == 1) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) w2[jt][r] += mine[(jt * 16 + r) * 64];
+        w1[r] += mine[(64 + r) * 64];
+        hd[r] += mine[(80 + r) * 64];
+    }
+    sb2 += mine[96 * 64]; sb1 += mine[97 * 64]; sbh += mine[98 * 64];
+
+    float* out = p.part + ((size_t)net * p.slabs + slab) * kPartStride;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int o = 32 * w + tile_row(r, kk);
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) out[kPW2 + o * kHid + 32 * jt + i] = w2[jt][r];
+        if (x_on) out[kPW1 + o * p.in_dim + i] = w1[r];
+    }
+    if (kk == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < nh) out[kPWh + r * kHid + 32 * w + i] = hd[r];
+    }
+    sb2 = half_sum(sb2); sb1 = half_sum(sb1); sbh = half_sum(sbh);
+    if (kk == 0) {
+        out[kPB2 + 32 * w + i] = sb2;
+        out[kPB1 + 32 * w + i] = sb1;
+        if (w == 0 && ah_on) out[kPBh + i] = sbh;
+    }
+}
+
+// ---------------------------------------------------------------- U12: U1 and U2 as one kernel (fpv_ppo_io.path = FPV_PPO_ONE_KERNEL, the default)
+// The matrices U1 hands to U2 are 4 KB per row and net: written and read back they are 537 MB of HBM traffic per 65 536-row
+// minibatch, and neither trip hides behind the products (U1 135 us with the stores, 66 without; U2 91 us, 60 with its operands in
+// registers: profiles/r04_ppo_update_profile.txt).  Here they never leave the CU.  A workgroup (four waves, one per SIMD) takes one
+// net and one slab of rows, 128 rows at a time; per chunk
+//   phase A  every wave: forward, loss derivatives and backward of its own 32 rows as in U1 (rows on the MFMA column, the matrices
+//            in accumulator tiles); H2 and d out are laid down in LDS as soon as D2 exists, so the backward runs with three tile
+//            sets live, not four;
+//   phase B  the weight gradients of the chunk's 128 rows as in U2 — K = the row index, wave w owns output rows 32 w .. 32 w + 31 of
+//            dW2 and dW1 and columns 32 w .. of the head gradient — with the operands read from ONE row-major LDS matrix
+//            [128 rows][132] that all four waves fill together, four times: H2 (head gradient, with d out), D2 (each wave takes
+//            its 64 A operands into registers), H1 (dW2 += D2^T H1), D1 (with x: dW1 += D1^T x).  The transposition U2 got from
+//            the row-major matrices in memory is the LDS write here.
+// LDS holds W2 ONCE, row-major with 132-float rows: the forward reads four consecutive k of a row (one 16-byte read, as from the
+// packed image), the backward reads a column (consecutive lanes, consecutive addresses).  W1's 48 A operands per lane come from
+// U0's image in memory (the same for every chunk; asked for during the previous chunk's last products).  The partial sums of a
+// slab stay in registers over its rows and are written once, in U2's layout: U3 does not know which kernel ran.  The barriers
+// order LDS traffic only.  fp32 throughout, no atomics: bitwise reproducible for a given launch shape.
+constexpr int kFRow = 132;                      // floats per row of the W2 image and of the staged matrix
+constexpr int kFOffB1 = 0, kFOffB2 = 128, kFOffW2 = 256, kFOffHead = kFOffW2 + kHid * kFRow;
+constexpr int kFOffX = (kFOffHead + kHeadFloats + 3) / 4 * 4;
+constexpr int kFOffDo = kFOffX + 128 * 24, kFOffM = kFOffDo + 128 * 4;
+constexpr int kFusedFloats = kFOffM + 128 * kFRow;
+static_assert(kFusedFloats * 4 <= 160 * 1024, "the fused PPO kernel's LDS image");
+static_assert(kFOffX % 4 == 0 && kFOffM % 4 == 0 && kFOffHead % 4 == 0, "16-byte rows");
+
+struct FusedArgs {
+    const float* image;       // U0's training image: W1p, b1, b2 and the head block are taken from it
+    const float* w2[2];       // the live [128][128] second-layer weights of pi and V
+    const int64_t* index;
+    const float *obs, *actions, *old_logp, *adv, *ret;
+    float* part;              // [2][slabs][kPartStride]
+    float* wave_stats;        // [2 * slabs * 4][8]
+    int64_t rows;
+    float clip_range, vf_coef, inv_rows;
+    int32_t rows_per_slab, slabs, in_dim, act_dim;
+};
+
+// workgroup barrier that orders LDS traffic only: global reads stay in flight across it
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// a wave's 32 rows of one matrix, accumulator tiles -> row-major LDS rows (four consecutive columns per register quad)
+__device__ __forceinline__ void stage_tile_rows(float* __restrict__ mat, int row, const Hidden& t, int h) {
+    f32x4* dst = reinterpret_cast<f32x4*>(mat + row * kFRow);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[m * 8 + 2 * q + h] = f32x4{t.t[m][4 * q], t.t[m][4 * q + 1], t.t[m][4 * q + 2], t.t[m][4 * q + 3]};
+}
+
+// Phase stamps (s_memrealtime, 100 MHz) of the diagnostic build -DFPV_PPO_STAMPS=1 (tools/ppo_stamps.py): two workgroups write
+// them over the start of the matrices' workspace, which this path does not use.  In the product the markers compile to nothing.
+#ifndef FPV_PPO_STAMPS
+#define FPV_PPO_STAMPS 0
+#endif
+#if FPV_PPO_STAMPS
+#define PPO_STAMP_SETUP()                                                                                                        \
+    unsigned long long* stamps_ = reinterpret_cast<unsigned long long*>(const_cast<float*>(p.image) + kTImage) +               \
+                                  (size_t)((blockIdx.x == 0 ? 0 : 1) * 4 + (threadIdx.x >> 6)) * 128;                           \
+    const bool stamp_on_ = ((blockIdx.x == 0 && blockIdx.y == 0) || (blockIdx.x == 77 && blockIdx.y == 1)) && (threadIdx.x & 63) == 0
+#define PPO_STAMP(k) do { if (stamp_on_ && (k) < 120) { stamps_[k] = __builtin_amdgcn_s_memrealtime(); if ((k) < 4) stamps_[120 + (k)] = __builtin_readcyclecounter(); } } while (0)
+#else
+#define PPO_STAMP_SETUP() ((void)0)
+#define PPO_STAMP(k) ((void)0)
+#endif
+
+__global__ __launch_bounds__(256) void ppo_fused_kernel(FusedArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const hb = lds + kFOffHead;
+    const int net = blockIdx.y, slab = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, h = lane >> 5;
+    const int nh = net == 0 ? p.act_dim : 1;
+    const bool x_on = col < p.in_dim, ah_on = col < nh;
+    const int64_t n0 = (int64_t)slab * p.rows_per_slab;
+    const int64_t n1 = n0 + p.rows_per_slab < p.rows ? n0 + p.rows_per_slab : p.rows;
+    float st[kWaveStats] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    PPO_STAMP_SETUP();
+    PPO_STAMP(0);
+    const float* const img = p.image + (size_t)net * kTNet;
+
+    // ---- the net's image: b1 | b2 from U0's image, W2 from the live tensor, the head block
+    {
+        for (int g = threadIdx.x; g < kHid / 4; g += 256) {
+            reinterpret_cast<f32x4*>(lds + kFOffB1)[g] = reinterpret_cast<const f32x4*>(img + kTOffB1)[g];
+            reinterpret_cast<f32x4*>(lds + kFOffB2)[g] = reinterpret_cast<const f32x4*>(img + kTOffB2)[g];
+        }
+        const f32x4* w2 = reinterpret_cast<const f32x4*>(p.w2[net]);
+#pragma unroll 4
+        for (int g = threadIdx.x; g < kHid * kHid / 4; g += 256)
+            *reinterpret_cast<f32x4*>(lds + kFOffW2 + (g >> 5) * kFRow + 4 * (g & 31)) = w2[g];
+        for (int g = threadIdx.x; g < kHeadFloats / 4; g += 256)
+            reinterpret_cast<f32x4*>(hb)[g] = reinterpret_cast<const f32x4*>(p.image + kTHead)[g];
+    }
+    // W1's A operands: the same for every chunk, but 48 registers are not to be had across a chunk: read again per chunk (the
+    // opaque zero keeps the reads inside the loop), during the previous chunk's last products
+    float w1r[48];
+    auto load_w1 = [&]() {
+        int zero;
+        asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+        const float* w1p = img + kTOffW1 + lane + zero;
+#pragma unroll
+        for (int q = 0; q < 48; ++q) w1r[q] = w1p[q * 64];
+    };
+    load_w1();
+
+    // weight-gradient sums of this wave's output rows over the whole slab
+    f32x16 w2s[4], w1s, hds;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        w2s[0][r] = 0.f; w2s[1][r] = 0.f; w2s[2][r] = 0.f; w2s[3][r] = 0.f; w1s[r] = 0.f; hds[r] = 0.f;
+    }
+    float sb2 = 0.f, sb1 = 0.f, sbh = 0.f;
+    float* const M = lds + kFOffM;
+    float* const XS = lds + kFOffX;
+    float* const DO = lds + kFOffDo;
+    const int kk = h, i = col;
+    const int srow = wave * 32 + col;                            // this lane's row inside the chunk
+    // the first chunk's row index and x (every later chunk's are asked for during the chunk before)
+    int64_t src_next = n0 + srow < n1 ? (p.index ? p.index[n0 + srow] : n0 + srow) : 0;
+    f32x4 xn[3];
+    {
+        const f32x4* row = reinterpret_cast<const f32x4*>(p.obs + src_next * p.in_dim);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) xn[q] = row[4 * (3 * h + q) < p.in_dim ? 3 * h + q : 0];
+    }
+    __syncthreads();                                             // the image is in place
+    PPO_STAMP(1);
+
+#pragma unroll 1
+    for (int64_t base = n0; base < n1; base += 128) {
+        // ================================================================ phase A: this wave's 32 rows (as ppo_fwd_bwd_kernel)
+        const int64_t n = base + srow;
+        [[maybe_unused]] const int ck = 4 + 16 * (int)((base - n0) >> 7);
+        const bool live = n < n1;
+        const int64_t src = src_next;
+        // the row's other inputs: asked for now, used after the forward (a gathered row is an HBM miss)
+        f32x4 act4 = {0.f, 0.f, 0.f, 0.f};
+        float in0 = 0.f, in1 = 0.f;                              // pi: old log-probability, advantage; V: return
+        if (net == 0) {
+            if (p.act_dim == 4) act4 = reinterpret_cast<const f32x4*>(p.actions)[src];
+            else
+                for (int j = 0; j < p.act_dim; ++j) act4[j] = p.actions[src * p.act_dim + j];
+            in0 = p.old_logp[src]; in1 = p.adv[src];
+        } else {
+            in0 = p.ret[src];
+        }
+        Hidden a;
+        {
+            float x[12];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const bool have = live && 4 * (3 * h + q) < p.in_dim;
+                const f32x4 v = have ? xn[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+                x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+            }
+            bias_init(a, lds + kFOffB1, h);
+#pragma unroll
+            for (int s = 0; s < 12; ++s)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    a.t[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1r[m * 12 + s], x[s], a.t[m], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) a.t[0][r] = fast_tanh(a.t[0][r]);
+        Hidden c;
+        bias_init(c, lds + kFOffB2, h);
+        {
+            // A[out 32 m + col][in 32 kt + 8 r4 + 4 h + rr], rr = 0..3: one 16-byte read per tile and register quad
+            const float* wrow = lds + kFOffW2 + col * kFRow + 4 * h;
+            f32x4 wc[4], wn[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) wc[m] = *reinterpret_cast<const f32x4*>(wrow + 32 * m * kFRow);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int kt = t >> 2, r4 = t & 3;
+                if (t < 15) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) wn[m] = *reinterpret_cast<const f32x4*>(wrow + 32 * m * kFRow + 8 * (t + 1));
+                }
+                if (kt < 3) {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) a.t[kt + 1][4 * r4 + rr] = fast_tanh(a.t[kt + 1][4 * r4 + rr]);
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        c.t[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[m][rr], a.t[kt][4 * r4 + rr], c.t[m], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) wc[m] = wn[m];
+            }
+        }
+        PPO_STAMP(ck + 0);
+        tanh_all(c);
+
+        // ---- heads, loss derivatives, g = dL/dH2
+        Hidden g;
+        float dout[4] = {0.f, 0.f, 0.f, 0.f};
+        if (net == 0) {
+            float mu[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(hb + kHWa + (((h * 4 + kt) * 16 + r) * 4));
+                    const float v = c.t[kt][r];
+                    mu[0] += w.x * v; mu[1] += w.y * v; mu[2] += w.z * v; mu[3] += w.w * v;
+                    if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+                }
+            const float act[4] = {live ? act4.x : 0.f, live ? act4.y : 0.f, live ? act4.z : 0.f, live ? act4.w : 0.f};
+            const float old_lp = live ? in0 : 0.f, adv = live ? in1 : 0.f;
+            float z[4], lp = hb[kHLpc];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                mu[j] = half_sum(mu[j]);
+                mu[j] += hb[kHBa + j];
+                z[j] = (act[j] - mu[j]) * hb[kHInvStd + j];
+                lp -= 0.5f * z[j] * z[j];
+            }
+            const float lr = lp - old_lp, ratio = __expf(lr);
+            const float lo = 1.0f - p.clip_range, hi = 1.0f + p.clip_range;
+            const float pg1 = adv * ratio, pg2 = adv * fminf(fmaxf(ratio, lo), hi);
+            const float glp = (live && pg1 <= pg2) ? -adv * ratio * p.inv_rows : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dout[j] = glp * z[j] * hb[kHInvStd + j];
+            if (live && h == 0) {
+                st[0] -= fminf(pg1, pg2);
+                st[2] += (ratio - 1.0f) - lr;
+                st[3] += fabsf(ratio - 1.0f) > p.clip_range ? 1.0f : 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) st[4 + j] += j < p.act_dim ? glp * (z[j] * z[j] - 1.0f) : 0.f;
+            }
+            const float b0 = h ? dout[1] : dout[0], b1 = h ? dout[3] : dout[2];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hb[kHWaT + (m * 2 + 0) * 64 + lane], b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hb[kHWaT + (m * 2 + 1) * 64 + lane], b1, acc, 0, 0, 0);
+                g.t[m] = acc;
+            }
+        } else {
+            float v = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    v += hb[kHWv + (h * 4 + kt) * 16 + r] * c.t[kt][r];
+                    if (r == 15) __builtin_amdgcn_sched_barrier(0);
+                }
+            v = half_sum(v);
+            v += hb[kHBv];
+            const float ret = live ? in0 : 0.f;
+            const float err = live ? v - ret : 0.f;
+            dout[0] = p.vf_coef * 2.0f * err * p.inv_rows;
+            if (live && h == 1) st[1] += err * err;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) g.t[m][r] = hb[kHWv + (h * 4 + m) * 16 + r] * dout[0];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- D2 = g (1 - H2^2); H2 and d out go to LDS now (the previous chunk's last readers are past this barrier)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) g.t[m][r] *= 1.0f - c.t[m][r] * c.t[m][r];
+        PPO_STAMP(ck + 1);
+        lds_barrier();
+        PPO_STAMP(ck + 2);
+        stage_tile_rows(M, srow, c, h);
+        if (h == 0) reinterpret_cast<f32x4*>(DO)[srow] = f32x4{dout[0], dout[1], dout[2], dout[3]};
+        // ---- dH1^T = W2^T . D2^T (the W2 column reads), D1 = dH1 (1 - H1^2)
+        Hidden e;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e.t[m][r] = 0.f;
+        {
+            // A[in 32 m + col][out 32 kt + 8 r4 + 4 h + rr]
+            const float* wcol = lds + kFOffW2 + 4 * h * kFRow + col;
+            float wc[4][4], wn[4][4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) wc[m][rr] = wcol[rr * kFRow + 32 * m];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int kt = t >> 2, r4 = t & 3;
+                if (t < 15) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) wn[m][rr] = wcol[(8 * (t + 1) + rr) * kFRow + 32 * m];
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        e.t[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[m][rr], g.t[kt][4 * r4 + rr], e.t[m], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) wc[m][rr] = wn[m][rr];
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e.t[m][r] *= 1.0f - a.t[m][r] * a.t[m][r];
+
+        PPO_STAMP(ck + 3);
+        // ================================================================ phase B: weight gradients of the chunk's 128 rows
+        // x again, from L2: asked for here, laid down with D1 three fillings later
+        f32x4 xr[3];
+        {
+            const f32x4* row = reinterpret_cast<const f32x4*>(p.obs + src * p.in_dim);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) xr[q] = row[4 * (3 * h + q) < p.in_dim ? 3 * h + q : 0];
+        }
+        // and the next chunk's row index and x
+        {
+            const int64_t nn = n + 128;
+            src_next = nn < n1 ? (p.index ? p.index[nn] : nn) : 0;
+            const f32x4* row = reinterpret_cast<const f32x4*>(p.obs + src_next * p.in_dim);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) xn[q] = row[4 * (3 * h + q) < p.in_dim ? 3 * h + q : 0];
+        }
+        // K = the chunk's 128 rows, two per product (row 2 s + kk); operands of the next group of k-steps are asked for before the
+        // current group is multiplied (pinned with scheduling fences, as in ppo_wgrad_kernel).
+        lds_barrier();                                           // H2 and d out of all four waves are in place
+        PPO_STAMP(ck + 4);
+        {                                                        // head gradient += d out^T H2
+            constexpr int G = 8;
+            struct Grp { float hh[G], ah[G]; };
+            const float* HH = M + kk * kFRow + 32 * wave + i;
+            const float* AH = DO + kk * 4 + (i < 4 ? i : 3);
+            auto load = [&](Grp& o, int s0) {
+#pragma unroll
+                for (int u = 0; u < G; ++u) { o.hh[u] = HH[2 * (s0 + u) * kFRow]; o.ah[u] = AH[2 * (s0 + u) * 4]; }
+            };
+            auto fma = [&](const Grp& o) {
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const float ah = ah_on ? o.ah[u] : 0.f;
+                    hds = __builtin_amdgcn_mfma_f32_32x32x2f32(ah, o.hh[u], hds, 0, 0, 0);
+                    sbh += ah;
+                }
+            };
+            Grp P, Q;
+            load(P, 0);
+#pragma unroll 1
+            for (int s0 = 0; s0 < 64; s0 += 2 * G) {
+                load(Q, s0 + G);
+                __builtin_amdgcn_sched_barrier(0);
+                fma(P);
+                __builtin_amdgcn_sched_barrier(0);
+                load(P, s0 + 2 * G < 64 ? s0 + 2 * G : 0);
+                __builtin_amdgcn_sched_barrier(0);
+                fma(Q);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        PPO_STAMP(ck + 5);
+        lds_barrier();
+        PPO_STAMP(ck + 6);
+        stage_tile_rows(M, srow, g, h);                          // D2 of the chunk
+        lds_barrier();
+        PPO_STAMP(ck + 7);
+        float a2r[64];                                           // this wave's A operands of dW2: D2[row 2 s + kk][32 wave + i]
+        {
+            const float* A2 = M + kk * kFRow + 32 * wave + i;
+#pragma unroll
+            for (int s = 0; s < 64; ++s) a2r[s] = A2[2 * s * kFRow];
+        }
+        PPO_STAMP(ck + 8);
+        lds_barrier();
+        stage_tile_rows(M, srow, a, h);                          // H1 of the chunk
+        PPO_STAMP(ck + 9);
+        lds_barrier();
+        PPO_STAMP(ck + 10);
+        {                                                        // dW2 += D2^T H1
+            constexpr int G = 4;
+            struct Grp { float b[G][4]; };
+            const float* B = M + kk * kFRow + i;
+            auto load = [&](Grp& o, int s0) {
+#pragma unroll
+                for (int u = 0; u < G; ++u)
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt) o.b[u][jt] = B[2 * (s0 + u) * kFRow + 32 * jt];
+            };
+            Grp P, Q;
+            load(P, 0);
+#pragma unroll
+            for (int s0 = 0; s0 < 64; s0 += 2 * G) {
+                load(Q, s0 + G);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt)
+                        w2s[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2r[s0 + u], P.b[u][jt], w2s[jt], 0, 0, 0);
+                    sb2 += a2r[s0 + u];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (s0 + 2 * G < 64) load(P, s0 + 2 * G);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+#pragma unroll
+                    for (int jt = 0; jt < 4; ++jt)
+                        w2s[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2r[s0 + G + u], Q.b[u][jt], w2s[jt], 0, 0, 0);
+                    sb2 += a2r[s0 + G + u];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        PPO_STAMP(ck + 11);
+        lds_barrier();
+        PPO_STAMP(ck + 12);
+        stage_tile_rows(M, srow, e, h);                          // D1 of the chunk, and x
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const bool have = live && 4 * (3 * h + q) < p.in_dim;
+            reinterpret_cast<f32x4*>(XS + srow * 24)[3 * h + q] = have ? xr[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        PPO_STAMP(ck + 13);
+        lds_barrier();
+        PPO_STAMP(ck + 14);
+        load_w1();                                               // for the next chunk
+        {                                                        // dW1 += D1^T x
+            constexpr int G = 8;
+            struct Grp { float a1[G], xv[G]; };
+            const float* A1 = M + kk * kFRow + 32 * wave + i;
+            const float* XV = XS + kk * 24 + (i < 24 ? i : 23);
+            auto load = [&](Grp& o, int s0) {
+#pragma unroll
+                for (int u = 0; u < G; ++u) { o.a1[u] = A1[2 * (s0 + u) * kFRow]; o.xv[u] = XV[2 * (s0 + u) * 24]; }
+            };
+            auto fma = [&](const Grp& o) {
+#pragma unroll
+                for (int u = 0; u < G; ++u) {
+                    const float xv = x_on ? o.xv[u] : 0.f;
+                    w1s = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a1[u], xv, w1s, 0, 0, 0);
+                    sb1 += o.a1[u];
+                }
+            };
+            Grp P, Q;
+            load(P, 0);
+#pragma unroll 1
+            for (int s0 = 0; s0 < 64; s0 += 2 * G) {
+                load(Q, s0 + G);
+                __builtin_amdgcn_sched_barrier(0);
+                fma(P);
+                __builtin_amdgcn_sched_barrier(0);
+                load(P, s0 + 2 * G < 64 ? s0 + 2 * G : 0);
+                __builtin_amdgcn_sched_barrier(0);
+                fma(Q);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    PPO_STAMP(2);
+    // ---- the slab's partial sums, in ppo_wgrad_kernel's layout
+    {
+        const int w = wave;
+        float* out = p.part + ((size_t)net * p.slabs + slab) * kPartStride;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = 32 * w + tile_row(r, kk);
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) out[kPW2 + o * kHid + 32 * jt + i] = w2s[jt][r];
+            if (x_on) out[kPW1 + o * p.in_dim + i] = w1s[r];
+        }
+        if (kk == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < nh) out[kPWh + r * kHid + 32 * w + i] = hds[r];
+        }
+        sb2 = half_sum(sb2); sb1 = half_sum(sb1); sbh = half_sum(sbh);
+        if (kk == 0) {
+            out[kPB2 + 32 * w + i] = sb2;
+            out[kPB1 + 32 * w + i] = sb1;
+            if (w == 0 && ah_on) out[kPBh + i] = sbh;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kWaveStats; ++k) {
+        float v = st[k];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) p.wave_stats[(((size_t)net * p.slabs + slab) * 4 + wave) * kWaveStats + k] = v;
+    }
+    PPO_STAMP(3);
+}
+
 // ---------------------------------------------------------------- U3: fixed-order sums -> gradient tensors + statistics
 struct ReduceArgs {
     const float* part;
@@ -715,10 +1356,26 @@ static int ppo_blocks(int64_t rows, int cus) {
     return (int)(b < cus ? b : cus);
 }
 
+// the one-kernel path: one workgroup per net and slab, slabs of whole 128-row chunks, cus / 2 slabs per net at full size
+static int ppo_fused_slabs(int64_t rows, int cus, int* rows_per_slab) {
+    const int64_t want = cus / 2 > 0 ? cus / 2 : 1;
+    int64_t rps = (rows + want - 1) / want;
+    rps = (rps + 127) / 128 * 128;
+    if (rps < 128) rps = 128;
+    *rows_per_slab = (int)rps;
+    return (int)((rows + rps - 1) / rps);
+}
+
+static int64_t ppo_stat_waves(int64_t rows, int cus) {
+    int rps;
+    const int64_t two = (int64_t)ppo_blocks(rows, cus) * (kFwdBwdThreads / 64), one = 2 * (int64_t)ppo_fused_slabs(rows, cus, &rps) * 4;
+    return two > one ? two : one;
+}
+
 int64_t ppo_workspace_floats(int64_t rows, int cus) {
     int rps;
-    const int slabs = ppo_slabs(rows, &rps);
-    return (int64_t)kTImage + 8 * rows * kHid + rows * 24 + rows * 4 + rows + (int64_t)ppo_blocks(rows, cus) * (kFwdBwdThreads / 64) * kWaveStats +
+    const int slabs = ppo_slabs(rows, &rps);                     // >= the one-kernel path's slab count
+    return (int64_t)kTImage + 8 * rows * kHid + rows * 24 + rows * 4 + rows + ppo_stat_waves(rows, cus) * kWaveStats +
            2 * (int64_t)slabs * kPartStride + 64;
 }
 
@@ -726,7 +1383,7 @@ template <typename ST>
 static hipError_t launch_ppo_grad_t(const float* const* w, float* const* grads, const int64_t* index, const float* obs,
                                     const float* actions, const float* old_logp, const float* adv, const float* ret,
                                     int64_t rows, float clip_range, float vf_coef, float ent_coef, float* stats, float* ws,
-                                    int in_dim, int act_dim, int cus, hipStream_t s) {
+                                    int in_dim, int act_dim, int cus, int path, hipStream_t s) {
     static bool attr_tab[64] = {};                    // hipFuncSetAttribute holds for one device: one flag per ordinal
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
@@ -738,6 +1395,12 @@ static hipError_t launch_ppo_grad_t(const float* const* w, float* const* grads, 
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)ppo_wgrad_kernel<ST>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(kWgradXchFloats * sizeof(float)));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)ppo_wgrad_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(kWgradXchFloats * sizeof(float)));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)ppo_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(kFusedFloats * sizeof(float)));
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -751,15 +1414,29 @@ static hipError_t launch_ppo_grad_t(const float* const* w, float* const* grads, 
     float* dmu = xg + rows * 24;
     float* dv = dmu + rows * 4;
     float* wave_stats = dv + (rows + 3) / 4 * 4;
-    float* part = wave_stats + (size_t)blocks * (kFwdBwdThreads / 64) * kWaveStats;
+    float* part = wave_stats + (size_t)ppo_stat_waves(rows, cus) * kWaveStats;
 
     PpoParams pp{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], in_dim, act_dim};
     hipLaunchKernelGGL(ppo_pack_kernel, dim3((kTImage + 255) / 256), dim3(256), 0, s, pp, image);
+    if (path == FPV_PPO_ONE_KERNEL && sizeof(ST) == 4) {
+        int frps;
+        const int fslabs = ppo_fused_slabs(rows, cus, &frps);
+        FusedArgs f{image, {w[2], w[9]}, index, obs, actions, old_logp, adv, ret, part, wave_stats,
+                    rows, clip_range, vf_coef, 1.0f / (float)rows, frps, fslabs, in_dim, act_dim};
+        hipLaunchKernelGGL(ppo_fused_kernel, dim3(fslabs, 2), dim3(256), kFusedFloats * sizeof(float), s, f);
+        ReduceArgs r{part, wave_stats, {}, stats, fslabs, 2 * fslabs * 4, in_dim, act_dim, 1.0f / (float)rows, ent_coef};
+        for (int k = 0; k < 13; ++k) r.g[k] = grads[k];
+        hipLaunchKernelGGL(ppo_reduce_kernel, dim3((2 * kPartStride + 31) / 32 + 1), dim3(256), 0, s, r);
+        return hipGetLastError();
+    }
     PpoArgs a{image, index, obs, actions, old_logp, adv, ret, mats, xg, dmu, dv, wave_stats,
               rows, clip_range, vf_coef, 1.0f / (float)rows, in_dim, act_dim};
     hipLaunchKernelGGL((ppo_fwd_bwd_kernel<kFwdBwdThreads, ST>), dim3(blocks), dim3(kFwdBwdThreads), lds_bytes, s, a);
     WgradArgs g{mats, xg, dmu, dv, part, rows, rps, slabs, in_dim, act_dim};
-    hipLaunchKernelGGL(ppo_wgrad_kernel<ST>, dim3(slabs, 2), dim3(512), kWgradXchFloats * sizeof(float), s, g);
+    if (path == FPV_PPO_TWO_KERNELS_BF16X6 && sizeof(ST) == 4)
+        hipLaunchKernelGGL(ppo_wgrad_split_kernel, dim3(slabs, 2), dim3(512), kWgradXchFloats * sizeof(float), s, g);
+    else
+        hipLaunchKernelGGL(ppo_wgrad_kernel<ST>, dim3(slabs, 2), dim3(512), kWgradXchFloats * sizeof(float), s, g);
     ReduceArgs r{part, wave_stats, {}, stats, slabs, blocks * (kFwdBwdThreads / 64), in_dim, act_dim, 1.0f / (float)rows, ent_coef};
     for (int k = 0; k < 13; ++k) r.g[k] = grads[k];
     hipLaunchKernelGGL(ppo_reduce_kernel, dim3((2 * kPartStride + 31) / 32 + 1), dim3(256), 0, s, r);
@@ -769,12 +1446,12 @@ static hipError_t launch_ppo_grad_t(const float* const* w, float* const* grads, 
 hipError_t launch_ppo_grad(const float* const* w, float* const* grads, const int64_t* index, const float* obs,
                            const float* actions, const float* old_logp, const float* adv, const float* ret, int64_t rows,
                            float clip_range, float vf_coef, float ent_coef, float* stats, float* ws, int in_dim, int act_dim,
-                           int cus, int storage, hipStream_t s) {
+                           int cus, int storage, int path, hipStream_t s) {
     if (storage == 1)
         return launch_ppo_grad_t<bf16_bits>(w, grads, index, obs, actions, old_logp, adv, ret, rows, clip_range, vf_coef,
-                                            ent_coef, stats, ws, in_dim, act_dim, cus, s);
+                                            ent_coef, stats, ws, in_dim, act_dim, cus, FPV_PPO_TWO_KERNELS, s);
     return launch_ppo_grad_t<float>(w, grads, index, obs, actions, old_logp, adv, ret, rows, clip_range, vf_coef, ent_coef,
-                                    stats, ws, in_dim, act_dim, cus, s);
+                                    stats, ws, in_dim, act_dim, cus, path, s);
 }
 
 }  // namespace fpv

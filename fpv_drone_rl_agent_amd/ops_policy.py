@@ -181,12 +181,17 @@ class FusedPolicy:
         return torch.empty((b.value + 3) // 4, dtype=torch.float32, device=self.device)
 
     def ppo_grad(self, obs, actions, old_logp, advantages, returns, *, index=None, rows=None, clip_range: float = 0.2,
-                 vf_coef: float = 0.5, ent_coef: float = 0.0, stats=None, workspace=None, storage: str = "f32"):
+                 vf_coef: float = 0.5, ent_coef: float = 0.0, stats=None, workspace=None, storage: str = "f32",
+                 path: str | None = None):
         """Gradient of SB3's PPO minibatch loss w.r.t. every parameter of the module, written into the parameters'
         .grad tensors by fpv_ppo_grad (forward, loss derivatives and backward as hand-written MFMA kernels; no torch
         autograd involved).  index: optional int64 row indices into the five arrays.  storage: "f32" (exact) or "bf16"
         (the activations / deltas pass between the kernels in bf16: half the HBM traffic, gradients within ~1e-3 of their
-        max-norm).  Returns stats[4] = (policy-gradient loss, value loss, approx KL, clip fraction)."""
+        max-norm; two-kernel path only).  path: "one_kernel" (FPV_PPO_ONE_KERNEL: forward, backward and weight gradients of a row
+        in one kernel, nothing stored; the default with fp32 storage), "two_kernels" (the activations / deltas pass through memory;
+        the default with bf16 storage) or "two_kernels_bf16x6" (as before, the weight-gradient products on the bf16 MFMA with every
+        fp32 operand cut into three bf16 pieces, six piece products per product: fp32-level error).
+        Returns stats[4] = (policy-gradient loss, value loss, approx KL, clip fraction)."""
         if index is not None:
             if index.dtype != torch.int64 or not index.is_contiguous():
                 raise ValueError("index must be a contiguous int64 device tensor")
@@ -212,6 +217,9 @@ class FusedPolicy:
             io.weights[k], io.grads[k] = w.data_ptr(), g.data_ptr()
         io.stats, io.workspace, io.workspace_bytes = _ptr(stats), _ptr(workspace), workspace.numel() * 4
         io.storage = {"f32": 0, "bf16": 1}[storage]
+        if path is None:
+            path = "one_kernel" if storage == "f32" else "two_kernels"
+        io.path = {"one_kernel": 0, "two_kernels": 1, "two_kernels_bf16x6": 2}[path]
         L.check(self.lib.fpv_ppo_grad(self._h, C.byref(io), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
                 "fpv_ppo_grad")
         return stats

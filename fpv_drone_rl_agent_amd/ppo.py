@@ -29,7 +29,7 @@ class PPO:
                  n_minibatches: int = 8, clip_range: float = 0.2, ent_coef: float = 0.0, vf_coef: float = 0.5,
                  max_grad_norm: float = 0.5, normalize_advantage: bool = True, target_kl: float | None = None,
                  use_graph: bool = True, fused_update: bool | None = None, log_std_min: float | None = None,
-                 grad_storage: str = "f32"):
+                 grad_storage: str = "f32", update_path: str | None = None):
         self.col = collector
         self.policy = collector.policy
         # capturable Adam: its step counter lives on the device, so one minibatch update (forward, loss, backward,
@@ -47,6 +47,13 @@ class PPO:
         if grad_storage not in ("f32", "bf16"):
             raise ValueError("grad_storage must be 'f32' or 'bf16'")
         self.grad_storage = grad_storage        # how fpv_ppo_grad passes activations between its kernels (ops_policy.ppo_grad)
+        if update_path is None:
+            update_path = "one_kernel" if grad_storage == "f32" else "two_kernels"
+        if update_path not in ("one_kernel", "two_kernels", "two_kernels_bf16x6") or (
+                grad_storage == "bf16" and update_path != "two_kernels"):
+            raise ValueError("update_path must be 'one_kernel', 'two_kernels' or 'two_kernels_bf16x6'; grad_storage='bf16' exists on "
+                             "'two_kernels' only")
+        self.update_path = update_path          # which kernels compute the gradient (ops_policy.ppo_grad's `path`)
         self._fp = fp
         self._ws = self._adv_n = None
         self._stats = torch.zeros(4, dtype=torch.float32, device=collector.device) if self.fused_update else None
@@ -102,7 +109,7 @@ class PPO:
         b = self._fused_src
         self._fp.ppo_grad(b["obs"], b["act"], b["old_lp"], b["adv"], b["ret"], index=idx, clip_range=self.clip_range,
                           vf_coef=self.vf_coef, ent_coef=self.ent_coef, stats=self._stats, workspace=self._ws,
-                          storage=self.grad_storage)
+                          storage=self.grad_storage, path=self.update_path)
         self._allreduce_grads()
         self.opt.step(self._flat_grad)
         if self.log_std_min is not None:

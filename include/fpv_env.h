@@ -375,6 +375,9 @@ int fpv_rollout_step(fpv_env* env, fpv_policy* pol, const fpv_policy_io* io, flo
  * the gradient of the MEAN loss over the rows is WRITTEN (not accumulated) to grads[]; optimiser, clipping and the
  * cross-rank all-reduce stay with the caller.  weights / grads: 13 DEVICE pointers each, in fpv_policy_load's order.
  * Deterministic (no atomics).  Everything is stream-ordered; nothing is allocated (graph-capturable). */
+#define FPV_PPO_ONE_KERNEL 0
+#define FPV_PPO_TWO_KERNELS 1
+#define FPV_PPO_TWO_KERNELS_BF16X6 2
 typedef struct {
     int64_t rows;             /* minibatch size M */
     const int64_t* index;     /* [M] device row indices into the arrays below, or NULL: rows 0..M-1 */
@@ -390,7 +393,13 @@ typedef struct {
     void* workspace;          /* device scratch, >= fpv_ppo_workspace_bytes(rows), 16-byte aligned */
     int64_t workspace_bytes;
     int32_t storage;          /* 0: activations / deltas pass between the kernels in fp32 (exact, default); 1: in bf16 —  */
-    int32_t reserved1;        /* half the HBM traffic of the update, gradients within ~1e-3 of their max-norm          */
+                              /* half the HBM traffic of the update, gradients within ~1e-3 of their max-norm          */
+    int32_t path;             /* FPV_PPO_ONE_KERNEL (0, default): forward, backward and the weight gradients of a row in  */
+                              /* one kernel, the activations / deltas never leave the CU (fp32; storage must be 0).       */
+                              /* FPV_PPO_TWO_KERNELS (1): they pass through memory between two kernels (`storage`).        */
+                              /* FPV_PPO_TWO_KERNELS_BF16X6 (2): as 1 with the weight-gradient products on the bf16 MFMA, */
+                              /* every fp32 operand cut into three bf16 pieces, six piece products per product (fp32      */
+                              /* accumulation, fp32-level error; storage 0 only).  Same results to fp32 summation order.  */
 } fpv_ppo_io;
 
 int fpv_ppo_workspace_bytes(fpv_policy* pol, int64_t rows, int64_t* bytes);

@@ -21,7 +21,10 @@ def _torch_grads(m, obs, act, old_lp, adv, ret, clip, vf, ent):
     return {n: p.grad.clone() for n, p in m.named_parameters()}, stats
 
 
-def _case(rows, obs_dim, act_dim, total=None, seed=0, ent=0.01, storage="f32", tol=2e-4):
+PATHS = ["one_kernel", "two_kernels", "two_kernels_bf16x6"]
+
+
+def _case(rows, obs_dim, act_dim, total=None, seed=0, ent=0.01, storage="f32", tol=2e-4, path=None):
     from fpv_drone_rl_agent_amd.ops_policy import FusedPolicy
     from fpv_drone_rl_agent_amd.policy import ActorCritic
     torch.manual_seed(seed)
@@ -46,7 +49,8 @@ def _case(rows, obs_dim, act_dim, total=None, seed=0, ent=0.01, storage="f32", t
     fp = FusedPolicy(m)
     for p in m.parameters():
         p.grad = torch.full_like(p, 7.0)        # the call overwrites, it does not accumulate
-    stats = fp.ppo_grad(obs, act, old_lp, adv, ret, index=idx, clip_range=0.2, vf_coef=0.5, ent_coef=ent, storage=storage)
+    stats = fp.ppo_grad(obs, act, old_lp, adv, ret, index=idx, clip_range=0.2, vf_coef=0.5, ent_coef=ent, storage=storage,
+                        path=path)
     torch.cuda.synchronize()
     for n, p in m.named_parameters():
         scale = want[n].abs().max().item()
@@ -56,36 +60,91 @@ def _case(rows, obs_dim, act_dim, total=None, seed=0, ent=0.01, storage="f32", t
     return m, fp
 
 
-def test_ppo_grad_matches_autograd_hover_shape():
-    _case(16384, 20, 4)
+@pytest.mark.parametrize("path", PATHS)
+def test_ppo_grad_matches_autograd_hover_shape(path):
+    _case(16384, 20, 4, path=path)
 
 
-def test_ppo_grad_gathered_minibatch():
-    _case(8192, 20, 4, total=32768, seed=1)
+@pytest.mark.parametrize("path", PATHS)
+def test_ppo_grad_gathered_minibatch(path):
+    _case(8192, 20, 4, total=32768, seed=1, path=path)
 
 
+@pytest.mark.parametrize("path", PATHS)
 @pytest.mark.parametrize("rows", [1, 31, 33, 130, 4099])
-def test_ppo_grad_ragged_rows(rows):
-    _case(rows, 20, 4, seed=rows)
+def test_ppo_grad_ragged_rows(rows, path):
+    _case(rows, 20, 4, seed=rows, path=path)
 
 
-def test_ppo_grad_yaw_shape():
-    _case(4096, 12, 1, seed=3, ent=0.0)
+@pytest.mark.parametrize("path", PATHS)
+def test_ppo_grad_full_minibatch_several_chunks_per_workgroup(path):
+    """65 536 rows gathered out of 131 072: the one-kernel path's workgroups take four 128-row chunks each."""
+    _case(65536, 20, 4, total=131072, seed=11, path=path)
 
 
-def test_ppo_grad_is_reproducible():
-    m, fp = _case(8192, 20, 4, seed=5)
+@pytest.mark.parametrize("path", PATHS)
+def test_ppo_grad_yaw_shape(path):
+    _case(4096, 12, 1, seed=3, ent=0.0, path=path)
+
+
+@pytest.mark.parametrize("path", PATHS)
+def test_ppo_grad_is_reproducible(path):
+    m, fp = _case(8192, 20, 4, seed=5, path=path)
     dev = torch.device("cuda:0")
     torch.manual_seed(9)
     obs = torch.randn(8192, 20, device=dev); act = torch.randn(8192, 4, device=dev)
     lp = torch.randn(8192, device=dev) - 4; adv = torch.randn(8192, device=dev); ret = torch.randn(8192, device=dev)
     ws = fp.ppo_workspace(8192)
-    fp.ppo_grad(obs, act, lp, adv, ret, workspace=ws)
+    fp.ppo_grad(obs, act, lp, adv, ret, workspace=ws, path=path)
     g1 = [p.grad.clone() for p in m.parameters()]
-    fp.ppo_grad(obs, act, lp, adv, ret, workspace=ws)
+    for _ in range(6):
+        fp.ppo_grad(obs, act, lp, adv, ret, workspace=ws, path=path)
     torch.cuda.synchronize()
     for a, p in zip(g1, m.parameters()):
         assert torch.equal(a, p.grad)
+
+
+@pytest.mark.parametrize("path", ["one_kernel", "two_kernels"])
+def test_ppo_grad_every_row_position_reaches_the_policy_gradient(path):
+    """One row at a time carries an advantage (all others 0, vf_coef = ent_coef = 0): the minibatch gradient of the policy tensors
+    must then be that row's own gradient times 1 / rows — a power of two here, so the comparison with the one-row minibatch is to
+    the last bit.  32 768 rows = two 128-row chunks per workgroup on the one-kernel path; every position of the first workgroup's
+    two chunks and 200 positions drawn over the rest are tried, launch after launch on the same workspace."""
+    from fpv_drone_rl_agent_amd.ops_policy import FusedPolicy
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    dev = torch.device("cuda:0")
+    torch.manual_seed(31)
+    rows = 32768
+    m = ActorCritic(20, 4, log_std_init=-0.5).to(dev)
+    with torch.no_grad():
+        m.action_net.weight.mul_(30.0)
+    fp = FusedPolicy(m)
+    obs = torch.randn(rows, 20, device=dev)
+    with torch.no_grad():
+        mean, _ = m.mean_value(obs)
+        act = mean + torch.exp(m.log_std) * torch.randn_like(mean)
+        old_lp = m.log_prob(mean, act) + 0.05 * torch.randn(rows, device=dev)      # inside the clip range: every row has a gradient
+    ret = torch.zeros(rows, device=dev)
+    ws, ws1 = fp.ppo_workspace(rows), fp.ppo_workspace(1)
+    names = [n for n, _ in m.named_parameters()]
+    pol = [k for k, n in enumerate(names) if not ("value" in n or "vf" in n)]
+    assert 0 < len(pol) < len(names)
+    g = torch.Generator().manual_seed(5)
+    positions = list(range(256)) + torch.randint(256, rows, (200,), generator=g).tolist()
+    adv = torch.zeros(rows, device=dev)
+    exact = 0
+    for k in positions:
+        adv.zero_(); adv[k] = 1.5
+        fp.ppo_grad(obs, act, old_lp, adv, ret, clip_range=0.2, vf_coef=0.0, ent_coef=0.0, workspace=ws, path=path)
+        full = [p.grad.clone() for p in m.parameters()]
+        idx = torch.tensor([k], device=dev, dtype=torch.int64)
+        fp.ppo_grad(obs, act, old_lp, adv, ret, index=idx, clip_range=0.2, vf_coef=0.0, ent_coef=0.0, workspace=ws1, path=path)
+        for j in pol:
+            one = list(m.parameters())[j].grad / rows
+            assert one.abs().max() > 0, (k, names[j])
+            assert torch.allclose(full[j], one, rtol=1e-5, atol=0.0), (k, names[j])
+            exact += int(torch.equal(full[j], one))
+    assert exact == len(pol) * len(positions), (exact, len(pol) * len(positions))
 
 
 def test_ppo_grad_argument_errors():
@@ -160,3 +219,49 @@ def test_ppo_grad_bf16_storage_stays_close(rows):
     """storage="bf16": the activations / deltas cross memory rounded to bf16 (2^-9 relative), the products stay fp32:
     every gradient tensor within 4e-3 of its max-norm (statistics and head inputs are not affected by the rounding)."""
     _case(rows, 20, 4, seed=rows + 1, storage="bf16", tol=4e-3)
+
+
+def test_ppo_grad_bf16_storage_is_refused_off_the_two_kernel_path():
+    from fpv_drone_rl_agent_amd.ops_policy import FusedPolicy
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    dev = torch.device("cuda:0")
+    fp = FusedPolicy(ActorCritic().to(dev))
+    obs = torch.randn(64, 20, device=dev); act = torch.randn(64, 4, device=dev); v = torch.randn(64, device=dev)
+    for path in ("one_kernel", "two_kernels_bf16x6"):
+        with pytest.raises(ValueError):
+            fp.ppo_grad(obs, act, v, v, v, storage="bf16", path=path)
+
+
+def test_ppo_grad_paths_against_the_float64_golden_vector():
+    """Against tests/golden/ppo_grad_v1.npz (torch autograd in float64): the one-kernel path's and the bf16 x 6 path's worst error
+    per tensor stay within 3 x the two-kernel fp32-MFMA path's (and within the same 1e-4 bar) — all three are fp32-level, which is
+    what lets the fastest one be the default; two launches give the same bits (no atomics, fixed order)."""
+    import os
+    import numpy as np
+    from fpv_drone_rl_agent_amd.ops_policy import FusedPolicy
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ppo_grad_v1.npz"))
+    dev = torch.device("cuda:0")
+    m = ActorCritic().to(dev)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            p.copy_(torch.from_numpy(g["param/" + n]).float())
+    t = lambda k: torch.from_numpy(g[k]).float().to(dev).contiguous()
+    fp = FusedPolicy(m)
+    errs = {}
+    for gemm in ("two_kernels", "two_kernels_bf16x6", "two_kernels_bf16x6", "one_kernel", "one_kernel"):
+        fp.ppo_grad(t("obs"), t("act"), t("old_lp"), t("adv"), t("ret"), clip_range=float(g["clip"]), vf_coef=float(g["vf"]),
+                    ent_coef=float(g["ent"]), path=gemm)
+        torch.cuda.synchronize()
+        got = {n: p.grad.clone() for n, p in m.named_parameters()}
+        if gemm in errs:
+            assert all(torch.equal(got[n], errs[gemm][1][n]) for n in got)          # bitwise reproducible
+        errs[gemm] = ({n: np.abs(got[n].double().cpu().numpy() - g["grad/" + n]).max() / (np.abs(g["grad/" + n]).max() + 1e-30)
+                       for n in got}, got)
+    for n in errs["two_kernels"][0]:
+        e32 = errs["two_kernels"][0][n]
+        for other in ("two_kernels_bf16x6", "one_kernel"):
+            eo = errs[other][0][n]
+            assert eo <= 1e-4 and eo <= 3 * e32 + 2e-7, (other, n, e32, eo)
+    print("golden errors (relative to each tensor's max-norm):",
+          {k: max(v[0].values()) for k, v in errs.items()})

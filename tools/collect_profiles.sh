@@ -25,8 +25,17 @@ cp gpurun_out/pmc_k0/summary.json profiles/${TAG}_rollout_step_pmc_raw.json
 { echo "# The boundary between rollouts (tools/trace_gaps.py on rocprofv3 kernel traces; durations under the profiler)"; echo;
   echo "## one 20-step rollout per timed region (python bench.py --steps 20 --warmup 5 --repeats 12): last rollout, then medians"; echo '```'; cat $O/boundary_s20.txt; echo '```'; echo;
   echo "## steady state (--steps 256 --warmup 32, 32-step rollouts back to back)"; echo '```'; cat $O/boundary_steady.txt; echo '```'; } > profiles/${TAG}_rollout_boundary.md
-{ echo "# PPO update (tools/microbench_ppo.py): HIP events, then rocprofv3 kernel statistics of the same script"; cat $O/ppo_events.json; echo;
-  head -12 "$(ls $O/prof_ppo/*/*kernel_stats.csv | head -1)"; } > profiles/${TAG}_ppo_update_profile.txt
+{ echo "# PPO update, one 65 536-row minibatch gathered out of 524 288 (tools/microbench_ppo.py): HIP events per path (gradient + clip + Adam),"
+  echo "# then rocprofv3 kernel statistics of the same script, path by path"; cat $O/ppo_events.json; echo;
+  for path in one_kernel two_kernels two_kernels_bf16x6; do
+    echo "## path = $path"; python3 - "$(ls $O/prof_ppo_$path/*/*kernel_stats.csv | head -1)" <<'PY'
+import csv, sys
+print('"Name","Calls","AverageNs","MinNs","MaxNs"')
+for r in csv.DictReader(open(sys.argv[1])):
+    if "fpv::" in r["Name"]:
+        print('"%s",%s,%.0f,%s,%s' % (r["Name"], r["Calls"], float(r["AverageNs"]), r["MinNs"], r["MaxNs"]))
+PY
+  done; } > profiles/${TAG}_ppo_update_profile.txt
 tail -3 $O/tests.txt > profiles/${TAG}_gpu_tests_tail.txt
 [ -f $O/bench_rehearsed_ranks.json ] && last $O/bench_rehearsed_ranks.json > profiles/${TAG}_bench_line_rehearsed_ranks.json
 ls -la profiles/${TAG}_* | awk '{print $5, $9}'

@@ -30,8 +30,11 @@ bash tools/pmc_rollstep.sh > $O/pmc_k0.txt 2>&1
 python tools/step_sweep.py $O/step_sweep_pixel.json pixel > /dev/null 2>&1
 python tools/step_quad_sweep.py $O/step_quad_sweep.json > /dev/null 2>&1
 python tools/trajectory_drift.py > $O/fp32_vs_fp64_trajectory.json 2> /dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ppo -- python3 tools/microbench_ppo.py > $O/prof_ppo.log 2>&1
-python tools/microbench_ppo.py > $O/ppo_events.json 2> /dev/null
+for path in one_kernel two_kernels two_kernels_bf16x6; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ppo_$path -- python3 tools/microbench_ppo.py 65536 524288 50 f32 $path > $O/prof_ppo_$path.log 2>&1
+  python tools/microbench_ppo.py 65536 524288 50 f32 $path >> $O/ppo_events.json 2> /dev/null
+done
+python tools/microbench_ppo.py 65536 524288 50 bf16 two_kernels >> $O/ppo_events.json 2> /dev/null
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -size +3M -delete
 python - <<'PY'
 import json
