@@ -37,6 +37,8 @@ def main():
                                                  "as train_hover.py:62-63 does")
     ap.add_argument("--grad-storage", choices=["f32", "bf16"], default="f32",
                     help="how the update kernels pass activations through memory: bf16 halves that traffic")
+    ap.add_argument("--update-path", choices=["one_kernel", "two_kernels", "two_kernels_bf16x6"], default=None,
+                    help="which kernels compute the minibatch gradient (default: one_kernel with fp32 storage)")
     ap.add_argument("--autograd-update", action="store_true",
                     help="minibatch gradient through torch autograd instead of the fpv_ppo_grad kernels")
     args = ap.parse_args()
@@ -51,11 +53,13 @@ def main():
     col = RolloutCollector(eng, policy, n_steps=args.n_steps, policy_seed=args.seed, gamma=args.gamma)
     model = PPO(col, learning_rate=args.lr, n_epochs=args.epochs, n_minibatches=args.minibatches, ent_coef=args.ent_coef,
                 target_kl=args.target_kl, fused_update=not args.autograd_update, log_std_min=args.log_std_min,
-                grad_storage=args.grad_storage)
+                grad_storage=args.grad_storage, update_path=args.update_path)
     t0 = time.time()
     model.learn(int(args.timesteps), log_every=args.log_every)
     if rank == 0:
-        print({"wall_s": round(time.time() - t0, 1), "timesteps": model.num_timesteps, **model.logger})
+        wall = time.time() - t0
+        print({"wall_s": round(wall, 1), "timesteps": model.num_timesteps, "env_steps_per_s_with_updates": round(model.num_timesteps / wall),
+               **model.logger})
         if args.save:
             from fpv_drone_rl_agent_amd.checkpoint import save_model, save_normalizer
             save_model(args.save, model)

@@ -44,7 +44,9 @@ constexpr float kTanhPrescale = 2.8853900817779268f;
 #ifndef FPV_TANH_FOLD
 #define FPV_TANH_FOLD 1
 #endif
-__device__ __forceinline__ float fast_tanh_prescaled(float z) {
+// What a hidden layer hands to the next one ("the carrier"): with the fold r = (1 - tanh x) / 2, NOT tanh x — only a consumer whose
+// image was packed by policy_pack_kernel of the same build (-2 W, b + sum W) may take it; without the fold tanh x itself.
+__device__ __forceinline__ float tanh_carrier_prescaled(float z) {
 #if FPV_TANH_FOLD
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z));          // r; the consumer's image holds -2 W and b + sum W
 #else
@@ -65,11 +67,11 @@ __device__ __forceinline__ void bias_init(Hidden& a, const float* __restrict__ l
     }
 }
 
-__device__ __forceinline__ void tanh_all_prescaled(Hidden& a) {
+__device__ __forceinline__ void carrier_all_prescaled(Hidden& a) {
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a.t[m][r] = fast_tanh_prescaled(a.t[m][r]);
+        for (int r = 0; r < 16; ++r) a.t[m][r] = tanh_carrier_prescaled(a.t[m][r]);
 }
 
 __device__ __forceinline__ void tanh_all(Hidden& a) {

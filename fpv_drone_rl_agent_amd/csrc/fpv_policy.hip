@@ -54,7 +54,7 @@ __global__ void policy_pack_kernel(PolicyParams p, float* __restrict__ img) {
                 for (int k = 0; k < kHid; ++k) b += (double)w2[j * kHid + k];
             v = (float)b;
         }
-        v *= kTanhPrescale;                     // both hidden layers end in tanh: fast_tanh_prescaled (fpv_mlp.h)
+        v *= kTanhPrescale;                     // both hidden layers end in tanh: tanh_carrier_prescaled (fpv_mlp.h)
     } else {
         const int q = e - kHeadBase;
         if (q < 512) {                          // Wa[h][kt][r][o]
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(THREADS) void policy_forward_kernel(PolicyArgs p, i
                         a.t[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(nb[kOffW1 + (m * 12 + s) * 64 + lane], x[s], a.t[m], 0, 0, 0);
                 }
             FPV_STAMP(4 + 5 * sl);
-            tanh_all_prescaled(a);
+            carrier_all_prescaled(a);
             FPV_STAMP(5 + 5 * sl);
             // ---- layer 2: 128 -> 128; the layer-1 tiles are the B operands as they stand
             Hidden c;
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(THREADS) void policy_forward_kernel(PolicyArgs p, i
                             c.t[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[m][rr], a.t[kt][4 * r4 + rr], c.t[m], 0, 0, 0);
                 }
             FPV_STAMP(6 + 5 * sl);
-            tanh_all_prescaled(c);
+            carrier_all_prescaled(c);
             FPV_STAMP(7 + 5 * sl);
             // ---- heads on the VALU: this lane holds 64 of its drone's 128 hidden values
             if (net == 0) {

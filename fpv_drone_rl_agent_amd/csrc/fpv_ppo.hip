@@ -802,12 +802,13 @@ __global__ __launch_bounds__(256) void ppo_fused_kernel(FusedArgs p) {
     load_w1();
 
     // weight-gradient sums of this wave's output rows over the whole slab
-    f32x16 w2s[4], w1s, hds;
+    f32x16 w2s[4], w1s;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        w2s[0][r] = 0.f; w2s[1][r] = 0.f; w2s[2][r] = 0.f; w2s[3][r] = 0.f; w1s[r] = 0.f; hds[r] = 0.f;
+        w2s[0][r] = 0.f; w2s[1][r] = 0.f; w2s[2][r] = 0.f; w2s[3][r] = 0.f; w1s[r] = 0.f;
     }
-    float sb2 = 0.f, sb1 = 0.f, sbh = 0.f;
+    float hd4[4] = {0.f, 0.f, 0.f, 0.f}, sb4[4] = {0.f, 0.f, 0.f, 0.f};      // head gradient of hidden unit 32 wave + i, head bias
+    float sb2 = 0.f, sb1 = 0.f;
     float* const M = lds + kFOffM;
     float* const XS = lds + kFOffX;
     float* const DO = lds + kFOffDo;
@@ -815,6 +816,7 @@ __global__ __launch_bounds__(256) void ppo_fused_kernel(FusedArgs p) {
     const int srow = wave * 32 + col;                            // this lane's row inside the chunk
     // the first chunk's row index and x (every later chunk's are asked for during the chunk before)
     int64_t src_next = n0 + srow < n1 ? (p.index ? p.index[n0 + srow] : n0 + srow) : 0;
+    int64_t src_after = n0 + 128 + srow < n1 ? (p.index ? p.index[n0 + 128 + srow] : n0 + 128 + srow) : 0;
     f32x4 xn[3];
     {
         const f32x4* row = reinterpret_cast<const f32x4*>(p.obs + src_next * p.in_dim);
@@ -1020,47 +1022,32 @@ __global__ __launch_bounds__(256) void ppo_fused_kernel(FusedArgs p) {
 #pragma unroll
             for (int q = 0; q < 3; ++q) xr[q] = row[4 * (3 * h + q) < p.in_dim ? 3 * h + q : 0];
         }
-        // and the next chunk's row index and x
+        // and the next chunk's x, through the row index asked for a chunk ago; the index of the chunk after that is asked for now
+        // (a gathered x behind a gathered index would be two misses in a row)
         {
-            const int64_t nn = n + 128;
-            src_next = nn < n1 ? (p.index ? p.index[nn] : nn) : 0;
+            src_next = src_after;
             const f32x4* row = reinterpret_cast<const f32x4*>(p.obs + src_next * p.in_dim);
 #pragma unroll
             for (int q = 0; q < 3; ++q) xn[q] = row[4 * (3 * h + q) < p.in_dim ? 3 * h + q : 0];
+            const int64_t na = n + 256;
+            src_after = na < n1 ? (p.index ? p.index[na] : na) : 0;
         }
         // K = the chunk's 128 rows, two per product (row 2 s + kk); operands of the next group of k-steps are asked for before the
         // current group is multiplied (pinned with scheduling fences, as in ppo_wgrad_kernel).
         lds_barrier();                                           // H2 and d out of all four waves are in place
         PPO_STAMP(ck + 4);
-        {                                                        // head gradient += d out^T H2
-            constexpr int G = 8;
-            struct Grp { float hh[G], ah[G]; };
+        {
+            // head gradient += d out^T H2 on the vector pipe: four (or one) outputs per hidden unit would fill an eighth of an MFMA
+            // tile, and a lone wave's two LDS reads per product cost more than the product.  Lane (i, kk) owns hidden unit
+            // 32 wave + i and the rows 2 s + kk: 64 reads of H2, 64 broadcast reads of d out, 256 fmas.
             const float* HH = M + kk * kFRow + 32 * wave + i;
-            const float* AH = DO + kk * 4 + (i < 4 ? i : 3);
-            auto load = [&](Grp& o, int s0) {
-#pragma unroll
-                for (int u = 0; u < G; ++u) { o.hh[u] = HH[2 * (s0 + u) * kFRow]; o.ah[u] = AH[2 * (s0 + u) * 4]; }
-            };
-            auto fma = [&](const Grp& o) {
-#pragma unroll
-                for (int u = 0; u < G; ++u) {
-                    const float ah = ah_on ? o.ah[u] : 0.f;
-                    hds = __builtin_amdgcn_mfma_f32_32x32x2f32(ah, o.hh[u], hds, 0, 0, 0);
-                    sbh += ah;
-                }
-            };
-            Grp P, Q;
-            load(P, 0);
-#pragma unroll 1
-            for (int s0 = 0; s0 < 64; s0 += 2 * G) {
-                load(Q, s0 + G);
-                __builtin_amdgcn_sched_barrier(0);
-                fma(P);
-                __builtin_amdgcn_sched_barrier(0);
-                load(P, s0 + 2 * G < 64 ? s0 + 2 * G : 0);
-                __builtin_amdgcn_sched_barrier(0);
-                fma(Q);
-                __builtin_amdgcn_sched_barrier(0);
+            const f32x4* DV = reinterpret_cast<const f32x4*>(DO) + kk;
+#pragma unroll 8
+            for (int s = 0; s < 64; ++s) {
+                const float hh = HH[2 * s * kFRow];
+                const f32x4 d = DV[2 * s];
+                hd4[0] += d.x * hh; hd4[1] += d.y * hh; hd4[2] += d.z * hh; hd4[3] += d.w * hh;
+                sb4[0] += d.x; sb4[1] += d.y; sb4[2] += d.z; sb4[3] += d.w;
             }
         }
         PPO_STAMP(ck + 5);
@@ -1139,11 +1126,15 @@ __global__ __launch_bounds__(256) void ppo_fused_kernel(FusedArgs p) {
 #pragma unroll
                 for (int u = 0; u < G; ++u) { o.a1[u] = A1[2 * (s0 + u) * kFRow]; o.xv[u] = XV[2 * (s0 + u) * 24]; }
             };
+            f32x16 odd;                                          // (the second chain, as in the head gradient)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) odd[r] = 0.f;
             auto fma = [&](const Grp& o) {
 #pragma unroll
                 for (int u = 0; u < G; ++u) {
                     const float xv = x_on ? o.xv[u] : 0.f;
-                    w1s = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a1[u], xv, w1s, 0, 0, 0);
+                    if (u & 1) odd = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a1[u], xv, odd, 0, 0, 0);
+                    else w1s = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a1[u], xv, w1s, 0, 0, 0);
                     sb1 += o.a1[u];
                 }
             };
@@ -1160,6 +1151,8 @@ __global__ __launch_bounds__(256) void ppo_fused_kernel(FusedArgs p) {
                 fma(Q);
                 __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) w1s[r] += odd[r];
         }
     }
 
@@ -1175,16 +1168,18 @@ __global__ __launch_bounds__(256) void ppo_fused_kernel(FusedArgs p) {
             for (int jt = 0; jt < 4; ++jt) out[kPW2 + o * kHid + 32 * jt + i] = w2s[jt][r];
             if (x_on) out[kPW1 + o * p.in_dim + i] = w1s[r];
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            hd4[j] = half_sum(hd4[j]); sb4[j] = half_sum(sb4[j]);
+        }
+        sb2 = half_sum(sb2); sb1 = half_sum(sb1);
         if (kk == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (r < nh) out[kPWh + r * kHid + 32 * w + i] = hds[r];
-        }
-        sb2 = half_sum(sb2); sb1 = half_sum(sb1); sbh = half_sum(sbh);
-        if (kk == 0) {
+            for (int j = 0; j < 4; ++j)
+                if (j < nh) out[kPWh + j * kHid + 32 * w + i] = hd4[j];
             out[kPB2 + 32 * w + i] = sb2;
             out[kPB1 + 32 * w + i] = sb1;
-            if (w == 0 && ah_on) out[kPBh + i] = sbh;
+            if (w == 0 && ah_on) out[kPBh + i] = i == 0 ? sb4[0] : (i == 1 ? sb4[1] : (i == 2 ? sb4[2] : sb4[3]));
         }
     }
 #pragma unroll

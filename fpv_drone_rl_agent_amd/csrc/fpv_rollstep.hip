@@ -144,7 +144,7 @@ __device__ __forceinline__ f32x4 rs_policy_core(const float* lds, const f32x2 (&
 #pragma unroll
             for (int m = 0; m < 4; ++m)
                 a.t[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(nb[kOffW1 + (m * 12 + s) * 64 + lane], x[s], a.t[m], 0, 0, 0);
-        tanh_all_prescaled(a);
+        carrier_all_prescaled(a);
         Hidden c;
         bias_init(c, nb + kOffB2, h);
 #pragma unroll
@@ -161,7 +161,7 @@ __device__ __forceinline__ f32x4 rs_policy_core(const float* lds, const f32x2 (&
                     for (int m = 0; m < 4; ++m)
                         c.t[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[m][rr], a.t[kt][4 * r4 + rr], c.t[m], 0, 0, 0);
             }
-        tanh_all_prescaled(c);
+        carrier_all_prescaled(c);
         if (net == 0) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)

@@ -45,12 +45,15 @@ def test_fused_forward_matches_torch(n, gemm):
     assert (out["clipped"].abs() == 1).any() or n < 31   # the clip is exercised
 
 
-@pytest.mark.parametrize("grow", [1.0, 3.0])
-def test_folded_tanh_image_keeps_fp32_accuracy(grow):
+@pytest.mark.parametrize("grow,shift,tol", [(1.0, 0.0, 2e-6), (3.0, 0.05, 2e-6), (3.0, 0.5, 1e-5)])
+def test_folded_tanh_image_keeps_fp32_accuracy(grow, shift, tol):
     """The exact-fp32 image hands r = 1 / (1 + e^{2x}) from layer to layer and carries -2 W and b + sum_k W_k for the layer that
     consumes it (FPV_TANH_FOLD, csrc/fpv_mlp.h): W tanh(x) + b up to rounding.  Against an fp64 evaluation of the module, with the
     initial weights and with hidden weights grown 3x and row sums pushed up (what the fold is sensitive to), every row:
-    errors stay at fp32 rounding level relative to the largest output (profiles/r03_tanh_fold.json has the measured figures)."""
+    errors stay at fp32 rounding level relative to the largest output (profiles/r03_tanh_fold.json has the measured figures).
+    shift = 0.5 moves every row sum of layer 2 by 64 — the partial sums of the folded chain then start near 64 instead of near b (the
+    large same-sign row sums of a trained net, the case the fold's cancellation could lose bits in): measured 4.7e-6 (action mean)
+    and 5.3e-6 (value) of the largest output there, 2.5 x the unshifted case — pinned at 1e-5."""
     import copy
     from fpv_drone_rl_agent_amd.ops_policy import FusedPolicy
     from fpv_drone_rl_agent_amd.policy import ActorCritic
@@ -59,8 +62,8 @@ def test_folded_tanh_image_keeps_fp32_accuracy(grow):
     with torch.no_grad():
         for lin in (m.pi[0], m.pi[2], m.vf[0], m.vf[2]):
             lin.weight.mul_(grow); lin.bias.normal_(0, 0.3)
-        if grow > 1:
-            m.pi[2].weight.add_(0.05); m.vf[2].weight.add_(0.05)       # every row sum of layer 2 moves by 6.4
+        if shift:
+            m.pi[2].weight.add_(shift); m.vf[2].weight.add_(shift)     # every row sum of layer 2 moves by 128 shift
         m.action_net.weight.mul_(30.0); m.value_net.weight.mul_(3.0)
     k = FusedPolicy(m)
     m64 = copy.deepcopy(m).double()
@@ -70,8 +73,10 @@ def test_folded_tanh_image_keeps_fp32_accuracy(grow):
             mu64, v64 = m64.mean_value(obs.double())
         a = torch.zeros(65536, 4, device="cuda")
         r = k.forward(obs, action=a, deterministic=True)
-        assert float((a.double() - mu64).abs().max()) <= 2e-6 * max(1.0, float(mu64.abs().max())), trial
-        assert float((r["value"].double() - v64).abs().max()) <= 2e-6 * max(1.0, float(v64.abs().max())), trial
+        e_mu = float((a.double() - mu64).abs().max()) / max(1.0, float(mu64.abs().max()))
+        e_v = float((r["value"].double() - v64).abs().max()) / max(1.0, float(v64.abs().max()))
+        print("fold accuracy", grow, shift, trial, "mu %.3g value %.3g" % (e_mu, e_v))
+        assert e_mu <= tol and e_v <= tol, (trial, e_mu, e_v)
 
 
 def test_raw_obs_path_and_deterministic():

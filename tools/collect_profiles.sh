@@ -25,6 +25,11 @@ cp gpurun_out/pmc_k0/summary.json profiles/${TAG}_rollout_step_pmc_raw.json
 { echo "# The boundary between rollouts (tools/trace_gaps.py on rocprofv3 kernel traces; durations under the profiler)"; echo;
   echo "## one 20-step rollout per timed region (python bench.py --steps 20 --warmup 5 --repeats 12): last rollout, then medians"; echo '```'; cat $O/boundary_s20.txt; echo '```'; echo;
   echo "## steady state (--steps 256 --warmup 32, 32-step rollouts back to back)"; echo '```'; cat $O/boundary_steady.txt; echo '```'; } > profiles/${TAG}_rollout_boundary.md
+[ -f $O/ppo_stamps.txt ] && { echo "# tools/ppo_stamps.py on the -DFPV_PPO_STAMPS=1 build: s_memrealtime stamps of two workgroups of ppo_fused_kernel, 65 536 rows"; cat $O/ppo_stamps.txt; } > profiles/${TAG}_ppo_one_kernel_phases.txt
+[ -f $O/ppo_rows_sweep.jsonl ] && cp $O/ppo_rows_sweep.jsonl profiles/${TAG}_ppo_rows_sweep.jsonl
+{ echo "# PPO training end to end (pixel detector, one-kernel update): python examples/train_hover.py --drones 16384 --timesteps 3e8 --log-every 20"
+  grep "^{" $O/train_16384.log; echo; echo "# --drones 65536 --timesteps 6e8"; grep "^{" $O/train_65536.log; echo
+  echo "# --drones 65536 --timesteps 6e8 --update-path two_kernels (round 3's update)"; grep "^{" $O/train_65536_two_kernels.log | tail -2; } > profiles/${TAG}_train_hover_curves.txt
 { echo "# PPO update, one 65 536-row minibatch gathered out of 524 288 (tools/microbench_ppo.py): HIP events per path (gradient + clip + Adam),"
   echo "# then rocprofv3 kernel statistics of the same script, path by path"; cat $O/ppo_events.json; echo;
   for path in one_kernel two_kernels two_kernels_bf16x6; do

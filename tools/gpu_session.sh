@@ -30,11 +30,24 @@ bash tools/pmc_rollstep.sh > $O/pmc_k0.txt 2>&1
 python tools/step_sweep.py $O/step_sweep_pixel.json pixel > /dev/null 2>&1
 python tools/step_quad_sweep.py $O/step_quad_sweep.json > /dev/null 2>&1
 python tools/trajectory_drift.py > $O/fp32_vs_fp64_trajectory.json 2> /dev/null
+# PPO training end to end (learning curve + wall clock), the default update path and the two-kernel one
+python examples/train_hover.py --drones 16384 --timesteps 3e8 --log-every 20 > $O/train_16384.log 2>&1
+python examples/train_hover.py --drones 65536 --timesteps 6e8 --log-every 20 > $O/train_65536.log 2>&1
+python examples/train_hover.py --drones 65536 --timesteps 6e8 --log-every 80 --update-path two_kernels > $O/train_65536_two_kernels.log 2>&1
 for path in one_kernel two_kernels two_kernels_bf16x6; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ppo_$path -- python3 tools/microbench_ppo.py 65536 524288 50 f32 $path > $O/prof_ppo_$path.log 2>&1
   python tools/microbench_ppo.py 65536 524288 50 f32 $path >> $O/ppo_events.json 2> /dev/null
 done
 python tools/microbench_ppo.py 65536 524288 50 bf16 two_kernels >> $O/ppo_events.json 2> /dev/null
+python tools/microbench_ppo.py 262144 2097152 20 f32 one_kernel >> $O/ppo_events.json 2> /dev/null
+python tools/microbench_ppo.py 262144 2097152 20 f32 two_kernels >> $O/ppo_events.json 2> /dev/null
+bash tools/ppo_rows_sweep.sh > /dev/null 2>&1; cp gpurun_out/ppo_sweep/sweep.jsonl $O/ppo_rows_sweep.jsonl
+# phase stamps of the one-kernel gradient: the diagnostic build (FPV_EXTRA_HIPCC_FLAGS=-DFPV_PPO_STAMPS=1, kept as variants/ppo_stamps.so)
+if [ -f variants/ppo_stamps.so ]; then
+  cp fpv_drone_rl_agent_amd/libfpv_env.so /tmp/keep_product.so && cp variants/ppo_stamps.so fpv_drone_rl_agent_amd/libfpv_env.so
+  python tools/ppo_stamps.py > $O/ppo_stamps.txt 2> /dev/null
+  cp /tmp/keep_product.so fpv_drone_rl_agent_amd/libfpv_env.so
+fi
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -size +3M -delete
 python - <<'PY'
 import json

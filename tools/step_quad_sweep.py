@@ -18,7 +18,7 @@ lib = L_.load()
 out_path = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/step_quad_sweep.json"
 rows = []
 for detector in ("pixel", "analytic"):
-    for n in (4096, 16384, 32768, 65536, 131072, 262144, 524288):
+    for n in (1024, 4096, 16384, 32768, 65536, 131072, 262144, 524288):
         L = 200
         rec = {"detector": detector, "drones": n}
         outs = {}
