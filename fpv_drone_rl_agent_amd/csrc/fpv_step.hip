@@ -396,7 +396,7 @@ int64_t g_pair_max_tiles = 512;   // step_kernel_pair up to 32 768 drones: P and
 // profiles/r03_step_quad_sweep.json): 16 384 drones 16.0 -> 15.5, 32 768 17.5 -> 16.0, 65 536 19.3 -> 17.2 (fused 21.1 -> 17.8);
 // 131 072 26.7 -> 31.2 (100 KB of LDS per workgroup: one workgroup per CU); with the analytic detector it loses at every size
 // (65 536: 12.2 -> 13.1).  Same bits either way.
-// Round 4, with the contour pipeline restated in full (the detector is 2.5 x the work): the window is what
+// Round 4, with the contour pipeline restated in full: the window is what
 // profiles/r04_step_quad_sweep.json measured — 1 024 drones 28.7 -> 22.9 us, 4 096 32.2 -> 25.8, 65 536 38.3 -> 29.6; 131 072 50.4 -> 52.8,
 // 524 288 141 -> 186 (beyond one workgroup per CU the plain kernel's eight waves per CU hide the contour chain better than four
 // tiles' pooled lane groups behind 100 KB of LDS) — hence every multiple of 256 up to 65 536.
