@@ -13,7 +13,7 @@ from .build import LIB_PATH, LIB_PATH_EXPERIMENTS, build_extension
 FPV_F32, FPV_F64 = 0, 1
 TASK_HOVER, TASK_YAW = 0, 1
 DETECTOR_PIXEL, DETECTOR_ANALYTIC = 0, 1   # fpv_detector: the reference's pixel rules are the default
-ABI_VERSION = 3                              # FPV_ABI_VERSION of include/fpv_env.h this binding was written against
+ABI_VERSION = 4                              # FPV_ABI_VERSION of include/fpv_env.h this binding was written against
 STATE_WORDS, OBS_WORDS, ACT_WORDS = 36, 20, 4
 INFO_TERMINATED, INFO_TRUNCATED, INFO_OUT_OF_BOUNDS, INFO_ON_FLOOR = 1, 2, 4, 8
 

@@ -29,8 +29,9 @@ extern "C" {
  * compares the two before its first call (fpv_step_extras grew and fpv_detector was renumbered between 1 and 2, so a host
  * built against another header would pass structs of another size).  History: 1 = rounds 1-2; 2 = round 3
  * (FPV_DETECTOR_PIXEL = 0 is the default, debug hooks moved to fpv_env_debug.h); 3 = fpv_ledger_scan(status_out),
- * fpv_policy_io.scatter_*, the whole-rollout launch moved to fpv_env_experiments.h. */
-#define FPV_ABI_VERSION 3
+ * fpv_policy_io.scatter_*, the whole-rollout launch moved to fpv_env_experiments.h; 4 = round 4: fpv_ppo_io.reserved1 became
+ * fpv_ppo_io.path (same layout; 0 now selects the one-kernel gradient), fpv_ppo_workspace_bytes covers every path. */
+#define FPV_ABI_VERSION 4
 
 #define FPV_STATE_WORDS 36 /* docs/SPEC.md §2 canonical order */
 #define FPV_OBS_WORDS 20   /* simulation/hover.py:63-70 */
