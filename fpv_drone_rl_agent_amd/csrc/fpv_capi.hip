@@ -783,8 +783,8 @@ int fpv_ppo_grad(fpv_policy* p, const fpv_ppo_io* io, void* stream) {
     if (((uintptr_t)io->obs | act_rows | (uintptr_t)io->workspace) & 15)
         return fail(FPV_ERR_ARG, "fpv_ppo_grad: row buffers and workspace must be 16-byte aligned");
     if (io->storage != 0 && io->storage != 1) return fail(FPV_ERR_ARG, "fpv_ppo_grad: storage must be 0 (fp32) or 1 (bf16)");
-    if (io->path < FPV_PPO_ONE_KERNEL || io->path > FPV_PPO_TWO_KERNELS_BF16X6)
-        return fail(FPV_ERR_ARG, "fpv_ppo_grad: path must be FPV_PPO_ONE_KERNEL, FPV_PPO_TWO_KERNELS or FPV_PPO_TWO_KERNELS_BF16X6");
+    if (io->path < FPV_PPO_ONE_KERNEL || io->path > FPV_PPO_TWO_KERNELS_BF16X3)
+        return fail(FPV_ERR_ARG, "fpv_ppo_grad: path must be FPV_PPO_ONE_KERNEL, FPV_PPO_TWO_KERNELS, FPV_PPO_TWO_KERNELS_BF16X6 or FPV_PPO_TWO_KERNELS_BF16X3");
     if (io->path != FPV_PPO_TWO_KERNELS && io->storage == 1)
         return fail(FPV_ERR_ARG, "fpv_ppo_grad: bf16 storage exists on the FPV_PPO_TWO_KERNELS path only (nothing is stored on the "
                                  "one-kernel path; the bf16 x 6 products split fp32 operands)");

@@ -579,16 +579,22 @@ __device__ __forceinline__ Pieces pieces_of(const float (&v)[8]) {
     }
     return o;
 }
+// TERMS = 6: every piece product down to 2^-24 of the product; TERMS = 3 (FPV_PPO_TWO_KERNELS_BF16X3, kept to have its error on
+// record): w2 x1 + w1 x2 + w1 x1 only — operands good to 16 bits, products to ~2^-16
+template <int TERMS>
 __device__ __forceinline__ f32x16 mfma6_pieces(const Pieces& w, const Pieces& x, f32x16 acc) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p3, x.p1, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p1, x.p3, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p2, x.p2, acc, 0, 0, 0);
+    if (TERMS == 6) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p3, x.p1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p1, x.p3, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p2, x.p2, acc, 0, 0, 0);
+    }
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p2, x.p1, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p1, x.p2, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p1, x.p1, acc, 0, 0, 0);
     return acc;
 }
 
+template <int TERMS>
 __global__ __launch_bounds__(512) void ppo_wgrad_split_kernel(WgradArgs p) {
     extern __shared__ __attribute__((aligned(16))) float xch[];     // [4 waves][99][64 lanes]
     const int net = blockIdx.y, slab = blockIdx.x;
@@ -642,9 +648,9 @@ __global__ __launch_bounds__(512) void ppo_wgrad_split_kernel(WgradArgs p) {
         }
         const Pieces pa2 = pieces_of(a2);
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt) w2[jt] = mfma6_pieces(pa2, pieces_of(b[jt]), w2[jt]);
-        w1 = mfma6_pieces(pieces_of(a1), pieces_of(x), w1);
-        hd = mfma6_pieces(pieces_of(ah), pieces_of(hh), hd);
+        for (int jt = 0; jt < 4; ++jt) w2[jt] = mfma6_pieces<TERMS>(pa2, pieces_of(b[jt]), w2[jt]);
+        w1 = mfma6_pieces<TERMS>(pieces_of(a1), pieces_of(x), w1);
+        hd = mfma6_pieces<TERMS>(pieces_of(ah), pieces_of(hh), hd);
     }
 
     // ---- set 1 hands its sums to set 0 (as in ppo_wgrad_kernel)
@@ -1391,7 +1397,10 @@ static hipError_t launch_ppo_grad_t(const float* const* w, float* const* grads, 
             e = hipFuncSetAttribute((const void*)ppo_wgrad_kernel<ST>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(kWgradXchFloats * sizeof(float)));
         if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)ppo_wgrad_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+            e = hipFuncSetAttribute((const void*)ppo_wgrad_split_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(kWgradXchFloats * sizeof(float)));
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)ppo_wgrad_split_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)(kWgradXchFloats * sizeof(float)));
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void*)ppo_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1429,7 +1438,9 @@ static hipError_t launch_ppo_grad_t(const float* const* w, float* const* grads, 
     hipLaunchKernelGGL((ppo_fwd_bwd_kernel<kFwdBwdThreads, ST>), dim3(blocks), dim3(kFwdBwdThreads), lds_bytes, s, a);
     WgradArgs g{mats, xg, dmu, dv, part, rows, rps, slabs, in_dim, act_dim};
     if (path == FPV_PPO_TWO_KERNELS_BF16X6 && sizeof(ST) == 4)
-        hipLaunchKernelGGL(ppo_wgrad_split_kernel, dim3(slabs, 2), dim3(512), kWgradXchFloats * sizeof(float), s, g);
+        hipLaunchKernelGGL(ppo_wgrad_split_kernel<6>, dim3(slabs, 2), dim3(512), kWgradXchFloats * sizeof(float), s, g);
+    else if (path == FPV_PPO_TWO_KERNELS_BF16X3 && sizeof(ST) == 4)
+        hipLaunchKernelGGL(ppo_wgrad_split_kernel<3>, dim3(slabs, 2), dim3(512), kWgradXchFloats * sizeof(float), s, g);
     else
         hipLaunchKernelGGL(ppo_wgrad_kernel<ST>, dim3(slabs, 2), dim3(512), kWgradXchFloats * sizeof(float), s, g);
     ReduceArgs r{part, wave_stats, {}, stats, slabs, blocks * (kFwdBwdThreads / 64), in_dim, act_dim, 1.0f / (float)rows, ent_coef};

@@ -190,7 +190,8 @@ class FusedPolicy:
         max-norm; two-kernel path only).  path: "one_kernel" (FPV_PPO_ONE_KERNEL: forward, backward and weight gradients of a row
         in one kernel, nothing stored; the default with fp32 storage), "two_kernels" (the activations / deltas pass through memory;
         the default with bf16 storage) or "two_kernels_bf16x6" (as before, the weight-gradient products on the bf16 MFMA with every
-        fp32 operand cut into three bf16 pieces, six piece products per product: fp32-level error).
+        fp32 operand cut into three bf16 pieces, six piece products per product: fp32-level error; "two_kernels_bf16x3": three piece
+        products, weight gradients to ~5e-6 of their max-norm — on record, not for use).
         Returns stats[4] = (policy-gradient loss, value loss, approx KL, clip fraction)."""
         if index is not None:
             if index.dtype != torch.int64 or not index.is_contiguous():
@@ -219,7 +220,7 @@ class FusedPolicy:
         io.storage = {"f32": 0, "bf16": 1}[storage]
         if path is None:
             path = "one_kernel" if storage == "f32" else "two_kernels"
-        io.path = {"one_kernel": 0, "two_kernels": 1, "two_kernels_bf16x6": 2}[path]
+        io.path = {"one_kernel": 0, "two_kernels": 1, "two_kernels_bf16x6": 2, "two_kernels_bf16x3": 3}[path]
         L.check(self.lib.fpv_ppo_grad(self._h, C.byref(io), C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
                 "fpv_ppo_grad")
         return stats

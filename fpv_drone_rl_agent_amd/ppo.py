@@ -49,9 +49,9 @@ class PPO:
         self.grad_storage = grad_storage        # how fpv_ppo_grad passes activations between its kernels (ops_policy.ppo_grad)
         if update_path is None:
             update_path = "one_kernel" if grad_storage == "f32" else "two_kernels"
-        if update_path not in ("one_kernel", "two_kernels", "two_kernels_bf16x6") or (
+        if update_path not in ("one_kernel", "two_kernels", "two_kernels_bf16x6", "two_kernels_bf16x3") or (
                 grad_storage == "bf16" and update_path != "two_kernels"):
-            raise ValueError("update_path must be 'one_kernel', 'two_kernels' or 'two_kernels_bf16x6'; grad_storage='bf16' exists on "
+            raise ValueError("update_path must be 'one_kernel', 'two_kernels', 'two_kernels_bf16x6' or 'two_kernels_bf16x3'; grad_storage='bf16' exists on "
                              "'two_kernels' only")
         self.update_path = update_path          # which kernels compute the gradient (ops_policy.ppo_grad's `path`)
         self._fp = fp

@@ -379,6 +379,7 @@ int fpv_rollout_step(fpv_env* env, fpv_policy* pol, const fpv_policy_io* io, flo
 #define FPV_PPO_ONE_KERNEL 0
 #define FPV_PPO_TWO_KERNELS 1
 #define FPV_PPO_TWO_KERNELS_BF16X6 2
+#define FPV_PPO_TWO_KERNELS_BF16X3 3
 typedef struct {
     int64_t rows;             /* minibatch size M */
     const int64_t* index;     /* [M] device row indices into the arrays below, or NULL: rows 0..M-1 */
@@ -401,6 +402,8 @@ typedef struct {
                               /* FPV_PPO_TWO_KERNELS_BF16X6 (2): as 1 with the weight-gradient products on the bf16 MFMA, */
                               /* every fp32 operand cut into three bf16 pieces, six piece products per product (fp32      */
                               /* accumulation, fp32-level error; storage 0 only).  Same results to fp32 summation order.  */
+                              /* FPV_PPO_TWO_KERNELS_BF16X3 (3): as 2 with three piece products — NOT fp32-level (weight  */
+                              /* gradients to ~5e-6 of their max-norm); kept so that its error is measured, not guessed.   */
 } fpv_ppo_io;
 
 int fpv_ppo_workspace_bytes(fpv_policy* pol, int64_t rows, int64_t* bytes);
