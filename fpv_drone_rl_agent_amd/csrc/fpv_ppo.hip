@@ -714,7 +714,9 @@ __global__ __launch_bounds__(512) void ppo_wgrad_split_kernel(WgradArgs p) {
 // packed image), the backward reads a column (consecutive lanes, consecutive addresses).  W1's 48 A operands per lane come from
 // U0's image in memory (the same for every chunk; asked for during the previous chunk's last products).  The partial sums of a
 // slab stay in registers over its rows and are written once, in U2's layout: U3 does not know which kernel ran.  The barriers
-// order LDS traffic only.  fp32 throughout, no atomics: bitwise reproducible for a given launch shape.
+// order LDS traffic only.  The three 128 x 128 products per row — layer 2, its transpose on the way back, dW2 — run as 6-term bf16
+// splits of fp32 operands cut into pieces where they are used (fp32-level: the golden-vector error is the fp32 kernels'), everything
+// else on the fp32-input MFMA; no atomics: bitwise reproducible for a given launch shape.
 constexpr int kFRow = 132;                      // floats per row of the W2 image and of the staged matrix
 constexpr int kFOffB1 = 0, kFOffB2 = 128, kFOffW2 = 256, kFOffHead = kFOffW2 + kHid * kFRow;
 constexpr int kFOffX = (kFOffHead + kHeadFloats + 3) / 4 * 4;
@@ -871,30 +873,36 @@ __global__ __launch_bounds__(256) void ppo_fused_kernel(FusedArgs p) {
         Hidden c;
         bias_init(c, lds + kFOffB2, h);
         {
-            // A[out 32 m + col][in 32 kt + 8 r4 + 4 h + rr], rr = 0..3: one 16-byte read per tile and register quad
+            // layer 2 on the bf16 pipe: k-step (kt, sp) sums over hidden units 32 kt + 16 sp + 8 (j >> 2) + 4 h + (j & 3), j = 0..7 — what
+            // registers 8 sp .. 8 sp + 7 of accumulator tile kt hold in lane half h.  B = those eight values of H1, A = the same eight
+            // columns of W2's row 32 m + col (two 16-byte reads); both are cut into three bf16 pieces HERE (LDS has no room for W2 as
+            // pieces), six piece products: fp32-level results at 6/16 of the matrix cycles, paid for with ~7.5 vector instructions per
+            // product (the cut).  Laying the cut out one fragment ahead of its products and interleaving them by scheduling groups was
+            // measured: the same time, and on the way back (four tile sets live) slower for its registers.
             const float* wrow = lds + kFOffW2 + col * kFRow + 4 * h;
-            f32x4 wc[4], wn[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) wc[m] = *reinterpret_cast<const f32x4*>(wrow + 32 * m * kFRow);
+            for (int ks = 0; ks < 8; ++ks) {
+                const int kt = ks >> 1, sp = ks & 1;
+                f32x4 lo[4], hi[4];
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int kt = t >> 2, r4 = t & 3;
-                if (t < 15) {
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) wn[m] = *reinterpret_cast<const f32x4*>(wrow + 32 * m * kFRow + 8 * (t + 1));
+                for (int m = 0; m < 4; ++m) {
+                    lo[m] = *reinterpret_cast<const f32x4*>(wrow + 32 * m * kFRow + 16 * ks);
+                    hi[m] = *reinterpret_cast<const f32x4*>(wrow + 32 * m * kFRow + 16 * ks + 8);
                 }
+                float bv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bv[j] = a.t[kt][8 * sp + j];
+                const Pieces pb = pieces_of(bv);
                 if (kt < 3) {
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) a.t[kt + 1][4 * r4 + rr] = fast_tanh(a.t[kt + 1][4 * r4 + rr]);
+                    for (int j = 0; j < 8; ++j) a.t[kt + 1][8 * sp + j] = fast_tanh(a.t[kt + 1][8 * sp + j]);
                 }
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-                    for (int m = 0; m < 4; ++m)
-                        c.t[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[m][rr], a.t[kt][4 * r4 + rr], c.t[m], 0, 0, 0);
+                for (int m = 0; m < 4; ++m) {
+                    const float av[8] = {lo[m].x, lo[m].y, lo[m].z, lo[m].w, hi[m].x, hi[m].y, hi[m].z, hi[m].w};
+                    c.t[m] = mfma6_pieces<6>(pieces_of(av), pb, c.t[m]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int m = 0; m < 4; ++m) wc[m] = wn[m];
             }
         }
         PPO_STAMP(ck + 0);
@@ -986,32 +994,23 @@ __global__ __launch_bounds__(256) void ppo_fused_kernel(FusedArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) e.t[m][r] = 0.f;
         {
-            // A[in 32 m + col][out 32 kt + 8 r4 + 4 h + rr]
+            // the same on the way back: A = column 32 m + col of W2 at the k-step's eight rows (eight dword reads), B = D2
             const float* wcol = lds + kFOffW2 + 4 * h * kFRow + col;
-            float wc[4][4], wn[4][4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr) wc[m][rr] = wcol[rr * kFRow + 32 * m];
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int kt = t >> 2, r4 = t & 3;
-                if (t < 15) {
-#pragma unroll
-                    for (int m = 0; m < 4; ++m)
-#pragma unroll
-                        for (int rr = 0; rr < 4; ++rr) wn[m][rr] = wcol[(8 * (t + 1) + rr) * kFRow + 32 * m];
-                }
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-                    for (int m = 0; m < 4; ++m)
-                        e.t[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[m][rr], g.t[kt][4 * r4 + rr], e.t[m], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+            for (int ks = 0; ks < 8; ++ks) {
+                const int kt = ks >> 1, sp = ks & 1;
+                float av[4][8];
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) wc[m][rr] = wn[m][rr];
+                    for (int j = 0; j < 8; ++j) av[m][j] = wcol[(16 * ks + 8 * (j >> 2) + (j & 3)) * kFRow + 32 * m];
+                float bv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bv[j] = g.t[kt][8 * sp + j];
+                const Pieces pb = pieces_of(bv);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) e.t[m] = mfma6_pieces<6>(pieces_of(av[m]), pb, e.t[m]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
@@ -1062,11 +1061,13 @@ __global__ __launch_bounds__(256) void ppo_fused_kernel(FusedArgs p) {
         stage_tile_rows(M, srow, g, h);                          // D2 of the chunk
         lds_barrier();
         PPO_STAMP(ck + 7);
-        float a2r[64];                                           // this wave's A operands of dW2: D2[row 2 s + kk][32 wave + i]
+        // this wave's A operands of dW2, as the bf16 product wants them: a k-step is 16 rows and lane half h supplies rows
+        // 16 S + 8 h + j, j = 0..7, of column 32 wave + i (cut into pieces k-step by k-step)
+        float a2r[64];
         {
-            const float* A2 = M + kk * kFRow + 32 * wave + i;
+            const float* A2 = M + 8 * kk * kFRow + 32 * wave + i;
 #pragma unroll
-            for (int s = 0; s < 64; ++s) a2r[s] = A2[2 * s * kFRow];
+            for (int s = 0; s < 64; ++s) { a2r[s] = A2[(16 * (s >> 3) + (s & 7)) * kFRow]; sb2 += a2r[s]; }
         }
         PPO_STAMP(ck + 8);
         lds_barrier();
@@ -1074,39 +1075,34 @@ __global__ __launch_bounds__(256) void ppo_fused_kernel(FusedArgs p) {
         PPO_STAMP(ck + 9);
         lds_barrier();
         PPO_STAMP(ck + 10);
-        {                                                        // dW2 += D2^T H1
-            constexpr int G = 4;
-            struct Grp { float b[G][4]; };
-            const float* B = M + kk * kFRow + i;
-            auto load = [&](Grp& o, int s0) {
+        {                                                        // dW2 += D2^T H1, six piece products per product (as layer 2 above)
+            struct Grp { float b[4][8]; };
+            const float* B = M + 8 * kk * kFRow + i;
+            auto load = [&](Grp& o, int S) {
 #pragma unroll
-                for (int u = 0; u < G; ++u)
+                for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-                    for (int jt = 0; jt < 4; ++jt) o.b[u][jt] = B[2 * (s0 + u) * kFRow + 32 * jt];
+                    for (int j = 0; j < 8; ++j) o.b[jt][j] = B[(16 * S + j) * kFRow + 32 * jt];
+            };
+            auto fma = [&](const Grp& o, int S) {
+                float t8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t8[j] = a2r[8 * S + j];
+                const Pieces pa = pieces_of(t8);
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) w2s[jt] = mfma6_pieces<6>(pa, pieces_of(o.b[jt]), w2s[jt]);
             };
             Grp P, Q;
             load(P, 0);
 #pragma unroll
-            for (int s0 = 0; s0 < 64; s0 += 2 * G) {
-                load(Q, s0 + G);
+            for (int S = 0; S < 8; S += 2) {
+                load(Q, S + 1);
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < G; ++u) {
-#pragma unroll
-                    for (int jt = 0; jt < 4; ++jt)
-                        w2s[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2r[s0 + u], P.b[u][jt], w2s[jt], 0, 0, 0);
-                    sb2 += a2r[s0 + u];
-                }
+                fma(P, S);
                 __builtin_amdgcn_sched_barrier(0);
-                if (s0 + 2 * G < 64) load(P, s0 + 2 * G);
+                if (S + 2 < 8) load(P, S + 2);
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < G; ++u) {
-#pragma unroll
-                    for (int jt = 0; jt < 4; ++jt)
-                        w2s[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2r[s0 + G + u], Q.b[u][jt], w2s[jt], 0, 0, 0);
-                    sb2 += a2r[s0 + G + u];
-                }
+                fma(Q, S + 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

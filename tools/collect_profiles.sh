@@ -20,7 +20,7 @@ cp $O/step_quad_sweep.json profiles/${TAG}_step_quad_sweep.json
 cp $O/fp32_vs_fp64_trajectory.json profiles/${TAG}_fp32_vs_fp64_trajectory.json
 python tools/summarize_prof.py ${TAG} $O/prof_hover $O/pmc_fetch $O/pmc_write > /dev/null
 python tools/make_kernel_traffic.py ${TAG} > /dev/null
-cp "$(ls $O/prof_s20/*/*kernel_stats.csv | head -1)" profiles/${TAG}_kernel_stats_s20.csv
+cp "$(ls -t $O/prof_s20/*/*kernel_stats.csv | head -1)" profiles/${TAG}_kernel_stats_s20.csv
 cp gpurun_out/pmc_k0/summary.json profiles/${TAG}_rollout_step_pmc_raw.json
 { echo "# The boundary between rollouts (tools/trace_gaps.py on rocprofv3 kernel traces; durations under the profiler)"; echo;
   echo "## one 20-step rollout per timed region (python bench.py --steps 20 --warmup 5 --repeats 12): last rollout, then medians"; echo '```'; cat $O/boundary_s20.txt; echo '```'; echo;
@@ -33,7 +33,7 @@ cp gpurun_out/pmc_k0/summary.json profiles/${TAG}_rollout_step_pmc_raw.json
 { echo "# PPO update, one 65 536-row minibatch gathered out of 524 288 (tools/microbench_ppo.py): HIP events per path (gradient + clip + Adam),"
   echo "# then rocprofv3 kernel statistics of the same script, path by path"; cat $O/ppo_events.json; echo;
   for path in one_kernel two_kernels two_kernels_bf16x6; do
-    echo "## path = $path"; python3 - "$(ls $O/prof_ppo_$path/*/*kernel_stats.csv | head -1)" <<'PY'
+    echo "## path = $path"; python3 - "$(ls -t $O/prof_ppo_$path/*/*kernel_stats.csv | head -1)" <<'PY'
 import csv, sys
 print('"Name","Calls","AverageNs","MinNs","MaxNs"')
 for r in csv.DictReader(open(sys.argv[1])):
