@@ -1047,12 +1047,32 @@ __global__ __launch_bounds__(256) void ppo_fused_kernel(FusedArgs p) {
             // 32 wave + i and the rows 2 s + kk: 64 reads of H2, 64 broadcast reads of d out, 256 fmas.
             const float* HH = M + kk * kFRow + 32 * wave + i;
             const f32x4* DV = reinterpret_cast<const f32x4*>(DO) + kk;
-#pragma unroll 8
-            for (int s = 0; s < 64; ++s) {
-                const float hh = HH[2 * s * kFRow];
-                const f32x4 d = DV[2 * s];
-                hd4[0] += d.x * hh; hd4[1] += d.y * hh; hd4[2] += d.z * hh; hd4[3] += d.w * hh;
-                sb4[0] += d.x; sb4[1] += d.y; sb4[2] += d.z; sb4[3] += d.w;
+            // two groups of eight k-steps in flight: the next group's reads are asked for before the current one is used (left alone,
+            // the compiler waits for every pair of reads)
+            float hP[8], hQ[8];
+            f32x4 dP[8], dQ[8];
+            auto load = [&](float (&hh)[8], f32x4 (&d)[8], int s0) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { hh[u] = HH[2 * (s0 + u) * kFRow]; d[u] = DV[2 * (s0 + u)]; }
+            };
+            auto use = [&](const float (&hh)[8], const f32x4 (&d)[8]) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    hd4[0] += d[u].x * hh[u]; hd4[1] += d[u].y * hh[u]; hd4[2] += d[u].z * hh[u]; hd4[3] += d[u].w * hh[u];
+                    sb4[0] += d[u].x; sb4[1] += d[u].y; sb4[2] += d[u].z; sb4[3] += d[u].w;
+                }
+            };
+            load(hP, dP, 0);
+#pragma unroll 1
+            for (int s0 = 0; s0 < 64; s0 += 16) {
+                load(hQ, dQ, s0 + 8);
+                __builtin_amdgcn_sched_barrier(0);
+                use(hP, dP);
+                __builtin_amdgcn_sched_barrier(0);
+                load(hP, dP, s0 + 16 < 64 ? s0 + 16 : 0);
+                __builtin_amdgcn_sched_barrier(0);
+                use(hQ, dQ);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         PPO_STAMP(ck + 5);
