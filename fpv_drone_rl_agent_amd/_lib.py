@@ -8,12 +8,12 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-from .build import LIB_PATH, LIB_PATH_EXPERIMENTS, build_extension
+from .build import LIB_PATH, LIB_PATH_EXPERIMENTS, build_extension, variant_path
 
 FPV_F32, FPV_F64 = 0, 1
 TASK_HOVER, TASK_YAW = 0, 1
 DETECTOR_PIXEL, DETECTOR_ANALYTIC = 0, 1   # fpv_detector: the reference's pixel rules are the default
-ABI_VERSION = 4                              # FPV_ABI_VERSION of include/fpv_env.h this binding was written against
+ABI_VERSION = 5                              # FPV_ABI_VERSION of include/fpv_env.h this binding was written against
 STATE_WORDS, OBS_WORDS, ACT_WORDS = 36, 20, 4
 INFO_TERMINATED, INFO_TRUNCATED, INFO_OUT_OF_BOUNDS, INFO_ON_FLOOR = 1, 2, 4, 8
 
@@ -99,6 +99,7 @@ SIGNATURES = {
     "fpv_get_tick": (C.c_int, [_vp, C.POINTER(_u64), _vp]),
     "fpv_ledger_view": (C.c_int, [_vp, C.POINTER(FpvLedger)]),
     "fpv_ledger_clear": (C.c_int, [_vp, _vp]),
+    "fpv_ledger_pack": (C.c_int, [_vp, _vp, _f32, _f32, _vp, _i64, _vp]),
     "fpv_rollout_begin": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "fpv_ledger_bind": (C.c_int, [_vp, C.POINTER(FpvLedger)]),
     "fpv_advantage_stats": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
@@ -137,7 +138,11 @@ DEBUG_SIGNATURES = {
 }
 
 _lib = None
+_lib_path = None
 EXPERIMENTS = os.environ.get("FPV_EXPERIMENTS", "") not in ("", "0")    # which library this process loads
+# FPV_LIB_VARIANT=name: this process runs on variants/name.so — an A/B or diagnostic build made by
+# build.build_extension(variant=name, flags=...) — instead of the product library (tools/ab_*.sh; never copied over the product)
+VARIANT = os.environ.get("FPV_LIB_VARIANT", "")
 
 
 def experiments() -> bool:
@@ -160,7 +165,12 @@ def load(build_if_missing: bool = True):
     # torch first: it brings its own copy of the HIP runtime, and a process must run on ONE — a library that pulled in the system's
     # copy before torch loads its own leaves the second one without a device ("no ROCm-capable device is detected")
     import torch  # noqa: F401
+    global _lib_path
     lib_path = LIB_PATH_EXPERIMENTS if EXPERIMENTS else LIB_PATH
+    if VARIANT:
+        lib_path = variant_path(VARIANT)
+        if not os.path.exists(lib_path):
+            raise RuntimeError(f"FPV_LIB_VARIANT={VARIANT}: {lib_path} does not exist (build.build_extension(variant=..., flags=...))")
     if not os.path.exists(lib_path):
         if not build_if_missing:
             raise RuntimeError(f"{lib_path} is missing: build it with fpv_drone_rl_agent_amd.build.build_extension()")
@@ -173,8 +183,19 @@ def load(build_if_missing: bool = True):
     if built != ABI_VERSION:         # struct layouts / enum values differ between versions: refuse before the first real call
         raise RuntimeError(f"{lib_path} was built for FPV_ABI_VERSION {built}, this binding is version {ABI_VERSION}: "
                            "rebuild it (fpv_drone_rl_agent_amd.build.build_extension(force=True))")
-    _lib = lib
+    _lib, _lib_path = lib, lib_path
     return lib
+
+
+def library_id() -> dict:
+    """Which build this process runs on: path relative to the repository and the first 16 hex digits of its SHA-256
+    (bench.py puts it on its JSON line, so a number can be traced to a binary)."""
+    import hashlib
+    load()
+    with open(_lib_path, "rb") as f:
+        sha = hashlib.sha256(f.read()).hexdigest()[:16]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return {"path": os.path.relpath(_lib_path, root), "sha16": sha, "variant": VARIANT or None}
 
 
 def check(rc: int, what: str = "fpv call") -> None:

@@ -39,17 +39,28 @@ def _stale(lib_path: str) -> bool:
     return any(os.path.exists(f) and os.path.getmtime(f) > t for f in files)
 
 
-def build_extension(force: bool = False, verbose: bool = False, experiments: bool = False) -> str:
+VARIANTS_DIR = os.path.join(os.path.dirname(_HERE), "variants")      # A/B and diagnostic builds (git-ignored; they travel to the GPU box)
+
+
+def variant_path(name: str) -> str:
+    return os.path.join(VARIANTS_DIR, name + ".so")
+
+
+def build_extension(force: bool = False, verbose: bool = False, experiments: bool = False, variant: str | None = None,
+                    flags: tuple = ()) -> str:
     """Compile csrc/*.hip for gfx950 into libfpv_env.so, or with experiments=True into libfpv_env_experiments.so
-    (-DFPV_EXPERIMENTS=1).  Returns the library path."""
-    lib_path = LIB_PATH_EXPERIMENTS if experiments else LIB_PATH
+    (-DFPV_EXPERIMENTS=1), or — variant="name", flags=("-DFPV_...=1", ...) — into variants/name.so: a diagnostic or A/B build that
+    a process selects with FPV_LIB_VARIANT=name (fpv_drone_rl_agent_amd._lib); the product library is never overwritten.
+    Returns the library path."""
+    lib_path = variant_path(variant) if variant else (LIB_PATH_EXPERIMENTS if experiments else LIB_PATH)
     if not force and not _stale(lib_path):
         return lib_path
-    extra = os.environ.get("FPV_EXTRA_HIPCC_FLAGS", "").split() + (["-DFPV_EXPERIMENTS=1"] if experiments else [])
+    extra = os.environ.get("FPV_EXTRA_HIPCC_FLAGS", "").split() + list(flags) + (["-DFPV_EXPERIMENTS=1"] if experiments else [])
     base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden"] + extra
-    objdir = os.path.join(_HERE, "build", "experiments" if experiments else "product")
+    objdir = os.path.join(_HERE, "build", os.path.join("variants", variant) if variant else ("experiments" if experiments else "product"))
+    os.makedirs(os.path.dirname(lib_path), exist_ok=True)
     os.makedirs(objdir, exist_ok=True)
-    objs = []
+    objs, cmds = [], []
     for f in SOURCES + (EXPERIMENT_SOURCES if experiments else []):
         src = os.path.join(CSRC, f)
         if not os.path.exists(src):
@@ -63,8 +74,11 @@ def build_extension(force: bool = False, verbose: bool = False, experiments: boo
         cmd = base + [f"-ffp-contract={contract}", "-c", "-o", obj, src]
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd, cwd=CSRC)
+        cmds.append(cmd)
         objs.append(obj)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, min(4, len(os.sched_getaffinity(0))))) as pool:     # a few hipcc processes side by side
+        list(pool.map(lambda c: subprocess.check_call(c, cwd=CSRC), cmds))
     cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs
     if verbose:
         print(" ".join(cmd))
@@ -73,5 +87,9 @@ def build_extension(force: bool = False, verbose: bool = False, experiments: boo
 
 
 if __name__ == "__main__":
-    print(build_extension(force=True, verbose=True))
-    print(build_extension(force=True, verbose=True, experiments=True))
+    import sys
+    if len(sys.argv) > 1:            # python -m fpv_drone_rl_agent_amd.build NAME -DFLAG=1 ...  ->  variants/NAME.so
+        print(build_extension(force=True, verbose=True, variant=sys.argv[1], flags=tuple(sys.argv[2:])))
+    else:
+        print(build_extension(force=True, verbose=True))
+        print(build_extension(force=True, verbose=True, experiments=True))

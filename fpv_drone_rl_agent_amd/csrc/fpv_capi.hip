@@ -437,6 +437,17 @@ int fpv_ledger_clear(fpv_env* e, void* stream) {
     return FPV_OK;
 }
 
+int fpv_ledger_pack(fpv_env* e, const double* obs_rms, float clip_obs, float eps_norm, uint32_t* out, int64_t max_rows, void* stream) {
+    if (!e || !out) return fail(FPV_ERR_ARG, "fpv_ledger_pack: null argument");
+    if (e->cfg.precision != FPV_F32) return fail(FPV_ERR_UNSUPPORTED, "fpv_ledger_pack: float handles only");
+    if (max_rows < 0 || ((uintptr_t)out & 3)) return fail(FPV_ERR_ARG, "fpv_ledger_pack: max_rows >= 0, out 4-byte aligned");
+    if (e->obs_words > 32) return fail(FPV_ERR_UNSUPPORTED, "fpv_ledger_pack: at most 32 observation words");
+    FPV_HIP(launch_ledger_pack(e->led_count, e->led_idx, e->led_info, e->led_tag, static_cast<const float*>(e->led_ret),
+                               static_cast<const float*>(e->led_obs), e->tiles, (int)e->led_rows, e->obs_words, obs_rms, clip_obs,
+                               eps_norm, out, max_rows, (hipStream_t)stream));
+    return FPV_OK;
+}
+
 int fpv_rollout_begin(fpv_env* e, uint8_t* starts_dst, const uint8_t* starts_src, int32_t* scan_counters, double* scan_sums,
                       void* stream) {
     if (!e) return fail(FPV_ERR_ARG, "fpv_rollout_begin: null handle");

@@ -199,6 +199,9 @@ hipError_t launch_rank_merge(const double* gathered, int world, int stride, int 
 hipError_t launch_zero_words(uint32_t* a, int64_t n, hipStream_t s);
 hipError_t launch_rollout_begin(uint32_t* counts, int64_t tiles, uint8_t* dst, const uint8_t* src, int64_t n, int32_t* scan_counters,
                                 double* scan_sums, hipStream_t s);
+hipError_t launch_ledger_pack(const uint32_t* led_count, const int32_t* led_idx, const uint32_t* led_info, const uint32_t* led_tag,
+                              const float* led_ret, const float* led_obs, int64_t tiles, int rows, int obs_words, const double* rms,
+                              float clip, float eps, uint32_t* out, int64_t max_rows, hipStream_t s);
 hipError_t launch_ledger_scan(const uint32_t* led_count, const int32_t* led_idx, const uint32_t* led_info, const uint32_t* led_tag,
                               const float* led_ret, const float* led_obs, const uint64_t* tick, int64_t tiles, int rows,
                               int obs_words, const double* snapshots, int64_t stride, int T, float clip_obs, float eps,

@@ -137,7 +137,7 @@ __device__ __forceinline__ void pixel_tile_setup(const Drone<T>& d, float* pool,
 
 // Every lane of the pool's waves (wv = 0 .. WAVES - 1), once the corner blocks are complete: the blobs.
 template <typename T, int TILES, int WAVES>
-__device__ __forceinline__ void pixel_pool_contours(float* pool, int wv, int lane) {
+__device__ __forceinline__ void pixel_pool_contours(float* pool, int wv, int lane, uint64_t* probe = nullptr) {
     using P = PixPool<T, TILES, WAVES>;
     // ---- the schedule, derived by every wave for itself (the waves write the same values to the same places).  Blobs of more
     // than `big` rows get 16 lanes; `big` is the smallest of 16, 20, 24, 28, 36 with which one round serves every blob (8 WAVES
@@ -183,6 +183,7 @@ __device__ __forceinline__ void pixel_pool_contours(float* pool, int wv, int lan
         }
     }
     pixel_wave_fence();
+    if (probe && lane == 0) *probe = __builtin_amdgcn_s_memrealtime();      // (diagnostic builds only: the schedule is done)
     const int octets = 2 * nbig + nsmall;
     const uint32_t* run = reinterpret_cast<const uint32_t*>(pool + P::kRun);
     for (int base = wv * 8; base < octets; base += 8 * WAVES) {                                   // (uniform over the wave)

@@ -512,6 +512,87 @@ hipError_t launch_zero_words(uint32_t* a, int64_t n, hipStream_t s) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- the done ledger as ONE dense block (host-mode VecEnv)
+// A host that reads the ledger after every step (FpvVecEnv's numpy mode: SB3's infos[i]["terminal_observation"], ["episode"],
+// hover.py:102's flags) wants one copy, not a count, a compaction and five gathers.  One workgroup: exclusive prefix of the tiles'
+// row counts (chunks of 1 024 tiles, a running base), then every thread copies its tile's rows — a step ends ~N / 31 episodes, a
+// couple per tile — as {idx, info, tag, ep_return, obs[O]} to out + 8 + (4 + O) * k, in (tile, row) order, i.e. by drone index for
+// a ledger that holds one step.  out[0] = rows appended since the clear (rows that did not fit included), out[1] = rows packed,
+// out[2] = row words.  With rms the terminal observation is normalised as normalize_apply_kernel does it (VecNormalize.step_wait
+// normalises infos[i]["terminal_observation"] with the statistics as they stand after the step's update).
+__global__ __launch_bounds__(1024) void ledger_pack_kernel(const uint32_t* __restrict__ led_count, const int32_t* __restrict__ led_idx,
+                                                           const uint32_t* __restrict__ led_info, const uint32_t* __restrict__ led_tag,
+                                                           const float* __restrict__ led_ret, const float* __restrict__ led_obs,
+                                                           int64_t tiles, int rows, int O, const double* __restrict__ rms, float clip,
+                                                           float eps, uint32_t* __restrict__ out, int64_t max_rows) {
+    __shared__ uint32_t wsum[16];
+    __shared__ float mu[32], inv[32];
+    __shared__ uint32_t base_s, total_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { base_s = 0u; total_s = 0u; }
+    if (tid < O) {
+        mu[tid] = rms ? (float)rms[tid] : 0.0f;
+        inv[tid] = rms ? (float)(1.0 / sqrt(rms[O + tid] + (double)eps)) : 1.0f;
+    }
+    __syncthreads();
+    const int W = 4 + O;
+    for (int64_t t0 = 0; t0 < tiles; t0 += 1024) {
+        const int64_t t = t0 + tid;
+        const uint32_t appended = t < tiles ? led_count[t] : 0u;
+        const uint32_t c = appended < (uint32_t)rows ? appended : (uint32_t)rows;
+        uint32_t incl = c, app = appended;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(incl, d);
+            if (lane >= d) incl += y;
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) app += __shfl_xor(app, d);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = base_s;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        if (lane == 0) atomicAdd(&total_s, app);
+        const uint32_t first = before + incl - c;
+        for (uint32_t r = 0; r < c; ++r) {
+            const int64_t k = (int64_t)first + r;
+            if (k >= max_rows) break;
+            const int64_t slot = t * rows + r;
+            uint32_t* row = out + 8 + k * W;
+            row[0] = (uint32_t)led_idx[slot];
+            row[1] = led_info[slot];
+            row[2] = led_tag[slot];
+            row[3] = __float_as_uint(led_ret[slot]);
+            for (int j = 0; j < O; ++j) {
+                const float x = led_obs[slot * O + j];
+                row[4 + j] = __float_as_uint(rms ? fminf(fmaxf((x - mu[j]) * inv[j], -clip), clip) : x);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t s = 0u;
+            for (int w = 0; w < 16; ++w) s += wsum[w];
+            base_s += s;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out[0] = total_s;
+        out[1] = (uint32_t)((int64_t)base_s < max_rows ? (int64_t)base_s : max_rows);
+        out[2] = (uint32_t)W;
+        out[3] = base_s;
+        out[4] = out[5] = out[6] = out[7] = 0u;
+    }
+}
+
+hipError_t launch_ledger_pack(const uint32_t* led_count, const int32_t* led_idx, const uint32_t* led_info, const uint32_t* led_tag,
+                              const float* led_ret, const float* led_obs, int64_t tiles, int rows, int obs_words, const double* rms,
+                              float clip, float eps, uint32_t* out, int64_t max_rows, hipStream_t s) {
+    hipLaunchKernelGGL(ledger_pack_kernel, dim3(1), dim3(1024), 0, s, led_count, led_idx, led_info, led_tag, led_ret, led_obs, tiles,
+                       rows, obs_words, rms, clip, eps, out, max_rows);
+    return hipGetLastError();
+}
+
 struct LedgerScanArgs {
     const uint32_t* led_count;
     const int32_t* led_idx;

@@ -69,6 +69,13 @@ static_assert(kRsPix + RsPix::kWords <= 2 * kNetFloats, "the pixel detector's ex
 // drains vmcnt too, and in these kernels every barrier would then wait out the ~1-2 us of the rollout-buffer / ledger / flag
 // stores issued just before it.  Nothing here passes GLOBAL data between waves of a workgroup across a barrier (where a row is
 // handed to other workgroups the storing wave drains it explicitly).
+// words per workgroup of the diagnostic stamp buffer (fpv_debug_rollout_stamps); the contour probe build (tools/contour_probe.py,
+// -DFPV_CONTOUR_PROBE=1: every wave's contour times, and the contour phase run a second time on warm caches) takes 64
+#ifdef FPV_CONTOUR_PROBE
+constexpr int kStampStride = 64;
+#else
+constexpr int kStampStride = 16;
+#endif
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ---------------------------------------------------------------- phase 1: fpv_policy.hip's body for one 256-drone chunk
@@ -357,7 +364,19 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
     if (s.detector) {
         lds_barrier();                                         // barrier P: the four tiles' corner blocks are in LDS
         if (o_.stamps && threadIdx.x == 0) o_.stamps[6] = __builtin_amdgcn_s_memrealtime();
+#ifdef FPV_CONTOUR_PROBE
+        if (o_.stamps && lane == 0) o_.stamps[36 + wave] = __builtin_amdgcn_s_memrealtime();                  // s[40 + w]: wave w past P
+        pixel_pool_contours<float, 4, 8>(pix, wave, lane, o_.stamps ? o_.stamps + 44 + wave : nullptr);      // s[48 + w]: schedule done
+        if (o_.stamps && lane == 0) o_.stamps[12 + wave] = __builtin_amdgcn_s_memrealtime();                  // s[16 + w]: blobs done
+        if (o_.stamps) {                                       // the same blobs once more: instructions and tables are warm now
+            lds_barrier();
+            if (lane == 0) o_.stamps[20 + wave] = __builtin_amdgcn_s_memrealtime();                           // s[24 + w]
+            pixel_pool_contours<float, 4, 8>(pix, wave, lane, o_.stamps + 52 + wave);                         // s[56 + w]
+            if (lane == 0) o_.stamps[28 + wave] = __builtin_amdgcn_s_memrealtime();                           // s[32 + w]
+        }
+#else
         pixel_pool_contours<float, 4, 8>(pix, wave, lane);
+#endif
         if (o_.stamps && (threadIdx.x & 255) == 0) o_.stamps[helper ? 11 : 7] = __builtin_amdgcn_s_memrealtime();
         lds_barrier();                                         // barrier R: every blob's result is in LDS
         if (o_.stamps && threadIdx.x == 0) o_.stamps[8] = __builtin_amdgcn_s_memrealtime();
@@ -644,7 +663,7 @@ template <int TASK>
 __global__ __launch_bounds__(512) void rollout_step_kernel(RollStepArgs p) {
     constexpr int IN = TASK == 0 ? kIn : kYawObsWords, ACT = TASK == 0 ? kAct : 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-#define RS1_STAMP(k) do { if (p.stamps && threadIdx.x == 0) p.stamps[(int64_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define RS1_STAMP(k) do { if (p.stamps && threadIdx.x == 0) p.stamps[(int64_t)blockIdx.x * kStampStride + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     RS1_STAMP(0);
     f32x2 xpre[IN / 4];
     rollstep_prologue<IN>(p, lds, xpre);
@@ -669,7 +688,7 @@ __global__ __launch_bounds__(512) void rollout_step_kernel(RollStepArgs p) {
     if (lane < 32) reinterpret_cast<f32x4*>(lds + kRsAct)[wave * 32 + lane] = cl;
     lds_barrier();
     const TailOut to{p.st.reward, p.st.terminated, p.st.truncated, p.st.done, p.st.partials, true, false, true,
-                     p.stamps ? p.stamps + (int64_t)blockIdx.x * 16 + 4 : nullptr};
+                     p.stamps ? p.stamps + (int64_t)blockIdx.x * kStampStride + 4 : nullptr};
     if constexpr (TASK == 0) {
         rs_tail(p.st, lds, tr, to);              // (stores the state itself: TailOut.store_state)
     } else {
@@ -694,7 +713,7 @@ __global__ __launch_bounds__(512) void step_quad_kernel(StepArgs<float> st, uint
     }
     __syncthreads();
     const TailOut to{st.reward, st.terminated, st.truncated, st.done, st.partials, true, false, true,
-                     stamps ? stamps + (int64_t)blockIdx.x * 16 + 4 : nullptr};
+                     stamps ? stamps + (int64_t)blockIdx.x * kStampStride + 4 : nullptr};
     rs_tail(st, lds, tr, to);
 }
 
@@ -741,7 +760,7 @@ __global__ __launch_bounds__(512) void rollout_step_split_kernel(RollStepSplitAr
     float* nrm = head + kHeadFloats;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 31;
     const float clip = p.rms ? p.clip_obs : 3.0e38f;
-#define RSS_STAMP(k) do { if (p.stamps && threadIdx.x == 0) p.stamps[(int64_t)blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define RSS_STAMP(k) do { if (p.stamps && threadIdx.x == 0) p.stamps[(int64_t)blockIdx.x * kStampStride + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     RSS_STAMP(0);
     for (int q = threadIdx.x; q < kHeadFloats; q += 512)
         head[q] = reinterpret_cast<const float*>(p.image + 2 * (size_t)kNetBytes)[q];
@@ -774,7 +793,7 @@ __global__ __launch_bounds__(512) void rollout_step_split_kernel(RollStepSplitAr
     if (lane < 32) reinterpret_cast<f32x4*>(lds + kRsAct)[wave * 32 + lane] = cl;
     lds_barrier();
     const TailOut to{p.st.reward, p.st.terminated, p.st.truncated, p.st.done, p.st.partials, true, false, true,
-                     p.stamps ? p.stamps + (int64_t)blockIdx.x * 16 + 4 : nullptr};
+                     p.stamps ? p.stamps + (int64_t)blockIdx.x * kStampStride + 4 : nullptr};
     rs_tail(p.st, lds, tr, to);
     RSS_STAMP(3);
 #undef RSS_STAMP

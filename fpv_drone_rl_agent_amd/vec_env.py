@@ -6,20 +6,61 @@ and `DummyVecEnv` / `VecNormalize.load` in simulation/test_hover.py:7-10.
 
 Two data modes:
   * host mode (default): numpy in, numpy out — drop-in under stock SB3 (BASELINE cfg "policy on
-    CPU"); one H2D of actions and one D2H of obs/reward/flags (+ the done rows) per step.
+    CPU").  Per step ONE H2D of the actions from a pinned staging buffer and ONE D2H into pinned memory of a single
+    device block that the step's kernels fill: flags, observations, rewards (normalised by VecNormalize's kernels when the
+    wrapper is there) and the done ledger packed densely (fpv_ledger_pack: terminal observations, episode returns / lengths,
+    hover.py:102's flags).  Everything is queued in step_async; the per-step `infos` dicts are made while the device works.
   * device mode (`device_mode=True`): torch device tensors in and out, nothing leaves HBM.
 SB3 is not installed in this image: the class subclasses SB3's VecEnv when importable and is
 otherwise a structural stand-in with the same method names, shapes and dtypes.
 """
 from __future__ import annotations
 
+import ctypes as C
 import time
+from itertools import repeat
 
 import numpy as np
 import torch
 
+from . import _lib as L
 from . import ops, spaces
 from .engine import FpvEngine
+
+# hover.py:102 — the info dict a live env returns on every step (hover.py:358); a finished one adds SB3's keys
+_LIVE_INFO = {"out_of_bounds": False, "collision": False, "env_complete": False, "on_floor": False}
+
+
+class _HostBlock:
+    """What a host-mode step hands to the host, as one device allocation and its pinned mirror:
+    [terminated N u8 | truncated N u8 | pad | obs N x O f32 | reward N f32 | pad | ledger header 8 u32 | ledger rows].
+    The copy that follows every step takes the block up to `first` ledger rows (a step ends ~N / 31 episodes); the steps that
+    end more (a truncation wave after a common reset) fetch the rest with a second copy."""
+
+    def __init__(self, n: int, obs_words: int, device):
+        al = lambda x: (x + 15) // 16 * 16
+        self.n, self.W = n, 4 + obs_words
+        self.first = min(n, max(64, n // 8))
+        o_obs = al(2 * n)
+        o_rew = o_obs + 4 * n * obs_words
+        o_led = al(o_rew + 4 * n)
+        self.o_led, self.main_bytes = o_led, o_led + 4 * (8 + self.first * self.W)
+        total = o_led + 4 * (8 + n * self.W)
+        self.dev = torch.zeros(total, dtype=torch.uint8, device=device)
+        self.host = torch.zeros(total, dtype=torch.uint8).pin_memory()
+        d = self.dev
+        self.term, self.trunc = d[0:n], d[n:2 * n]
+        self.obs = d[o_obs:o_rew].view(torch.float32).view(n, obs_words)
+        self.rew = d[o_rew:o_rew + 4 * n].view(torch.float32)
+        self.led = d[o_led:]
+        h = self.host.numpy()
+        self.h_term, self.h_trunc = h[0:n], h[n:2 * n]
+        self.h_obs = h[o_obs:o_rew].view(np.float32).reshape(n, obs_words)
+        self.h_rew = h[o_rew:o_rew + 4 * n].view(np.float32)
+        self.h_hdr = h[o_led:o_led + 32].view(np.uint32)
+        self.h_rows = h[o_led + 32:].view(np.uint32).reshape(n, self.W)
+        self.act_host = torch.zeros((n, 4), dtype=torch.float32).pin_memory()
+        self.event = torch.cuda.Event()
 
 try:  # pragma: no cover
     from stable_baselines3.common.vec_env import VecEnv as _VecEnvBase  # type: ignore
@@ -43,8 +84,16 @@ class FpvVecEnv(_VecEnvBase):
         self.render_mode = None
         self._actions = torch.zeros((n_envs, 4), dtype=torch.float32, device=self.engine.device)
         self._t_start = time.time()
-        self._empty_infos = [{} for _ in range(n_envs)]
         self._pending = False
+        self._normalizer = None        # the VecNormalize wrapped around this env, host mode: its kernels write into the block
+        self._infos = None
+        self._blk = None
+        if not self.device_mode:
+            e = self.engine
+            with torch.cuda.device(e.device):
+                self._blk = _HostBlock(n_envs, e.obs_words, e.device)
+            e.terminated, e.truncated = self._blk.term, self._blk.trunc     # the engine's flags live in the block
+            self._raw_obs, self._raw_rew = e.obs, e.reward                  # (raw outputs when a normaliser stands behind)
 
     # -- VecEnv protocol ---------------------------------------------------------------
     def reset(self):
@@ -53,13 +102,31 @@ class FpvVecEnv(_VecEnvBase):
         return obs if self.device_mode else obs.cpu().numpy()
 
     def step_async(self, actions) -> None:
+        e = self.engine
         if self.device_mode:
             self._actions.copy_(actions)
-        else:
-            a = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, 4)
-            self._actions.copy_(torch.from_numpy(a), non_blocking=False)
-        self.engine.ledger_clear()
-        self.engine.step(self._actions)
+            e.ledger_clear()
+            e.step(self._actions)
+            self._pending = True
+            return
+        b, nz = self._blk, self._normalizer
+        b.act_host.numpy()[...] = np.asarray(actions, dtype=np.float32).reshape(self.num_envs, 4)
+        self._actions.copy_(b.act_host, non_blocking=True)
+        e.ledger_clear()
+        rms = None
+        # engine.obs / engine.reward name the step's RAW outputs: the block itself, or tensors of their own under a normaliser
+        e.obs, e.reward = (b.obs, b.rew) if nz is None else (self._raw_obs, self._raw_rew)
+        e.step(self._actions)
+        if nz is not None:
+            rms = nz._enqueue(e.obs, e.reward, b)                 # VecNormalize's kernels: block <- normalised obs / rewards
+        L.check(e.lib.fpv_ledger_pack(e._h, C.c_void_p(rms.data_ptr()) if rms is not None else None,
+                                      nz.clip_obs if nz is not None else 0.0, nz.epsilon if nz is not None else 0.0,
+                                      C.c_void_p(b.led.data_ptr()), self.num_envs,
+                                      C.c_void_p(torch.cuda.current_stream(e.device).cuda_stream)), "fpv_ledger_pack")
+        b.host[:b.main_bytes].copy_(b.dev[:b.main_bytes], non_blocking=True)
+        b.event.record(torch.cuda.current_stream(e.device))
+        # hover.py:102,358: every env returns its own info dict on every step — made here, while the device works
+        self._infos = list(map(dict.copy, repeat(_LIVE_INFO, self.num_envs)))
         self._pending = True
 
     def step_wait(self):
@@ -70,22 +137,28 @@ class FpvVecEnv(_VecEnvBase):
         if self.device_mode:
             dones = torch.bitwise_or(e.terminated, e.truncated).bool()
             return e.obs, e.reward, dones, LedgerInfos(e)
-        obs = e.obs.cpu().numpy()
-        rewards = e.reward.cpu().numpy()
-        term, trunc = e.terminated.cpu().numpy().astype(bool), e.truncated.cpu().numpy().astype(bool)
-        dones = term | trunc
-        infos = self._empty_infos
-        if dones.any():
-            infos = list(self._empty_infos)
-            led = e.ledger_read()
-            now = time.time() - self._t_start
-            for k in range(len(led["idx"])):
-                i, bits = int(led["idx"][k]), int(led["info"][k])
+        b, infos = self._blk, self._infos
+        self._infos = None
+        b.event.synchronize()
+        obs, rewards = b.h_obs.copy(), b.h_rew.copy()              # (the pinned block is overwritten by the next step)
+        dones = (b.h_term | b.h_trunc).astype(bool)
+        appended, packed, held = int(b.h_hdr[0]), int(b.h_hdr[1]), int(b.h_hdr[3])
+        if appended > held:
+            raise RuntimeError(f"done ledger overflow: {appended} episode ends, {held} rows (raise ledger_capacity)")
+        if packed:
+            if packed > b.first:                                   # a wave of episode ends: the rows behind the first copy
+                lo, hi = b.o_led + 32 + 4 * b.first * b.W, b.o_led + 32 + 4 * packed * b.W
+                b.host[lo:hi].copy_(b.dev[lo:hi])
+            rows = b.h_rows[:packed].copy()
+            bits = rows[:, 1]
+            tobs = np.ascontiguousarray(rows[:, 4:]).view(np.float32)
+            now = round(time.time() - self._t_start, 6)
+            for i, bt, r, to in zip(rows[:, 0].tolist(), bits.tolist(), rows[:, 3].view(np.float32).tolist(), tobs):
                 infos[i] = {
-                    "terminal_observation": led["obs"][k],
-                    "TimeLimit.truncated": bool(bits & 2) and not bool(bits & 1),
-                    "episode": {"r": float(led["ep_return"][k]), "l": bits >> 8, "t": round(now, 6)},
-                    "out_of_bounds": bool(bits & 4), "on_floor": bool(bits & 8),
+                    "terminal_observation": to,
+                    "TimeLimit.truncated": (bt & 3) == 2,
+                    "episode": {"r": r, "l": bt >> 8, "t": now},
+                    "out_of_bounds": (bt & 4) != 0, "on_floor": (bt & 8) != 0,
                     "collision": False, "env_complete": False,
                 }
         return obs, rewards, dones, infos
@@ -164,6 +237,22 @@ class VecNormalize:
         self._done = torch.zeros((venv.num_envs,), dtype=torch.uint8, device=dev)
         self.old_obs = None
 
+    def _enqueue(self, raw_obs, raw_rew, blk):
+        """Host mode, called by the env's step_async behind the env-step kernel: SB3's VecNormalize.step_wait as kernels on the
+        stream — statistics update (while training), normalised observations and rewards straight into the block the host will
+        receive.  Returns the statistics the terminal observations are to be normalised with (None: not at all)."""
+        if self.norm_obs:
+            self.obs_rms(raw_obs, out=blk.obs, update=self.training)
+        else:
+            blk.obs.copy_(raw_obs)
+        torch.bitwise_or(blk.term, blk.trunc, out=self._done)
+        if self.norm_reward:
+            # SB3 updates the return statistics only while training, but always clears finished returns
+            self.ret_rms(raw_rew, self._done, out=blk.rew, update=self.training)
+        else:
+            blk.rew.copy_(raw_rew)
+        return self.obs_rms.rms if self.norm_obs else None
+
     def _norm_obs_dev(self, raw: torch.Tensor) -> torch.Tensor:
         if not self.norm_obs:
             return raw
@@ -186,9 +275,18 @@ class VecNormalize:
         return out if self.venv.device_mode else out.cpu().numpy()
 
     def step_async(self, actions):
-        self.venv.step_async(actions)
+        if self.venv.device_mode:
+            self.venv.step_async(actions)
+            return
+        self.venv._normalizer = self              # the wrapper that steps is the one whose kernels fill the block
+        try:
+            self.venv.step_async(actions)
+        finally:
+            self.venv._normalizer = None          # (a step of the bare env returns raw values again)
 
     def step_wait(self):
+        if not self.venv.device_mode:
+            return self.venv.step_wait()          # already normalised: the env's step_async queued this wrapper's kernels
         obs, rewards, dones, infos = self.venv.step_wait()
         e = self.venv.engine
         obs_n = self._norm_obs_dev(e.obs)
@@ -198,15 +296,7 @@ class VecNormalize:
             rew_n = self.ret_rms(e.reward, self._done, out=self._rew_n, update=self.training)
         else:
             rew_n = e.reward
-        if self.venv.device_mode:
-            return obs_n, rew_n, dones, infos
-        if self.norm_obs and dones.any():
-            idx = [i for i in np.nonzero(dones)[0] if "terminal_observation" in infos[i]]
-            if idx:                                   # one normalisation launch for all terminal observations
-                tn = self.normalize_obs(np.stack([infos[i]["terminal_observation"] for i in idx]))
-                for k, i in enumerate(idx):
-                    infos[i]["terminal_observation"] = tn[k]
-        return obs_n.cpu().numpy(), rew_n.cpu().numpy(), dones, infos
+        return obs_n, rew_n, dones, infos
 
     def step(self, actions):
         self.step_async(actions)

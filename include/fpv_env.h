@@ -30,8 +30,9 @@ extern "C" {
  * built against another header would pass structs of another size).  History: 1 = rounds 1-2; 2 = round 3
  * (FPV_DETECTOR_PIXEL = 0 is the default, debug hooks moved to fpv_env_debug.h); 3 = fpv_ledger_scan(status_out),
  * fpv_policy_io.scatter_*, the whole-rollout launch moved to fpv_env_experiments.h; 4 = round 4: fpv_ppo_io.reserved1 became
- * fpv_ppo_io.path (same layout; 0 now selects the one-kernel gradient), fpv_ppo_workspace_bytes covers every path. */
-#define FPV_ABI_VERSION 4
+ * fpv_ppo_io.path (same layout; 0 now selects the one-kernel gradient), fpv_ppo_workspace_bytes covers every path; 5 = round 5:
+ * fpv_ledger_pack added (no layout changed). */
+#define FPV_ABI_VERSION 5
 
 #define FPV_STATE_WORDS 36 /* docs/SPEC.md §2 canonical order */
 #define FPV_OBS_WORDS 20   /* simulation/hover.py:63-70 */
@@ -205,6 +206,16 @@ int fpv_get_tick(fpv_env* env, uint64_t* tick_host, void* stream);
 
 int fpv_ledger_view(fpv_env* env, fpv_ledger* out);
 int fpv_ledger_clear(fpv_env* env, void* stream);
+/* The done ledger as ONE dense block, for a host that reads it after every step (FpvVecEnv's numpy mode under stock SB3:
+ * infos[i]["terminal_observation"], ["episode"], hover.py:102's flags — simulation/train_hover.py:42-43): a header of 8 words —
+ * out[0] = rows appended since the last fpv_ledger_clear (rows that no longer fitted a tile's partition included), out[1] = rows
+ * packed here (<= max_rows), out[2] = words per row W = 4 + obs words, out[3] = rows held by the ledger — followed by the rows
+ * {idx, info, tag, ep_return (float), obs[..]} in (tile, row) order, which for a ledger cleared before the step is the order of
+ * the drone index.  obs_rms (float64 {mean[O], var[O], count}) != NULL: the terminal observation is written normalised,
+ * clip((x - mean) / sqrt(var + eps_norm), +-clip_obs), the arithmetic of fpv_normalize — what SB3's VecNormalize.step_wait does
+ * to infos[i]["terminal_observation"].  out holds 8 + max_rows * W words (device memory; the caller copies it to the host
+ * together with the step's outputs).  One small launch; float handles. */
+int fpv_ledger_pack(fpv_env* env, const double* obs_rms, float clip_obs, float eps_norm, uint32_t* out, int64_t max_rows, void* stream);
 /* Start of a rollout in one launch: fpv_ledger_clear, the episode-start flags carried over from the end of the previous
  * rollout (starts_dst[i] = starts_src[i] for the handle's num_envs drones; both NULL to skip; 16-byte aligned), and — when
  * given — the words fpv_ledger_scan will accumulate into at the end of this rollout set to zero (scan_counters[4],

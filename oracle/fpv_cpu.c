@@ -226,6 +226,47 @@ int fpv_cpu_ledger_clear(fpv_env* e, void* stream) {
     return FPV_OK;
 }
 
+/* The done ledger as one dense block (include/fpv_env.h, fpv_ledger_pack): header {appended, packed, W, held, 0, 0, 0, 0}, then
+ * {idx, info, tag, ep_return, obs[O]} per row in (tile, row) order; with obs_rms the terminal observation normalised in float as
+ * fpv_normalize does: clip((x - (float)mean) * (float)(1 / sqrt(var + eps)), +-clip). */
+int fpv_cpu_ledger_pack(fpv_env* e, const double* obs_rms, float clip_obs, float eps_norm, uint32_t* out, int64_t max_rows, void* stream) {
+    (void)stream;
+    if (!e || !out) return fail(FPV_ERR_ARG, "fpv_ledger_pack: null argument");
+    if (e->cfg.precision != FPV_F32) return fail(FPV_ERR_UNSUPPORTED, "fpv_ledger_pack: float handles only");
+    if (max_rows < 0) return fail(FPV_ERR_ARG, "fpv_ledger_pack: max_rows >= 0, out 4-byte aligned");
+    const int O = e->obs_words, W = 4 + O;
+    uint32_t appended = 0, held = 0;
+    int64_t k = 0;
+    for (int64_t t = 0; t < e->tiles; ++t) {
+        const uint32_t c = e->led_count[t] < (uint32_t)e->led_rows ? e->led_count[t] : (uint32_t)e->led_rows;
+        appended += e->led_count[t];
+        held += c;
+        for (uint32_t r = 0; r < c; ++r, ++k) {
+            if (k >= max_rows) continue;
+            const int64_t slot = t * e->led_rows + r;
+            uint32_t* row = out + 8 + k * W;
+            row[0] = (uint32_t)e->led_idx[slot];
+            row[1] = e->led_info[slot];
+            row[2] = e->led_tag[slot];
+            memcpy(row + 3, (const float*)e->led_ret + slot, 4);
+            for (int j = 0; j < O; ++j) {
+                float x = ((const float*)e->led_obs)[slot * O + j];
+                if (obs_rms) {
+                    const float mu = (float)obs_rms[j], inv = (float)(1.0 / sqrt(obs_rms[O + j] + (double)eps_norm));
+                    x = fminf(fmaxf((x - mu) * inv, -clip_obs), clip_obs);
+                }
+                memcpy(row + 4 + j, &x, 4);
+            }
+        }
+    }
+    out[0] = appended;
+    out[1] = (uint32_t)(held < max_rows ? held : max_rows);
+    out[2] = (uint32_t)W;
+    out[3] = held;
+    out[4] = out[5] = out[6] = out[7] = 0u;
+    return FPV_OK;
+}
+
 /* SB3 RolloutBuffer.compute_returns_and_advantage; stats = {count, sum A, sum A^2}, mean_std = {mean, population std} */
 int fpv_cpu_gae(int64_t T, int64_t n, const float* rewards, const float* values, const uint8_t* episode_starts,
                 const float* last_values, const uint8_t* last_dones, float gamma, float lam, float* advantages, float* returns,

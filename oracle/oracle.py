@@ -28,7 +28,8 @@ TERM, TRUNC, OOB, FLOOR = 1, 2, 4, 8
 
 def build(force: bool = False) -> str:
     """Compile oracle/fpv_oracle.c with gcc (make).  Returns the .so path."""
-    srcs = [os.path.join(_HERE, f) for f in ("fpv_oracle.c", "fpv_oracle.h", "fpv_cpu.c", "cv_restate.c", "cv_restate.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("fpv_oracle.c", "fpv_oracle.h", "fpv_cpu.c", "cv_restate.c", "cv_restate.h",
+                                                os.path.join("..", "include", "fpv_env.h"))]
     if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libfpv_oracle.so"],
                               stdout=subprocess.DEVNULL)

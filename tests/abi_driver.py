@@ -9,7 +9,7 @@ import numpy as np
 from fpv_drone_rl_agent_amd import _lib
 
 TWIN = ["fpv_create", "fpv_destroy", "fpv_reset", "fpv_step", "fpv_step_f64", "fpv_dims", "fpv_get_state", "fpv_set_state",
-        "fpv_set_tick", "fpv_get_tick", "fpv_ledger_view", "fpv_ledger_clear", "fpv_gae", "fpv_last_error", "fpv_version"]
+        "fpv_set_tick", "fpv_get_tick", "fpv_ledger_view", "fpv_ledger_clear", "fpv_ledger_pack", "fpv_gae", "fpv_last_error", "fpv_version"]
 
 
 class AbiDriver:
@@ -125,6 +125,14 @@ class AbiDriver:
 
     def ledger_clear(self):
         self.call("ledger_clear", self.h, None)
+
+    def ledger_pack(self, max_rows, obs_rms=None, clip=10.0, eps=1e-8):
+        """fpv_ledger_pack: (header[8], rows [packed, 4 + O] as uint32 words)."""
+        out = self.buf((8 + max_rows * (4 + self.O),), np.uint32)
+        rms = self.put(np.asarray(obs_rms, np.float64)) if obs_rms is not None else None
+        self.call("ledger_pack", self.h, self.ptr(rms), C.c_float(clip), C.c_float(eps), self.ptr(out), C.c_int64(max_rows), None)
+        w = self.host(out).copy()
+        return w[:8], w[8:8 + int(w[1]) * (4 + self.O)].reshape(int(w[1]), 4 + self.O)
 
     def gae(self, rewards, values, starts, last_values, last_dones, gamma=0.99, lam=0.95):
         T, n = rewards.shape

@@ -64,6 +64,23 @@ def test_twin_steps_like_the_oracle_batch_functions(oracle):
     d.destroy()
 
 
+def test_twin_ledger_pack_is_the_ledger_as_one_block(oracle):
+    n = 256
+    st = oracle.synthetic_states(n, seed=4)
+    st[::3, 34] = 401
+    d = twin().create(n, precision=0, noise=0.02, seed=5, ledger_capacity=2 * n)
+    d.set_state(st)
+    d.step(np.random.default_rng(0).uniform(-1, 1, (n, 4)))
+    got = d.ledger()
+    hdr, rows = d.ledger_pack(n)                           # fpv_ledger_pack: the same rows, dense, in (tile, row) order
+    assert hdr[0] == hdr[1] == hdr[3] == got["count"] >= n // 3 and hdr[2] == 24
+    assert np.array_equal(rows[:, 0].astype(np.int32), got["idx"]) and np.array_equal(rows[:, 1], got["info"])
+    assert np.array_equal(np.ascontiguousarray(rows[:, 4:]).view(np.float32), got["obs"])
+    d.ledger_clear()
+    assert d.ledger_pack(8)[0][0] == 0
+    d.destroy()
+
+
 def test_twin_reset_keeps_prev_action_and_honours_the_mask(oracle):
     n = 64
     d = twin().create(n, precision=1, noise=0.0, detector=1)

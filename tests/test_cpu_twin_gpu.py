@@ -106,3 +106,36 @@ def test_gae_agrees(oracle):
     a, b = product().gae(r, v, s, lv, ld), twin().gae(r, v, s, lv, ld)
     assert np.allclose(a[0], b[0], rtol=1e-5, atol=1e-5) and np.allclose(a[1], b[1], rtol=1e-5, atol=1e-5)
     assert a[2][0] == b[2][0] == T * n and np.allclose(a[2][1:], b[2][1:], rtol=1e-5) and np.allclose(a[3], b[3], rtol=1e-5, atol=1e-6)
+
+
+def test_ledger_pack_is_the_ledger_as_one_block(oracle):
+    """fpv_ledger_pack (the host-mode VecEnv's one copy per step): header + rows equal the ledger's own arrays in (tile, row) order,
+    on the device and through the twin; with statistics the terminal observations come normalised as fpv_normalize does it; a
+    max_rows below the row count packs the first rows and still reports every count."""
+    n = 4096
+    st = oracle.synthetic_states(n, seed=8).astype(np.float32).astype(np.float64)
+    st[::5, 34] = 401                                                  # a truncation wave on top of the terminations
+    a = np.random.default_rng(3).uniform(-1, 1, (n, 4)).astype(np.float32)
+    rms = np.concatenate([np.linspace(-0.5, 0.5, 20), np.linspace(0.5, 2.0, 20), [100.0]])
+    got = {}
+    for name, d in (("product", product()), ("twin", twin())):
+        d.create(n, precision=0, noise=0.02, seed=7, ledger_capacity=2 * n)
+        d.set_state(st); d.set_tick(77)
+        d.step(a)
+        led = d.ledger()
+        hdr, rows = d.ledger_pack(n)
+        assert hdr[0] == hdr[1] == hdr[3] == led["count"] > n // 5 and hdr[2] == 24
+        assert np.array_equal(rows[:, 0].astype(np.int32), led["idx"]) and np.array_equal(rows[:, 1], led["info"])
+        assert np.array_equal(rows[:, 2], led["tag"]) and (np.diff(rows[:, 0].astype(np.int64)) > 0).all()
+        assert np.array_equal(rows[:, 3].view(np.float32), led["ep_return"])
+        assert np.array_equal(np.ascontiguousarray(rows[:, 4:]).view(np.float32), led["obs"])
+        hdr_n, rows_n = d.ledger_pack(n, obs_rms=rms, clip=10.0, eps=1e-8)
+        mu, inv = rms[:20].astype(np.float32), (1.0 / np.sqrt(rms[20:40] + np.float64(np.float32(1e-8)))).astype(np.float32)
+        want = np.clip((led["obs"] - mu) * inv, -10.0, 10.0).astype(np.float32)
+        assert np.allclose(np.ascontiguousarray(rows_n[:, 4:]).view(np.float32), want, rtol=0, atol=2e-6)
+        hdr_s, rows_s = d.ledger_pack(100)
+        assert hdr_s[0] == hdr_s[3] == led["count"] and hdr_s[1] == 100 and np.array_equal(rows_s, rows[:100])
+        got[name] = (hdr, rows)
+        d.destroy()
+    (ha, ra), (hb, rb) = got["product"], got["twin"]
+    assert np.array_equal(ha, hb) and np.array_equal(ra[:, :3], rb[:, :3])           # who ended, how, when: bit-exact

@@ -47,6 +47,7 @@ def test_vec_env_host_mode_matches_oracle(oracle, n):
     cfg = oracle.make_cfg(noise_ratio=0.0)
     rng = np.random.default_rng(0)
     saw_done = False
+    prev_infos = None
     t_got, t_ref, ep_got, ep_ref = [], [], [], []
     for t in range(45):
         a = rng.uniform(-1, 1, (n, 4))
@@ -72,8 +73,12 @@ def test_vec_env_host_mode_matches_oracle(oracle, n):
             if n == 16 and t < 35:     # (these sixteen stay down at zero throttle: the floor rule ends them on call 32; among 4 096
                 assert inf["episode"]["l"] == 32 and inf["on_floor"]      # some are lifted by the rate controller's saturated mixer)
             ep_got.append(inf["episode"]["r"]); ep_ref.append(led.rows()[2][k])
-        for i in np.nonzero(~d)[0]:
-            assert infos[i] == {}
+        for i in np.nonzero(~d)[0]:          # hover.py:102,358: a live env returns its four flags on every step
+            assert infos[i] == {"out_of_bounds": False, "collision": False, "env_complete": False, "on_floor": False}
+        assert len({id(x) for x in infos}) == n and (prev_infos is None or not ({id(x) for x in infos} & {id(x) for x in prev_infos}))
+        for x in infos:                      # what a wrapper writes into this step's dicts (SB3's VecMonitor: "episode") ...
+            x["written_by_a_wrapper"] = t
+        prev_infos = infos                   # ... never shows in a later step's
     assert saw_done
     # terminal observations (without the camera words): airborne drones under +-30 rad/s rate commands tumble, and an fp32
     # trajectory leaves the fp64 one within a few steps — a small share of the late episode ends may differ

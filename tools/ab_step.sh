@@ -1,11 +1,10 @@
 #!/bin/bash
-# A/B of library builds on the stand-alone env step inside ONE gpurun call: variants/<name>.so are copied over the product library in
-# turn and tools/pmc_step.py-like timing is taken (HIP events, 65 536 drones, synthetic states).  Usage: bash tools/ab_step.sh A B ...
+# A/B of library builds on the stand-alone env step inside ONE gpurun call: variants/<name>.so are selected in turn
+# (FPV_LIB_VARIANT; "product" = the product library) and tools/pmc_step.py-like timing is taken (HIP events, 65 536 drones, synthetic states).  Usage: bash tools/ab_step.sh A B ...
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-cp fpv_drone_rl_agent_amd/libfpv_env.so /tmp/keep.so
 for v in "$@"; do
-  cp variants/$v.so fpv_drone_rl_agent_amd/libfpv_env.so
+  if [ "$v" = product ]; then unset FPV_LIB_VARIANT; else export FPV_LIB_VARIANT=$v; fi
   python - "$v" <<'PY'
 import sys, numpy as np, torch
 sys.path.insert(0, ".")
@@ -30,4 +29,3 @@ print(sys.argv[1], out)
 eng.close()
 PY
 done
-cp /tmp/keep.so fpv_drone_rl_agent_amd/libfpv_env.so

@@ -44,9 +44,7 @@ python tools/microbench_ppo.py 262144 2097152 20 f32 two_kernels >> $O/ppo_event
 bash tools/ppo_rows_sweep.sh > /dev/null 2>&1; cp gpurun_out/ppo_sweep/sweep.jsonl $O/ppo_rows_sweep.jsonl
 # phase stamps of the one-kernel gradient: the diagnostic build (FPV_EXTRA_HIPCC_FLAGS=-DFPV_PPO_STAMPS=1, kept as variants/ppo_stamps.so)
 if [ -f variants/ppo_stamps.so ]; then
-  cp fpv_drone_rl_agent_amd/libfpv_env.so /tmp/keep_product.so && cp variants/ppo_stamps.so fpv_drone_rl_agent_amd/libfpv_env.so
-  python tools/ppo_stamps.py > $O/ppo_stamps.txt 2> /dev/null
-  cp /tmp/keep_product.so fpv_drone_rl_agent_amd/libfpv_env.so
+  FPV_LIB_VARIANT=ppo_stamps python tools/ppo_stamps.py > $O/ppo_stamps.txt 2> /dev/null
 fi
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -size +3M -delete
 python - <<'PY'
