@@ -39,6 +39,10 @@ sys.path.insert(0, ROOT)
 ALG_BYTES_PER_STEP = 382  # 35 words r+w, 16 B action, 80 B obs, 4 B reward, 2 B flags
 HBM_PEAK_GBPS = 8000.0    # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32-input MFMA (= vector fp32) peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (~2.5 PFLOP/s; the 2:1-sparsity figure is not used)
+# what the 6-term bf16 split of the policy issues per drone on the bf16 pipe: both nets, layer 1 (K = 20 padded to 32) and layer 2,
+# six piece products each (csrc/fpv_policy_split.h mfma6)
+SPLIT_BF16_FLOP_PER_ROW = 2 * 6 * 2 * (128 * 32 + 128 * 128)  # 491 520
 POLICY_FLOP_PER_ROW = 2 * (2 * (20 * 128 + 128 * 128) + 128 * 4 + 128)  # 77 056: both MLPs + heads
 # fp32 operations of one hover env step per drone, counted (profiles/r02_step_instruction_mix.json, per 64-drone wave: 529 add +
 # 692 mul + 831 fma (x 2) + 120 transcendental); SURVEY.md §8(d) had estimated 5.2 k
@@ -219,7 +223,11 @@ def main() -> None:
     ap.add_argument("--task", choices=["hover", "yaw"], default="hover",
                     help="yaw = BASELINE configs[4] (yaw-setpoint task with domain randomisation); not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-split-extra", action="store_true", help="skip the extra bf16x6-policy measurement")
+    ap.add_argument("--no-split-extra", action="store_true",
+                    help="skip the extra measurements with the other policy arithmetic (exact fp32-input MFMA) and launch shape")
+    ap.add_argument("--policy-gemm", choices=["bf16x6", "f32"], default=None,
+                    help="policy arithmetic of the headline: bf16x6 (the default since round 5: the 128-wide products as 6-term bf16 "
+                         "splits, fp32 accumulate, every row at fp32 rounding level) or f32 (exact fp32-input MFMA, rounds 1-4's headline)")
     ap.add_argument("--no-host-mode", action="store_true", help="skip the extra BASELINE configs[1] (host numpy mode) measurement")
     ap.add_argument("--kernel-launches", type=int, default=200)
     ap.add_argument("--plumbing-only", action="store_true",
@@ -275,7 +283,9 @@ def main() -> None:
     policy = (ActorCritic(obs_dim=12, act_dim=1) if yaw else ActorCritic()).to(dev)
     eng = FpvEngine(n, dev, noise_ratio=0.02, seed=0, id_offset=rank * n, task=args.task, domain_rand=yaw,
                     ledger_capacity=n * max(2, T // 8), detector="analytic" if yaw else args.detector)
-    col = RolloutCollector(eng, policy, n_steps=T, use_graph=not args.no_graph, one_launch=False if args.two_launch else None)
+    col = RolloutCollector(eng, policy, n_steps=T, use_graph=not args.no_graph, one_launch=False if args.two_launch else None,
+                           policy_gemm=None if yaw else args.policy_gemm)
+    gemm = col.policy_gemm                                   # "bf16x6" for the hover task unless --policy-gemm f32
     col.start()
     if not yaw:
         eng.set_state(torch.from_numpy(synthetic_states(n, seed=rank)))  # staggered step counts => staggered dones
@@ -310,23 +320,25 @@ def main() -> None:
     elapsed = repeats[len(repeats) // 2] if len(repeats) % 2 else 0.5 * (repeats[len(repeats) // 2 - 1] + repeats[len(repeats) // 2])
     episodes = int(col.episodes["count"])
 
-    # ---- extra (not the headline): the same K steps with the policy GEMMs on the 6-term bf16 split — as ONE kernel per step
-    # (rollout_step_split_kernel) where the one-kernel step is served, and as two kernels per step ----
-    split_value = split_value_two = None
+    # ---- extras (not the headline): the same K steps with the OTHER policy arithmetic — exact fp32-input MFMA when the headline runs
+    # the 6-term bf16 split (the default), the split when the headline was asked to be exact — as one kernel per step where that is
+    # served, and as two kernels per step ----
+    other_gemm = "f32" if gemm == "bf16x6" else "bf16x6"
+    other_value = other_value_two = None
     if not yaw and not args.no_split_extra:
-        def split_rate():
+        def other_rate():
             for _ in range(2):
                 col.collect()
             r2 = sorted(timed_region() for _ in range(max(1, min(3, n_rep))))
             return n * world * K / r2[len(r2) // 2]
         was_one = col._one_launch
-        col.set_policy_gemm("bf16x6")
+        col.set_policy_gemm(other_gemm)
         if col._one_launch:
-            split_value = split_rate()
+            other_value = other_rate()
             col._one_launch = False
             col._graph = None
-        split_value_two = split_rate()
-        col.set_policy_gemm("f32")
+        other_value_two = other_rate()
+        col.set_policy_gemm(gemm)
         col._one_launch = was_one
         col._graph = None
 
@@ -492,7 +504,9 @@ def main() -> None:
                                         clip_obs=col.obs_norm.clip, eps_norm=col.obs_norm.eps)
                 ev_one = timed(one_step)
                 in_graph = graph_kernel_times()
-                us_traced = pick(in_graph, "rollout_step_kernel")
+                split = gemm == "bf16x6"
+                k0_name = "fpv::rollout_step_split_kernel" if split else "fpv::rollout_step_kernel<%d>" % (1 if yaw else 0)
+                us_traced = pick(in_graph, "rollout_step_split_kernel" if split else "rollout_step_kernel")
                 # `us_per_launch` = HIP events on the launch stream around back-to-back launches of the kernel (what rocprofv3's
                 # per-kernel average agrees with, profiles/); the activity tracer's timestamps of the launches inside the replayed
                 # graph stand beside it (the tracer stretches the replay it traces)
@@ -506,17 +520,31 @@ def main() -> None:
                 phases = kernel_phases() if world == 1 else None      # (extra captures + collects: kept off the multi-rank runs)
                 tf = pol_flop * n / us_one / 1e6                         # MFMA work only: what `bound: mfma` prices
                 tf_all = (pol_flop + env_flop) * n / us_one / 1e6
-                roofline = {"bound": "mfma", "kernel": "fpv::rollout_step_kernel<%d>" % (1 if yaw else 0), "achieved": round(tf, 1),
+                roofline = {"bound": "mfma", "kernel": k0_name, "achieved": round(tf, 1),
                             "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
-                            "traffic": None if yaw else traffic_of("fpv::rollout_step_kernel"), "us_per_launch": round(us_one, 2),
+                            "traffic": None if yaw else traffic_of(k0_name.split("<")[0]), "us_per_launch": round(us_one, 2),
                             "launches": L, "algorithmic_flop_per_launch": pol_flop * n,
                             "algorithmic_flop_per_drone": {"policy (MFMA)": pol_flop, "env step (VALU, counted, not in frac)": env_flop or None},
-                            "frac_fp32_pipe_incl_env_step_valu_flops": round(tf_all / MFMA_F32_PEAK_TFLOPS, 4), "dtype": "f32",
+                            "frac_fp32_pipe_incl_env_step_valu_flops": round(tf_all / MFMA_F32_PEAK_TFLOPS, 4),
+                            "dtype": "f32 (policy products: 6-term bf16 split, fp32 accumulate)" if split else "f32",
                             "measured": how,
                             "us_per_launch_traced_inside_the_replayed_graph": round(us_traced, 2) if us_traced else None,
                             "us_per_step_timed_region": round(cadence, 2),
                             "frac_upper_bound_from_step_cadence": round(pol_flop * n / min(us_one, cadence) / 1e6 / MFMA_F32_PEAK_TFLOPS, 4)}
-                roofline["note"] = ("one kernel per rollout step: actor-critic forward (the matrix work `frac` prices: MFMA flops only over the "
+                if split:
+                    bf = SPLIT_BF16_FLOP_PER_ROW * n / us_one / 1e6
+                    roofline["as_issued_on_the_bf16_pipe"] = {
+                        "flop_per_drone": SPLIT_BF16_FLOP_PER_ROW, "achieved": round(bf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(bf / MFMA_BF16_PEAK_TFLOPS, 4),
+                        "note": "the six bf16 piece products per fp32 product that the kernel really issues, over the WHOLE kernel; the "
+                                "matrix pipe is no longer what bounds this kernel — vector issue is (the cut of the activations into "
+                                "pieces, tanh, heads, sampling, and the env step: DESIGN §4)"}
+                roofline["note"] = (("`achieved` / `frac` price the ALGORITHMIC work — the policy's 77 056 fp32 multiply-add flops per drone, "
+                                     "delivered at fp32 rounding level — against the dense fp32-input MFMA peak, the rate an exact-fp32 matrix "
+                                     "formulation is bound by (it is the figure rounds 1-4 reported for rollout_step_kernel<0>, so the two are "
+                                     "comparable); the products themselves run as 6-term bf16 splits on the bf16 pipe, priced in "
+                                     "`as_issued_on_the_bf16_pipe`.  " if split else "") +
+                                    "one kernel per rollout step: actor-critic forward (the matrix work `frac` prices: MFMA flops only over the "
                                     "WHOLE kernel's measured duration) AND the env step of the same drones (vector work on the same fp32 pipe; "
                                     "`frac_fp32_pipe_incl_env_step_valu_flops` adds its counted flops); peak = dense fp32-input MFMA rate (155 TF "
                                     "measured with resident operands at a 2.38 GHz in-kernel clock, profiles/r02_mfma_peak.txt); vector "
@@ -528,10 +556,10 @@ def main() -> None:
                 # flags, return accumulator) over the whole kernel's measured duration
                 k0_bytes = 563 if not yaw else None
                 if k0_bytes:
-                    out_hbm_whole = hbm("fpv::rollout_step_kernel<0> (whole kernel)", us_one, k0_bytes)
-                    out_hbm_whole.update(traffic=traffic_of("fpv::rollout_step_kernel"), measured=how,
-                                         note="563 B per drone and step over the WHOLE kernel's duration: the kernel is bound by the fp32 "
-                                              "pipe (policy products), not by HBM; this is the honest HBM figure of the rollout step")
+                    out_hbm_whole = hbm(k0_name + " (whole kernel)", us_one, k0_bytes)
+                    out_hbm_whole.update(traffic=traffic_of(k0_name.split("<")[0]), measured=how,
+                                         note="563 B per drone and step over the WHOLE kernel's duration: the kernel is bound by instruction "
+                                              "issue (policy products and vector work), not by HBM; this is the honest HBM figure of the rollout step")
                 else:
                     out_hbm_whole = None
                 if phases:
@@ -558,8 +586,9 @@ def main() -> None:
                 ev_fused = timed(lambda: eng.step_fused(col.clipped, done=col._starts[1], ret=col.rew_norm.ret,
                                                         partials=col.partials, gamma=col.gamma, reward=col.raw_rew[0]))
                 in_graph = graph_kernel_times()
-                us_pol = pick(in_graph, "policy_forward_kernel", at_least=0.75 * ev_pol) or ev_pol
-                us_pol_all = pick(in_graph, "policy_forward_kernel")     # what a per-symbol profiler average shows
+                pol_sym = "policy_split_forward_kernel" if gemm == "bf16x6" else "policy_forward_kernel"
+                us_pol = pick(in_graph, pol_sym, at_least=0.75 * ev_pol) or ev_pol
+                us_pol_all = pick(in_graph, pol_sym)     # what a per-symbol profiler average shows
                 us_fused = pick(in_graph, "step_quad_kernel" if quad else "step_kernel<float,true,true") or ev_fused
                 if not (0.6 * ev_pol < us_pol < 1.6 * ev_pol and 0.6 * ev_fused < us_fused < 1.6 * ev_fused):
                     in_graph, us_pol, us_fused = {}, ev_pol, ev_fused     # tracer output implausible: trust the events
@@ -568,10 +597,11 @@ def main() -> None:
                 roofline_env = hbm(k_fused, us_fused, ALG_BYTES_PER_STEP)
                 roofline_env.update(measured=how, us_per_launch_hip_events_back_to_back=round(ev_fused, 2))
                 tf = POLICY_FLOP_PER_ROW * n / us_pol / 1e6
-                roofline = {"bound": "mfma", "kernel": "fpv::policy_forward_kernel", "achieved": round(tf, 1),
+                roofline = {"bound": "mfma", "kernel": "fpv::" + pol_sym, "achieved": round(tf, 1),
                             "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
-                            "traffic": traffic_of("fpv::policy_forward_kernel"), "us_per_launch": round(us_pol, 2),
-                            "launches": L, "algorithmic_flop_per_launch": POLICY_FLOP_PER_ROW * n, "dtype": "f32",
+                            "traffic": traffic_of("fpv::" + pol_sym), "us_per_launch": round(us_pol, 2),
+                            "launches": L, "algorithmic_flop_per_launch": POLICY_FLOP_PER_ROW * n,
+                            "dtype": "f32 (policy products: 6-term bf16 split, fp32 accumulate)" if gemm == "bf16x6" else "f32",
                             "measured": how, "us_per_launch_hip_events_back_to_back": round(ev_pol, 2)}
                 roofline["note"] = ("peak = dense fp32-input MFMA rate (155 TF measured with resident random operands, 2.38 GHz in-kernel "
                                     "clock: profiles/r02_mfma_peak.txt); vector instructions do not co-execute with fp32-input MFMA "
@@ -600,20 +630,22 @@ def main() -> None:
             "metric": "env_steps_per_sec", "value": n * world * K / elapsed, "unit": "env-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3,
             "repeats": len(repeats), "repeats_ms_per_step": [round(r / K * 1e3, 5) for r in repeats],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (policy products: 6-term bf16 split, fp32 accumulate)" if gemm == "bf16x6" else "f32",
             "data": "synthetic (random-init policy, seeded random-init drone states, motor noise on)",
             "config": {"workload": ("BASELINE.json configs[4]: yaw-setpoint task with domain-randomised mass/drag, on-device "
                                     "PPO rollout (torch policy 12->1, HIP env-step, VecNormalize) + GAE + all-gather" if yaw else
                                     "BASELINE.json configs[2]: 65 536 hover drones per GPU, on-device PPO rollout "
-                                    + ("(one kernel per step: VecNormalize statistics merge, fp32-MFMA policy forward + sample, then the "
+                                    + ("(one kernel per step: VecNormalize statistics merge, MFMA policy forward + sample, then the "
                                        "env step + VecNormalize bookkeeping of the same drones; " if col._one_launch else
-                                       "(two kernels per step: fp32-MFMA policy forward + sample with the VecNormalize statistics merge in "
+                                       "(two kernels per step: MFMA policy forward + sample with the VecNormalize statistics merge in "
                                        "its prologue, HIP env-step + VecNormalize bookkeeping; ") +
                                     "done-ledger timeout bootstrap, GAE) + advantage-stat all-gather every n_steps"),
                        "drones_per_gpu": n, "total_drones": n * world, "n_steps": T,
-                       "hip_graph": not args.no_graph, "kernels_per_step": 1 if col._one_launch else 2, "detector": "analytic" if yaw else args.detector, "policy": "MlpPolicy pi/vf [128,128] tanh" + ("" if yaw else " (39 049 params), exact-fp32 MFMA"),
+                       "hip_graph": not args.no_graph, "hip_graph_capture_mode": col.capture_mode_used, "kernels_per_step": 1 if col._one_launch else 2, "detector": "analytic" if yaw else args.detector, "policy": "MlpPolicy pi/vf [128,128] tanh" + ("" if yaw else " (39 049 params), " + ("hidden products as 6-term bf16 splits on the bf16 MFMA, fp32 accumulate (fp32 rounding level on every row)" if gemm == "bf16x6" else "exact fp32-input MFMA")), "policy_gemm": gemm,
                        "episodes_in_last_rollout": episodes, **({"rehearsal": "FPV_REHEARSE_RANKS=1: the collector's N > 1 arrangement (the real all-gather over a single-rank RCCL group behind every rollout, advantage statistics from the gathered payload, rank merge of the VecNormalize statistics) with ONE rank"} if (world == 1 and D.several_ranks()) else {})},
             "roofline": roofline,
+            "library": __import__("fpv_drone_rl_agent_amd")._lib.library_id(),      # which build produced this line (path, sha256[:16])
         }
         if roofline_env is not None:
             out["env_step_phase" if "exposed_phase_us" in roofline_env else "roofline_env_step"] = roofline_env
@@ -622,11 +654,13 @@ def main() -> None:
             out["roofline_hbm_whole_kernel"] = out_hbm_whole
         if roofline_env_fused is not None:
             out["roofline_env_step_standalone_fused"] = roofline_env_fused
-        if split_value is not None or split_value_two is not None:
-            out["extra"] = {"value_one_kernel_bf16x6": split_value, "value_with_policy_gemm_bf16x6": split_value_two,
-                            "note": "same workload with the policy's hidden GEMMs on a 6-term bf16 split (fp32-level error, "
-                                    "tests/test_policy_gpu.py): value_one_kernel_bf16x6 = one kernel per step (rollout_step_split_kernel), "
-                                    "value_with_policy_gemm_bf16x6 = two kernels per step; the headline value uses exact-fp32 MFMA"}
+        if other_value is not None or other_value_two is not None:
+            key = "exact_fp32_policy" if other_gemm == "f32" else "policy_gemm_bf16x6"
+            out["extra"] = {f"value_one_kernel_{key}": other_value, f"value_two_kernels_{key}": other_value_two,
+                            "note": ("same workload with the policy's products on the exact fp32-input MFMA (rounds 1-4's headline "
+                                     "arithmetic; rollout_step_kernel<0> / policy_forward_kernel)" if other_gemm == "f32" else
+                                     "same workload with the policy's hidden products as 6-term bf16 splits (rollout_step_split_kernel)") +
+                                    ": one kernel per step, and two kernels per step; DESIGN §5b has the decision and its evidence"}
         if f64_value is not None:
             out.setdefault("extra", {})["value_f64_env"] = f64_value
             out["extra"]["value_f64_env_note"] = ("env-steps/s of fpv_step on an FPV_F64 handle (env step only, no policy, HIP events over "

@@ -105,6 +105,8 @@ SIGNATURES = {
     "fpv_advantage_stats": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
     "fpv_rank_merge": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "fpv_ledger_scan": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp]),
+    "fpv_ledger_scan_finalize": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp, _vp, _i64, _f32,
+                                           _f32, _vp, _vp]),
     "fpv_ledger_scatter": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _vp, _i64, _i64, _vp]),
     "fpv_gae": (C.c_int, [_i64, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "fpv_normalize": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _i32, _f32, _f32, _vp]),

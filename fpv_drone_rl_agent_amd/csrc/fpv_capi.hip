@@ -476,18 +476,37 @@ int fpv_rank_merge(const double* gathered, int32_t world, int32_t stride, int32_
     return FPV_OK;
 }
 
-int fpv_ledger_scan(fpv_env* e, const double* snapshots, int64_t snapshot_stride, int32_t T, float clip_obs, float eps_norm,
-                    float* tobs, int32_t* t_idx, int32_t* d_idx, int64_t cap, int32_t* counters, double* sums,
-                    int32_t counters_are_zero, void* status_out, void* stream) {
+static int ledger_scan_impl(const char* who, fpv_env* e, const double* snapshots, int64_t snapshot_stride, int32_t T, float clip_obs,
+                            float eps_norm, float* tobs, int32_t* t_idx, int32_t* d_idx, int64_t cap, int32_t* counters, double* sums,
+                            int32_t counters_are_zero, void* status_out, const float* raw, const double* rew_snapshots,
+                            int64_t rew_stride, float clip_reward, float eps_reward, float* rewards, void* stream) {
     if (!e || !tobs || !t_idx || !d_idx || !counters || !sums || cap <= 0 || T <= 0 || T > 65535)
-        return fail(FPV_ERR_ARG, "fpv_ledger_scan: null argument, cap <= 0 or T outside 1..65535");
-    if (e->cfg.precision != FPV_F32) return fail(FPV_ERR_UNSUPPORTED, "fpv_ledger_scan: fp32 handles");
-    if (snapshots && snapshot_stride < 2 * e->obs_words) return fail(FPV_ERR_ARG, "fpv_ledger_scan: snapshot rows hold {mean[O], var[O], ...}");
+        return fail(FPV_ERR_ARG, "%s: null argument, cap <= 0 or T outside 1..65535", who);
+    if (e->cfg.precision != FPV_F32) return fail(FPV_ERR_UNSUPPORTED, "%s: fp32 handles", who);
+    if (snapshots && snapshot_stride < 2 * e->obs_words) return fail(FPV_ERR_ARG, "%s: snapshot rows hold {mean[O], var[O], ...}", who);
+    if (raw && (!rewards || !rew_snapshots || rew_stride < 43)) return fail(FPV_ERR_ARG, "%s: reward scaling needs rewards and snapshot rows of >= 43 words", who);
     FPV_HIP(launch_ledger_scan(e->led_count, e->led_idx, e->led_info, e->led_tag, (const float*)e->led_ret, (const float*)e->led_obs,
                                e->tick, e->tiles, (int)e->led_rows, e->obs_words, snapshots, snapshot_stride, T, clip_obs, eps_norm,
                                tobs, t_idx, d_idx, cap, counters, sums, counters_are_zero != 0, e->merge_ticket + 4, status_out,
-                               (hipStream_t)stream));
+                               raw, rewards, rew_snapshots, rew_stride, e->cfg.num_envs, clip_reward, eps_reward, (hipStream_t)stream));
     return FPV_OK;
+}
+
+int fpv_ledger_scan(fpv_env* e, const double* snapshots, int64_t snapshot_stride, int32_t T, float clip_obs, float eps_norm,
+                    float* tobs, int32_t* t_idx, int32_t* d_idx, int64_t cap, int32_t* counters, double* sums,
+                    int32_t counters_are_zero, void* status_out, void* stream) {
+    return ledger_scan_impl("fpv_ledger_scan", e, snapshots, snapshot_stride, T, clip_obs, eps_norm, tobs, t_idx, d_idx, cap, counters, sums,
+                            counters_are_zero, status_out, nullptr, nullptr, 0, 0.f, 0.f, nullptr, stream);
+}
+
+int fpv_ledger_scan_finalize(fpv_env* e, const double* snapshots, int64_t snapshot_stride, int32_t T, float clip_obs, float eps_norm,
+                             float* tobs, int32_t* t_idx, int32_t* d_idx, int64_t cap, int32_t* counters, double* sums,
+                             int32_t counters_are_zero, void* status_out, const float* raw, const double* reward_snapshots,
+                             int64_t reward_snapshot_stride, float clip_reward, float eps_reward, float* rewards, void* stream) {
+    if (!raw) return fail(FPV_ERR_ARG, "fpv_ledger_scan_finalize: raw is required (fpv_ledger_scan is the call without the reward scaling)");
+    return ledger_scan_impl("fpv_ledger_scan_finalize", e, snapshots, snapshot_stride, T, clip_obs, eps_norm, tobs, t_idx, d_idx, cap,
+                            counters, sums, counters_are_zero, status_out, raw, reward_snapshots, reward_snapshot_stride, clip_reward,
+                            eps_reward, rewards, stream);
 }
 
 int fpv_ledger_scatter(const int32_t* counters, const int32_t* t_idx, const int32_t* d_idx, const float* values, float gamma,
@@ -632,12 +651,12 @@ int fpv_policy_forward(fpv_policy* p, const fpv_policy_io* io, void* stream) {
             return fail(FPV_ERR_ARG, "fpv_policy_forward: scatter needs the V net, scatter_t, scatter_d and a positive scatter_stride");
         sc = ScatterArgs{io->scatter_t, io->scatter_d, io->scatter_out, io->scatter_stride, io->scatter_scale};
     }
-    // the bf16-split kernel evaluates both nets of the hover widths in 512-thread workgroups over a host-side row count;
-    // any other request is served by the exact-fp32 kernel (its image is always packed)
-    if (p->gemm == 1 && p->in_dim == 20 && p->act_dim == 4 && nets == 3 && !io->narrow && !io->n_dev && !sc.out) {
+    // the bf16-split kernel evaluates the hover widths' nets (both, or one: the rollout tail's V(s_T)) in 512-thread workgroups over
+    // a host-side row count; any other request is served by the exact-fp32 kernel (its image is always packed)
+    if (p->gemm == 1 && p->in_dim == 20 && p->act_dim == 4 && !io->narrow && !io->n_dev && !sc.out) {
         FPV_HIP(launch_policy_split_forward(p->split_image, io->obs, io->rms, io->eps_in, io->tick, io->obs_n, io->action,
                                             io->clipped, io->value, io->logp, io->eps_out, io->n, io->seed, io->id_offset,
-                                            io->clip_obs, io->eps_norm, io->deterministic, p->cus, mg, (hipStream_t)stream));
+                                            io->clip_obs, io->eps_norm, io->deterministic, p->cus, nets, mg, (hipStream_t)stream));
         return FPV_OK;
     }
 #ifdef FPV_EXPERIMENTS

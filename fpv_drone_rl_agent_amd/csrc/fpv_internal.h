@@ -206,7 +206,8 @@ hipError_t launch_ledger_scan(const uint32_t* led_count, const int32_t* led_idx,
                               const float* led_ret, const float* led_obs, const uint64_t* tick, int64_t tiles, int rows,
                               int obs_words, const double* snapshots, int64_t stride, int T, float clip_obs, float eps,
                               float* tobs, int32_t* t_idx, int32_t* d_idx, int64_t cap, int32_t* counters, double* sums,
-                              bool counters_are_zero, uint32_t* ticket, void* status_out, hipStream_t s);
+                              bool counters_are_zero, uint32_t* ticket, void* status_out, const float* fin_raw, float* fin_out,
+                              const double* fin_snap, int64_t fin_stride, int64_t fin_n, float fin_clip, float fin_eps, hipStream_t s);
 hipError_t launch_ledger_scatter(const int32_t* counters, const int32_t* t_idx, const int32_t* d_idx, const float* v, float gamma,
                                  float* rewards, int64_t n, int64_t cap, hipStream_t s);
 
@@ -373,7 +374,7 @@ hipError_t launch_policy_split_pack(const float* const* w, unsigned char* image,
 hipError_t launch_policy_split_forward(const unsigned char* image, const float* obs, const double* rms, const float* eps_in,
                                        const uint64_t* tick, float* obs_n, float* action, float* clipped, float* value,
                                        float* logp, float* eps_out, int64_t n, uint64_t seed, uint64_t id_offset,
-                                       float clip_obs, float eps_norm, int deterministic, int max_blocks,
+                                       float clip_obs, float eps_norm, int deterministic, int max_blocks, int nets,
                                        const MergeArgs& merge, hipStream_t s);
 int policy_split_image_bytes();
 

@@ -90,7 +90,7 @@ __device__ __forceinline__ f32x4 split_net_row(int net, const unsigned char* img
             if (k < kIn) x[j] = fminf(fmaxf((x[j] - nrm[k]) * nrm[20 + k], -clip), clip);
         }
         x[12] = x[13] = x[14] = x[15] = 0.0f;
-        if (net == 0 && out.obs_n && live) {
+        if (out.obs_n && live) {                  // (the caller hands obs_n to ONE pass: the first net it evaluates)
             f32x4* o = reinterpret_cast<f32x4*>(out.obs_n + d * kIn);
 #pragma unroll
             for (int q = 0; q < 3; ++q)

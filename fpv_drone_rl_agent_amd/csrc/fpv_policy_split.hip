@@ -74,6 +74,7 @@ struct SplitArgs {
     uint64_t seed, id_offset;
     float clip_obs, eps_norm;
     int32_t deterministic;
+    int32_t net_first, net_count;     // which nets: {0, 2} both (pi, then V), {0, 1} pi only, {1, 1} V only
     MergeArgs mg;
 };
 
@@ -97,11 +98,11 @@ __global__ __launch_bounds__(kSplitThreads) void policy_split_forward_kernel(Spl
     }
 
 #pragma unroll 1
-    for (int net = 0; net < 2; ++net) {
+    for (int net = p.net_first; net < p.net_first + p.net_count; ++net) {
         __syncthreads();   // everyone is done with the previous image
         split_stage_image<kSplitThreads>(p.image, net, lds_raw);
         __syncthreads();
-        const SplitOut out{p.obs_n, p.action, p.clipped, p.value, p.logp, p.eps_out};
+        const SplitOut out{net == p.net_first ? p.obs_n : nullptr, p.action, p.clipped, p.value, p.logp, p.eps_out};
         const uint64_t tick = p.tick ? p.tick[0] : 0ull;
         for (int64_t base = (int64_t)blockIdx.x * kSplitDrones; base < p.n; base += (int64_t)gridDim.x * kSplitDrones) {
             const int64_t d = base + wave * 32 + col;
@@ -120,7 +121,7 @@ hipError_t launch_policy_split_pack(const float* const* w, unsigned char* image,
 hipError_t launch_policy_split_forward(const unsigned char* image, const float* obs, const double* rms, const float* eps_in,
                                        const uint64_t* tick, float* obs_n, float* action, float* clipped, float* value,
                                        float* logp, float* eps_out, int64_t n, uint64_t seed, uint64_t id_offset,
-                                       float clip_obs, float eps_norm, int deterministic, int max_blocks,
+                                       float clip_obs, float eps_norm, int deterministic, int max_blocks, int nets,
                                        const MergeArgs& merge, hipStream_t s) {
     static bool attr_tab[64] = {};                    // hipFuncSetAttribute holds for one device: one flag per ordinal
     int dev_ = 0;
@@ -133,7 +134,7 @@ hipError_t launch_policy_split_forward(const unsigned char* image, const float* 
         attr_set = true;
     }
     SplitArgs p{image, obs, rms, eps_in, tick, obs_n, action, clipped, value, logp, eps_out,
-                n, seed, id_offset, clip_obs, eps_norm, deterministic, merge};
+                n, seed, id_offset, clip_obs, eps_norm, deterministic, (nets & 1) ? 0 : 1, nets == 3 ? 2 : 1, merge};
     int64_t blocks = (n + kSplitDrones - 1) / kSplitDrones;
     if (blocks > max_blocks) blocks = max_blocks;
     hipLaunchKernelGGL(policy_split_forward_kernel, dim3((unsigned)blocks), dim3(kSplitThreads), kSplitLdsBytes, s, p);

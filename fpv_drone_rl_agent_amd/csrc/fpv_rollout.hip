@@ -613,6 +613,14 @@ struct LedgerScanArgs {
     uint32_t* ticket;         // per-handle device word, zero between launches (used when status_out is given)
     void* status_out;         // optional, 32 bytes {counters[4], sums[2]} as they stand when every workgroup has added its share;
                               // may be host memory the device can write (pinned): the host then needs no copy behind the launch
+    // fpv_ledger_scan_finalize: the rollout's deferred reward scaling (reward_finalize_kernel's arithmetic) rides in this launch —
+    // the workgroups behind the first scan_blocks take it — instead of being a launch of its own in front of it
+    const float* fin_raw;     // [T][fin_n] or null
+    float* fin_out;
+    const double* fin_snap;   // [T][fin_stride]: word 42 = the return variance after step t
+    int64_t fin_n, fin_stride;
+    float fin_clip, fin_eps;
+    int32_t scan_blocks;      // workgroups 0 .. scan_blocks - 1 walk the ledger
 };
 
 // Each workgroup walks kScanPerThread x 256 consecutive slots and adds its statistics with ONE set of atomics (an
@@ -623,6 +631,26 @@ __global__ __launch_bounds__(256) void ledger_scan_kernel(LedgerScanArgs a) {
     __shared__ double red_d[4][2];
     __shared__ int red_i[4][3];
     extern __shared__ double nrm_lds[];                          // [T][obs_words]{mean, 1 / sqrt(var + eps)} when a.table != 0
+    if ((int)blockIdx.x >= a.scan_blocks) {                      // (uniform over the workgroup)
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        // r_norm[t][i] = clip(r[t][i] / sqrt(var_t + eps)), var_t = snapshots[t][42]: reward_finalize_kernel on this launch's spare
+        // workgroups; 16 bytes per lane and trip
+        const bool vec = (a.fin_n & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.fin_raw) | reinterpret_cast<uintptr_t>(a.fin_out)) & 15) == 0;
+        const int64_t quads = vec ? a.fin_n / 4 : 0, fb = (int64_t)blockIdx.x - a.scan_blocks, nfb = (int64_t)gridDim.x - a.scan_blocks;
+        for (int64_t t = 0; t < a.T; ++t) {
+            const float inv = (float)(1.0 / sqrt(a.fin_snap[t * a.fin_stride + 42] + (double)a.fin_eps));
+            const f32x4* src = reinterpret_cast<const f32x4*>(a.fin_raw + t * a.fin_n);
+            f32x4* dst = reinterpret_cast<f32x4*>(a.fin_out + t * a.fin_n);
+            for (int64_t q = fb * 256 + threadIdx.x; q < quads; q += nfb * 256) {
+                const f32x4 v = src[q];
+                dst[q] = f32x4{fminf(fmaxf(v.x * inv, -a.fin_clip), a.fin_clip), fminf(fmaxf(v.y * inv, -a.fin_clip), a.fin_clip),
+                               fminf(fmaxf(v.z * inv, -a.fin_clip), a.fin_clip), fminf(fmaxf(v.w * inv, -a.fin_clip), a.fin_clip)};
+            }
+            for (int64_t i = quads * 4 + fb * 256 + threadIdx.x; i < a.fin_n; i += nfb * 256)
+                a.fin_out[t * a.fin_n + i] = fminf(fmaxf(a.fin_raw[t * a.fin_n + i] * inv, -a.fin_clip), a.fin_clip);
+        }
+        return;
+    }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t slots = a.tiles * a.rows;
     const uint32_t tick0 = (uint32_t)(a.tick[0] - (uint64_t)a.T);
@@ -765,7 +793,7 @@ __global__ __launch_bounds__(256) void ledger_scan_kernel(LedgerScanArgs a) {
             // ~20 us between one rollout's last kernel and the next one's first (profiles/r03_rollout_boundary.md).
             __threadfence();
             const unsigned tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            if (tk == gridDim.x - 1u) {
+            if (tk == (unsigned)a.scan_blocks - 1u) {
                 int32_t* oi = reinterpret_cast<int32_t*>(a.status_out);
                 double* od = reinterpret_cast<double*>(a.status_out) + 2;
                 for (int k = 0; k < 4; ++k)
@@ -793,20 +821,29 @@ hipError_t launch_ledger_scan(const uint32_t* led_count, const int32_t* led_idx,
                               const float* led_ret, const float* led_obs, const uint64_t* tick, int64_t tiles, int rows,
                               int obs_words, const double* snapshots, int64_t stride, int T, float clip_obs, float eps,
                               float* tobs, int32_t* t_idx, int32_t* d_idx, int64_t cap, int32_t* counters, double* sums,
-                              bool counters_are_zero, uint32_t* ticket, void* status_out, hipStream_t s) {
+                              bool counters_are_zero, uint32_t* ticket, void* status_out, const float* fin_raw, float* fin_out,
+                              const double* fin_snap, int64_t fin_stride, int64_t fin_n, float fin_clip, float fin_eps, hipStream_t s) {
     // zeroed by a kernel — this one, unless the rollout's fpv_rollout_begin has done it — never by hipMemsetAsync: a memset node
     // in a captured graph may write garbage from the graph's second replay on (profiles/r03_graph_memset_probe.json)
     if (!counters_are_zero)
         hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<uint32_t*>(counters), (int64_t)4,
                            reinterpret_cast<uint32_t*>(sums), (int64_t)4);
     LedgerScanArgs a{led_count, led_idx, led_info, led_tag, led_ret, led_obs, tick, snapshots, tiles, stride, cap,
-                     rows, T, obs_words, 0, clip_obs, eps, tobs, t_idx, d_idx, counters, sums, ticket, status_out};
+                     rows, T, obs_words, 0, clip_obs, eps, tobs, t_idx, d_idx, counters, sums, ticket, status_out,
+                     fin_raw, fin_out, fin_snap, fin_n, fin_stride, fin_clip, fin_eps, 0};
     const int64_t slots = tiles * rows, per_block = 256 * kScanPerThread;
     if (slots >= (1ll << 31) || cap >= (1ll << 31) || T > 65535) return hipErrorInvalidValue;   // (the step rides in 16 bits of a list entry)
     const size_t table_bytes = (size_t)T * (size_t)obs_words * 16;
     a.table = snapshots && table_bytes <= 40 * 1024 ? 1 : 0;        // (longer rollouts: the normaliser is computed per entry; 16 KB of
                                                                     // the 64 KB a workgroup gets without asking are the waves' lists)
-    hipLaunchKernelGGL(ledger_scan_kernel, dim3((unsigned)((slots + per_block - 1) / per_block)), dim3(256),
+    a.scan_blocks = (int32_t)((slots + per_block - 1) / per_block);
+    int64_t fin_blocks = 0;
+    if (fin_raw) {                                   // ~8 KB of rewards per workgroup and step, at most 1 024 workgroups
+        fin_blocks = (fin_n + 2047) / 2048;
+        if (fin_blocks > 1024) fin_blocks = 1024;
+        if (fin_blocks < 1) fin_blocks = 1;
+    }
+    hipLaunchKernelGGL(ledger_scan_kernel, dim3((unsigned)(a.scan_blocks + fin_blocks)), dim3(256),
                        a.table ? table_bytes : 0, s, a);
     return hipGetLastError();
 }

@@ -782,7 +782,9 @@ __global__ __launch_bounds__(512) void rollout_step_split_kernel(RollStepSplitAr
         split_stage_image<512>(p.image, net, lds_raw);
         __syncthreads();
         if (net == 0) RSS_STAMP(1);
-        const f32x4 r = split_net_row(net, lds_raw, head, nrm, clip, p.st.obs, d, d < p.st.n, lane, out, nullptr, tick, false, p.pol_seed,
+        SplitOut o = out;
+        if (net) o.obs_n = nullptr;                    // (the normalised row is written once, by the first pass)
+        const f32x4 r = split_net_row(net, lds_raw, head, nrm, clip, p.st.obs, d, d < p.st.n, lane, o, nullptr, tick, false, p.pol_seed,
                                       p.pol_id_offset);
         if (net == 0) cl = r;
     }

@@ -142,17 +142,33 @@ def rank_merge(gathered, obs_words, *, base_obs_rms=None, base_ret_rms=None, obs
                                     _ptr(base_ret_rms), _ptr(obs_rms), _ptr(ret_rms), _stream(gathered.device)), "fpv_rank_merge")
 
 
-def ledger_scan(engine, T, *, snapshots, clip_obs, eps, tobs, t_idx, d_idx, counters, sums, prezeroed=False, status_out=None):
+def ledger_scan(engine, T, *, snapshots, clip_obs, eps, tobs, t_idx, d_idx, counters, sums, prezeroed=False, status_out=None,
+                finalize=None):
     """fpv_ledger_scan on the engine's done ledger: episode statistics + the dense list of truncated-not-terminated
     episode ends of the last T agent steps (see include/fpv_env.h).  No host synchronisation.
     prezeroed: counters / sums were zeroed by this rollout's engine.rollout_begin(scan_counters=, scan_sums=).
     status_out: >= 32 bytes that receive {counters[4], sums[2]} at the end of the launch — a device tensor or a PINNED host tensor
-    (the kernel writes it directly; no copy is queued)."""
+    (the kernel writes it directly; no copy is queued).
+    finalize = {raw [T, n] f32, snapshots [T, >= 43] f64, clip, eps, out [T, n] f32}: reward_finalize(...) in the same launch
+    (fpv_ledger_scan_finalize)."""
     if status_out is not None:
         if status_out.numel() * status_out.element_size() < 32 or not status_out.is_contiguous() or status_out.data_ptr() % 8:
             raise ValueError("status_out: >= 32 contiguous bytes, 8-byte aligned")
         if not status_out.is_cuda and not status_out.is_pinned():
             raise ValueError("status_out on the host must be pinned memory (the device writes it)")
+    if finalize is not None:
+        raw, fs, out = finalize["raw"], finalize["snapshots"], finalize["out"]
+        _need(raw, torch.float32, "raw")
+        _need(fs, torch.float64, "snapshots")
+        _need(out, torch.float32, "out")
+        if raw.shape != (int(T), engine.num_envs) or out.shape != raw.shape or fs.shape[0] < int(T) or fs.shape[1] < 43:
+            raise ValueError("finalize: raw / out are [T, num_envs], snapshots [T, >= 43]")
+        L.check(L.load().fpv_ledger_scan_finalize(engine._h, _ptr(snapshots), snapshots.shape[1] if snapshots is not None else 0, int(T),
+                                                  float(clip_obs), float(eps), _ptr(tobs), _ptr(t_idx), _ptr(d_idx), tobs.shape[0],
+                                                  _ptr(counters), _ptr(sums), 1 if prezeroed else 0, _ptr(status_out), _ptr(raw),
+                                                  _ptr(fs), fs.shape[1], float(finalize["clip"]), float(finalize["eps"]), _ptr(out),
+                                                  _stream(tobs.device)), "fpv_ledger_scan_finalize")
+        return
     L.check(L.load().fpv_ledger_scan(engine._h, _ptr(snapshots), snapshots.shape[1] if snapshots is not None else 0, int(T),
                                      float(clip_obs), float(eps), _ptr(tobs), _ptr(t_idx), _ptr(d_idx), tobs.shape[0],
                                      _ptr(counters), _ptr(sums), 1 if prezeroed else 0, _ptr(status_out), _stream(tobs.device)),

@@ -107,7 +107,7 @@ class RolloutCollector:
     def __init__(self, engine: FpvEngine, policy: ActorCritic, n_steps: int = 32, gamma: float = 0.99,
                  lam: float = 0.95, norm_obs: bool = True, norm_reward: bool = True, use_graph: bool = True,
                  clip_obs: float = 10.0, clip_reward: float = 10.0, fused: bool = True, policy_seed: int = 0,
-                 policy_gemm: str = "f32", overlap_critic: bool = False, merge_in_policy: bool = True,
+                 policy_gemm: str | None = None, overlap_critic: bool = False, merge_in_policy: bool = True,
                  fused_step: bool = True, merge_in_step: bool = False, one_launch: bool | None = None,
                  persistent: bool | None = None):
         self._f64_env = engine.dtype == torch.float64
@@ -158,6 +158,13 @@ class RolloutCollector:
             self._clip64 = torch.zeros((N, A), dtype=torch.float64, device=dev)
             self.env_obs = torch.zeros((T, N, O), dtype=torch.float64, device=dev)   # raw fp64 env outputs of the rollout, step by step
             self.env_rew = torch.zeros((T, N), dtype=torch.float64, device=dev)
+        # policy_gemm=None, the default (round 5): the hidden 128 x 128 products of pi and V as 6-term bf16 splits with
+        # fp32 accumulation ("bf16x6": every row at fp32 rounding level against an fp64 evaluation, tests/test_policy_gpu.py) wherever
+        # that kernel exists — the hover task's widths on the fused path; "f32" (exact fp32-input MFMA) stays selectable and is what the
+        # experiment shapes (persistent, overlap_critic) and the other widths run on
+        if policy_gemm is None:
+            policy_gemm = "bf16x6" if (fused and fused_policy and (O, A) == (20, 4) and not persistent and not overlap_critic) else "f32"
+        self.policy_gemm = policy_gemm
         self.fused = bool(fused)
         self._one_launch = self._one_launch_ok = False
         self._persistent = self._persistent_ok = False
@@ -246,6 +253,7 @@ class RolloutCollector:
         self._stats_done = [torch.cuda.Event() for _ in range(2)]
         self._done_stream = [None, None]                 # the stream each _stats_done was last recorded on
         self._capture_mode = None                        # None: "global" with one rank, "thread_local" with several (_capture)
+        self.capture_mode_used = None                    # the mode the captured graphs were taken in (None: eager launches so far)
         self._stats_last = 0
         # several ranks: VecNormalize's statistics ride in the same payload ({adv stats[3], obs_rms[2 O + 1], ret_rms[3]}); every
         # rank starts a rollout from the statistics of the union of all ranks' samples so far (fpv_rank_merge) — kept here as the base
@@ -471,15 +479,19 @@ class RolloutCollector:
                             clip_obs=self.obs_norm.clip, eps_norm=self.obs_norm.eps, merge=merge)
         # (V(s_T) beside the chain below on a second captured stream was measured: 70.7 vs 69.3 us per step with one 20-step
         # rollout per timed region — each fork / join edge of the graph costs 4-12 us, more than the overlap returns)
+        # the deferred reward scaling rides in the ledger scan's launch (fpv_ledger_scan_finalize: the two are independent of each
+        # other and of V(s_T); as launches of their own they stood one behind the other on the tail)
+        fin = None
         if self.fused:
             if self.norm_reward:
-                ops.reward_finalize(self.raw_rew, self.snap, clip=self.rew_norm.clip, eps=self.rew_norm.eps, out=self.buf_rew)
+                fin = {"raw": self.raw_rew, "snapshots": self.snap, "clip": self.rew_norm.clip, "eps": self.rew_norm.eps, "out": self.buf_rew}
             else:
                 self.buf_rew.copy_(self.raw_rew)
         ops.ledger_scan(eng, self.T, snapshots=self.snap if self.norm_obs else None, clip_obs=self.obs_norm.clip,
                         eps=self.obs_norm.eps, tobs=self._tobs, t_idx=self._t_idx, d_idx=self._d_idx,
                         counters=self._led_counters, sums=self._led_sums, prezeroed=self._scan_prezeroed,
-                        status_out=None if self._persistent else self._status_host[self._slot])   # straight into pinned host memory
+                        status_out=None if self._persistent else self._status_host[self._slot],   # straight into pinned host memory
+                        finalize=fin)
         # V(terminal observations) and r_t += gamma * V in one launch (fpv_policy_io.scatter_*; ops.ledger_scatter is that as a launch)
         self.fp.forward(self._tobs, value=self._tv, deterministic=True, nets="v", n_dev=self._led_counters[0:1],
                         scatter={"t_idx": self._t_idx, "d_idx": self._d_idx, "out": self.buf_rew, "scale": self.gamma})
@@ -555,29 +567,47 @@ class RolloutCollector:
         # several ranks: the collective library's watchdog thread polls events while this thread captures; thread-local capture
         # mode keeps another thread's calls from invalidating the capture (nothing collective is captured here)
         mode = self._capture_mode or os.environ.get("FPV_CAPTURE_MODE") or ("thread_local" if multi else "global")
-        try:
-            self._graphs = capture_both(mode)
-        except Exception as first:
-            # A capture can be invalidated by a runtime call that has nothing to do with the rollout — seen on this stack when a
-            # collector is captured right after others were dropped (the allocators' event bookkeeping; it goes away under
-            # call logging, and "relaxed" mode passes).  Nothing has executed: a capture only records.  So: drain the device and
-            # capture once more, in relaxed mode; only if that fails too, give up (one rank) or go on with eager launches (several
-            # ranks: the rollout has no collective inside the graph, so ranks need not agree on this).  The process keeps running
-            # either way — never re-exec.
-            self._graphs = [None, None]
+        # A capture in global mode is invalidated by ANY implicitly synchronising runtime call of the process while it is open —
+        # hipFree / hipHostFree / hipGraphExecDestroy, an event query of an allocator — whichever object makes it.  The occurrence on
+        # record (round 4) came when a collector was captured right after others had been dropped: their finalisers (pinned status
+        # words, captured graphs, cached blocks with pending stream-use events) are exactly such calls, and they run whenever the
+        # garbage collector decides to — inside the capture window if it so happens.  So the window is fenced: collect the garbage
+        # NOW, drain the device, hand the allocator's cached blocks back (its event bookkeeping ends with them), and keep the
+        # collector off until the capture has ended.  If a capture still fails it is taken again IN THE SAME MODE on a fresh private
+        # stream (nothing has executed: a capture only records); relaxed mode — which would also let a genuinely unsafe call of ours
+        # through — is the last resort and is reported (capture_mode_used, bench.py prints it); then eager launches (several ranks)
+        # or the error (one rank).  The process keeps running either way — never re-exec.
+        import gc
+
+        def fenced(m):
+            gc.collect()
             torch.cuda.synchronize(self.device)
-            print(f"fpv rollout (rank {D.rank()}): HIP-graph capture failed in {mode!r} mode ({first!r}); capturing again in 'relaxed' mode",
-                  file=sys.stderr, flush=True)
+            torch.cuda.empty_cache()
+            was = gc.isenabled()
+            gc.disable()
             try:
-                self._graphs = capture_both("relaxed")
-            except Exception as second:
+                return capture_both(m)
+            finally:
+                if was:
+                    gc.enable()
+
+        self.capture_mode_used, errors = None, []
+        for attempt in (mode, mode, "relaxed"):
+            try:
+                self._graphs = fenced(attempt)
+                self.capture_mode_used = attempt
+                break
+            except Exception as exc:
+                errors.append(exc)
                 self._graphs = [None, None]
                 torch.cuda.synchronize(self.device)
-                if not multi:
-                    raise second from first
-                self.use_graph = False
-                print(f"fpv rollout (rank {D.rank()}): the second capture failed too ({second!r}); collecting with eager launches",
-                      file=sys.stderr, flush=True)
+                print(f"fpv rollout (rank {D.rank()}): HIP-graph capture failed in {attempt!r} mode ({exc!r})" +
+                      ("; capturing again" if len(errors) < 3 else ""), file=sys.stderr, flush=True)
+        if self.capture_mode_used is None:
+            if not multi:
+                raise errors[-1] from errors[0]
+            self.use_graph = False
+            print(f"fpv rollout (rank {D.rank()}): no capture succeeded; collecting with eager launches", file=sys.stderr, flush=True)
         self._slot = keep
 
     def set_policy_gemm(self, gemm: str) -> None:
@@ -585,6 +615,7 @@ class RolloutCollector:
         if not self.fused:
             raise ValueError("policy_gemm applies to the fused path")
         self.fp.set_gemm(gemm)
+        self.policy_gemm = gemm
         self._one_launch = self._one_launch_ok and gemm in self._one_launch_gemms   # fpv_rollout_step: exact fp32, and the split for hover
         self._persistent = self._persistent_ok and gemm == "f32"
         self.overlap_critic = self._vstream is not None and gemm == "f32"

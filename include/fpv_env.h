@@ -31,7 +31,7 @@ extern "C" {
  * (FPV_DETECTOR_PIXEL = 0 is the default, debug hooks moved to fpv_env_debug.h); 3 = fpv_ledger_scan(status_out),
  * fpv_policy_io.scatter_*, the whole-rollout launch moved to fpv_env_experiments.h; 4 = round 4: fpv_ppo_io.reserved1 became
  * fpv_ppo_io.path (same layout; 0 now selects the one-kernel gradient), fpv_ppo_workspace_bytes covers every path; 5 = round 5:
- * fpv_ledger_pack added (no layout changed). */
+ * fpv_ledger_pack and fpv_ledger_scan_finalize added (no layout changed). */
 #define FPV_ABI_VERSION 5
 
 #define FPV_STATE_WORDS 36 /* docs/SPEC.md §2 canonical order */
@@ -287,6 +287,15 @@ int fpv_rank_merge(const double* gathered, int32_t world, int32_t stride, int32_
 int fpv_ledger_scan(fpv_env* env, const double* snapshots, int64_t snapshot_stride, int32_t T, float clip_obs, float eps_norm,
                     float* tobs, int32_t* t_idx, int32_t* d_idx, int64_t cap, int32_t* counters, double* sums,
                     int32_t counters_are_zero, void* status_out, void* stream);
+/* fpv_ledger_scan and fpv_reward_finalize(T, num_envs, raw, reward_snapshots, clip_reward, eps_reward, rewards) as ONE launch: the
+ * scan's workgroups walk the ledger, further workgroups of the same grid scale the rollout's rewards (rewards[t][i] =
+ * clip(raw[t][i] / sqrt(var_t + eps_reward)), var_t = reward_snapshots[t][42]; raw / rewards [T][num_envs], rewards may alias raw).
+ * The two are independent of each other and of V(s_T); as two launches the scaling stood in front of the scan on the rollout's
+ * tail (SB3 collect_rollouts' end).  Same bits as the two calls. */
+int fpv_ledger_scan_finalize(fpv_env* env, const double* snapshots, int64_t snapshot_stride, int32_t T, float clip_obs, float eps_norm,
+                             float* tobs, int32_t* t_idx, int32_t* d_idx, int64_t cap, int32_t* counters, double* sums,
+                             int32_t counters_are_zero, void* status_out, const float* raw, const double* reward_snapshots,
+                             int64_t reward_snapshot_stride, float clip_reward, float eps_reward, float* rewards, void* stream);
 int fpv_ledger_scatter(const int32_t* counters, const int32_t* t_idx, const int32_t* d_idx, const float* values, float gamma,
                        float* rewards, int64_t n, int64_t cap, void* stream);
 

@@ -82,21 +82,11 @@ def test_fp32_step_features_match_oracle_up_to_one_pixel_flips(oracle):
     bad = (diff > 1e-5).any(axis=1) & ~done
     assert (obs_r[:, 13] == 1).sum() > n // 4
     frac = bad.mean()
-    # the measured rate goes on record (gpurun_out/ is scratch; the copy under profiles/ is the committed one)
-    import json, os
-    seen = (obs_r[:, 13] == 1) & ~done
-    rec = {"drones": n, "see_the_panel": int(seen.sum()), "rows_with_a_feature_difference": int(bad.sum()),
-           "fraction_of_all_drones": float(frac), "fraction_of_drones_that_see_the_panel": float(bad.sum() / max(1, seen.sum())),
-           "visibility_flips": int((bad & (obs[:, 13] != obs_r[:, 13])).sum()),
-           "what": "fp32 HIP env step (detector=pixel) vs the fp64 oracle from identical fp32 states, one step, motor noise on; a row "
-                   "counts when any of obs[7,8,11,13,14] differs by more than 1e-5"}
-    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-    os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "pixel_flip_rate.json"), "w") as f:
-        json.dump(rec, f, indent=1)
-    print("pixel detector fp32 flip rate:", rec)
+    # (the measured rate is on record in profiles/r05_flip_rates.json, written by tools/flip_rates.py — not by this test)
+    visibility_flips = int((bad & (obs[:, 13] != obs_r[:, 13])).sum())
+    print("pixel detector fp32 flip rate:", int(bad.sum()), "of", n, "rows, visibility flips:", visibility_flips)
     assert frac < 0.001, frac                                      # one-pixel rasterisation flips: measured 8 of 65 536 (1.2e-4); 8 x that
-    assert rec["visibility_flips"] == 0                            # ... and none of them changes the visibility decision here
+    assert visibility_flips == 0                                   # ... and none of them changes the visibility decision here
     # ... and small: a visibility flip, or one pixel of w / h, a few px^2 of contour, one pixel of one vertex
     same_vis = bad & (obs[:, 13] == obs_r[:, 13])
     if same_vis.any():
@@ -161,5 +151,7 @@ def test_fp32_contours_equal_the_oracle_on_adversarial_poses(oracle, n):
     feat = [7, 8, 11, 13, 14]
     bad = (np.abs(fin[:, feat] - fin_r[:, feat]) > 1e-6).any(axis=1)
     assert 0.25 * n < (fin_r[:, 13] == 1).sum() < 0.75 * n
-    assert bad.sum() <= 0.004 * n, (int(bad.sum()), n)             # far-away blobs sit on fewer pixels: more of them flip than in a
-    eng.close()                                                    # hovering population (profiles/*pixel_flip_rate.json)
+    # far-away blobs sit on fewer pixels: more of them flip than in a hovering population — measured 4 of 16 384 (2.4e-4,
+    # profiles/r05_flip_rates.json one_step_adversarial); the bound is 4 x that, and two rows at least
+    assert bad.sum() <= max(2, int(0.001 * n)), (int(bad.sum()), n)
+    eng.close()

@@ -290,6 +290,27 @@ def test_ledger_scan_and_scatter_match_a_torch_restatement(oracle):
     with pytest.raises(ValueError, match="pinned"):
         ops.ledger_scan(eng, T, snapshots=snap, clip_obs=10.0, eps=1e-8, tobs=tobs, t_idx=t_idx, d_idx=d_idx, counters=counters,
                         sums=sums, status_out=torch.zeros(4, dtype=torch.float64))
+    # fpv_ledger_scan_finalize: the same scan with the rollout's deferred reward scaling in the same launch (what the collector's tail
+    # calls) — the counters, the list as a set, the status words and the scaled rewards of fpv_ledger_scan + fpv_reward_finalize
+    raw = torch.randn((T, n), device="cuda") * 3
+    snap[:, 42] = torch.rand(T, dtype=torch.float64, device="cuda") * 0.05 + 0.01          # return variances: some rewards reach the clip
+    want_rew = ops.reward_finalize(raw, snap, clip=10.0, eps=1e-8)
+    c2 = torch.full((4,), 9, dtype=torch.int32, device="cuda"); s2 = torch.full((2,), 1.0, dtype=torch.float64, device="cuda")
+    tobs2, t2, d2 = torch.zeros_like(tobs), torch.zeros_like(t_idx), torch.zeros_like(d_idx)
+    got_rew = torch.zeros_like(raw)
+    host2 = torch.full((4,), -1.0, dtype=torch.float64).pin_memory()
+    ops.ledger_scan(eng, T, snapshots=snap, clip_obs=10.0, eps=1e-8, tobs=tobs2, t_idx=t2, d_idx=d2, counters=c2, sums=s2, status_out=host2,
+                    finalize={"raw": raw, "snapshots": snap, "clip": 10.0, "eps": 1e-8, "out": got_rew})
+    torch.cuda.synchronize()
+    assert torch.equal(got_rew, want_rew) and float(got_rew.abs().max()) == 10.0
+    assert torch.equal(c2, counters) and torch.equal(host2[:2], host[:2]) and host2[2:4].tolist() == s2.tolist()
+    assert abs(float(s2[0] - sums[0])) <= 1e-9 * abs(float(sums[0])) and s2[1] == sums[1]       # (atomic adds: the order may differ)
+    kk = int(counters[0])
+    key = lambda t_, d_: set(zip(t_[:kk].tolist(), d_[:kk].tolist()))
+    assert key(t2, d2) == key(t_idx, d_idx)
+    o1 = {(int(a_), int(b_)): r_ for a_, b_, r_ in zip(t_idx[:kk].tolist(), d_idx[:kk].tolist(), tobs[:kk].cpu().numpy())}
+    for a_, b_, r_ in zip(t2[:kk].tolist(), d2[:kk].tolist(), tobs2[:kk].cpu().numpy()):
+        assert np.array_equal(o1[(a_, b_)], r_)
     fp.forward(tobs, value=tv, deterministic=True, nets="v", n_dev=counters[0:1])
     rew = torch.zeros((T, n), device="cuda")
     ops.ledger_scatter(counters, t_idx, d_idx, tv, gamma, rew)

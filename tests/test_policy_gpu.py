@@ -170,8 +170,13 @@ def test_policy_kernel_repeated_launches_every_row(gemm):
 
 
 @pytest.mark.parametrize("narrow", [False, pytest.param(True, marks=pytest.mark.experiments)])
-def test_single_net_launches_match_the_joint_launch(narrow):
-    m, fp = _setup(9)
+@pytest.mark.parametrize("gemm", ["f32", "bf16x6"])
+def test_single_net_launches_match_the_joint_launch(narrow, gemm):
+    """nets = "pi" / "v" (the rollout tail's V(s_T) is a V-only launch) against the joint launch, bit for bit, on both arithmetics:
+    the split kernel runs the same instructions on a row whichever nets the launch evaluates."""
+    if narrow and gemm != "f32":
+        pytest.skip("narrow launches exist for the exact-fp32 kernel")
+    m, fp = _setup(9, gemm)
     n = 7777
     g = torch.Generator(device="cuda").manual_seed(1)
     obs = torch.randn(n, 20, device="cuda", generator=g)
@@ -216,3 +221,48 @@ def test_w16_kernel_matches_the_two_wave_kernel_on_the_rollout_launch(n):
         assert float((va - vb).abs().max()) <= 4e-6 * max(1.0, float(va.abs().max())), trial
         assert torch.allclose(la, lb, atol=1e-5, rtol=1e-6)
         assert torch.equal(b["clipped"], b["action"].clamp(-1, 1))
+
+
+def test_default_rollout_arithmetic_every_row_against_fp64():
+    """The arithmetic the collector runs by default since round 5 — the 128-wide products of pi and V as 6-term bf16 splits with
+    fp32 accumulation, inside the one-kernel rollout step (rollout_step_split_kernel) — on the rollout's own rows: EVERY value and
+    EVERY log-probability of 8 x 65 536 transitions against an fp64 evaluation of the module on the stored (normalised)
+    observations and actions; the exact fp32-input MFMA path through the same check for scale.  (SB3's policy is a torch fp32
+    module, simulation/train_hover.py:57: fp32 rounding level is the bar, and it is the bar for every row, not for an average.)"""
+    import copy
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    from fpv_drone_rl_agent_amd.rollout import RolloutCollector
+    from fpv_drone_rl_agent_amd.synthetic import synthetic_states
+    n, T = 65536, 8
+    worst = {}
+    for gemm in (None, "f32"):
+        torch.manual_seed(13)
+        m = ActorCritic().cuda()
+        with torch.no_grad():
+            for p in m.parameters():
+                if p.dim() == 1:
+                    p.add_(torch.randn_like(p) * 0.3)
+        m64 = copy.deepcopy(m).double()
+        eng = FpvEngine(n, 0, seed=3, ledger_capacity=4 * n)
+        col = RolloutCollector(eng, m, n_steps=T, policy_seed=5, policy_gemm=gemm)
+        assert col.policy_gemm == ("bf16x6" if gemm is None else "f32") and col._one_launch
+        col.start()
+        eng.set_state(torch.from_numpy(synthetic_states(n, 2)).float())
+        col.collect()
+        b = col.collect()
+        torch.cuda.synchronize()
+        obs, act = b["obs"].reshape(-1, 20).double(), b["actions"].reshape(-1, 4).double()
+        with torch.no_grad():
+            mu64, v64 = m64.mean_value(obs)
+            ls = m64.log_std
+            lp64 = (-0.5 * ((act - mu64) / ls.exp()) ** 2).sum(1) - ls.sum() - 0.5 * 4 * math.log(2 * math.pi)
+        ev = (b["values"].reshape(-1).double() - v64).abs()
+        el = (b["log_probs"].reshape(-1).double() - lp64).abs()
+        sv, sl = max(1.0, float(v64.abs().max())), max(1.0, float(lp64.abs().max()))
+        worst[col.policy_gemm] = (float(ev.max()) / sv, float(el.max()) / sl)
+        assert float(ev.max()) <= 4e-6 * sv, (col.policy_gemm, float(ev.max()), sv)
+        assert float(el.max()) <= 1e-5 * sl, (col.policy_gemm, float(el.max()), sl)
+        eng.close()
+    print("worst relative error (value, log-prob):", worst)
+    assert worst["bf16x6"][0] <= 3 * worst["f32"][0] + 1e-6 and worst["bf16x6"][1] <= 3 * worst["f32"][1] + 1e-6, worst

@@ -126,8 +126,8 @@ def test_default_collector_takes_the_one_launch_path_where_served():
     assert RolloutCollector(FpvEngine(4096, 0), _policy(), n_steps=4)._one_launch
     assert not RolloutCollector(FpvEngine(4000, 0), _policy(), n_steps=4)._one_launch            # not a multiple of 256
     assert not RolloutCollector(FpvEngine(4096, 0, noise_ratio=0.0), _policy(), n_steps=4)._one_launch
-    c = RolloutCollector(FpvEngine(4096, 0), _policy(), n_steps=4, policy_gemm="bf16x6")        # hover: rollout_step_split_kernel
-    assert c._one_launch
+    c = RolloutCollector(FpvEngine(4096, 0), _policy(), n_steps=4)        # hover: the 6-term bf16 split is the default arithmetic
+    assert c._one_launch and c.policy_gemm == "bf16x6" and c.fp.gemm == "bf16x6"          # (rollout_step_split_kernel)
     c.set_policy_gemm("f32"); assert c._one_launch
     from fpv_drone_rl_agent_amd import _lib as L
     if not L.experiments():                               # the alternatives that lost are not in the product library
@@ -175,7 +175,9 @@ def test_persistent_rollout_equals_step_by_step(oracle, n, T):
             eng = FpvEngine(n, 0, seed=2, detector="analytic")   # (the persistent launch serves the analytic detector only)
             # eager launches: graph capture runs a warm-up outside the capture (one step, or one whole rollout in the persistent
             # shape), which would leave the two collectors a different number of steps into their episodes
-            cols.append(RolloutCollector(eng, _policy(4), n_steps=T, policy_seed=9, persistent=pers, one_launch=True, use_graph=False))
+            # (the persistent launch exists on the exact fp32-input MFMA only: the per-step collector is asked for the same arithmetic)
+            cols.append(RolloutCollector(eng, _policy(4), n_steps=T, policy_seed=9, persistent=pers, one_launch=True, use_graph=False,
+                                         policy_gemm="f32"))
             cols[-1].start()
             _synthetic(eng, oracle, 6)
         assert cols[0]._persistent and not cols[1]._persistent
@@ -447,8 +449,9 @@ def test_one_kernel_step_policy_half_keeps_fp32_accuracy_over_repeated_launches(
 
 def test_an_invalidated_capture_is_taken_again_and_changes_nothing():
     """RolloutCollector._capture: a capture that a stray runtime call invalidates (here: a device synchronisation smuggled into the
-    first captured rollout) is repeated once in relaxed mode after draining the device — nothing has executed, a capture only
-    records — and the collector then returns the very batches of a collector whose capture went through at once."""
+    first captured rollout) is taken again IN THE SAME MODE on a fresh private stream after draining the device — nothing has
+    executed, a capture only records — and the collector then returns the very batches of a collector whose capture went through
+    at once.  Relaxed mode is the last resort only: a stray call on every attempt in the stricter mode ends there, and says so."""
     from fpv_drone_rl_agent_amd.engine import FpvEngine
     from fpv_drone_rl_agent_amd.policy import ActorCritic
     from fpv_drone_rl_agent_amd.rollout import RolloutCollector
@@ -471,6 +474,7 @@ def test_an_invalidated_capture_is_taken_again_and_changes_nothing():
         b = [col.collect() for _ in range(3)]
         torch.cuda.synchronize()
         assert col.use_graph and all(g is not None for g in col._graphs)
+        assert col.capture_mode_used == "global"               # one rank: never relaxed when the same mode succeeds
         if sabotage:
             assert state["calls"] >= 3                         # the spoiled attempt, then both slots again
         outs.append({k: b[-1][k].clone() for k in ("obs", "actions", "values", "advantages", "returns")} | {"rms": col.obs_norm.rms.clone()})
