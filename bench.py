@@ -240,7 +240,8 @@ def main() -> None:
     ap.add_argument("--detector", choices=["analytic", "pixel"], default="pixel",
                     help="hover task camera features: the reference's 128x128 pixel rules (SPEC §6b, hover.py:157-222; the default and "
                          "the headline) or the continuous projection (§6)")
-    ap.add_argument("--no-f64-rollout", action="store_true", help="skip the extra rollout measurement on an fp64 engine (the reference's arithmetic type)")
+    ap.add_argument("--no-f64-rollout", action="store_true",
+                    help="skip the extra rollout measurement on an fp64 engine (the reference's arithmetic type); runs with --steps >= 256 only")
     ap.add_argument("--two-launch", action="store_true",
                     help="policy forward and env step as two kernels per rollout step (the default is fpv_rollout_step: one)")
     args = ap.parse_args()
@@ -346,7 +347,7 @@ def main() -> None:
     # simulation/hover.py:61, :70): fp32 policy kernel + fpv_step_f64 + stand-alone normaliser kernels, no graph, host-synchronising
     # timeout bootstrap (rollout.py).  A few rollouts only: it exists to be right, not to be fast. ----
     f64_rollout_value = None
-    if not yaw and not args.no_f64_rollout:
+    if not yaw and not args.no_f64_rollout and K >= 256:       # (a short driver-shaped run, --steps 20, skips it: four host-synchronising fp64 rollouts)
         eng64 = FpvEngine(n, dev, noise_ratio=0.02, seed=0, id_offset=rank * n, ledger_capacity=n * max(2, T // 8), detector=args.detector,
                           precision="f64")
         col64 = RolloutCollector(eng64, policy, n_steps=T)

@@ -25,6 +25,7 @@
 //   per tile: corner block [4][64] Vec4<T> (u, v, edge slopes, {jlo, jhi, -, -} of every drone; jlo > jhi: nothing to do) and
 //   results [64] int4 ({visible | w << 8 | h << 16, sum x | sum y << 16, 2 x contourArea, -});
 //   cv2.arcLength's float32 length of a run of k = 0 .. 127 diagonal steps in units of 2^-23 (128 words);
+//   the census: per tile the numbers of its blobs of more than 0 / 16 / 20 / 24 / 28 / 36 rows (two words), then the octet count;
 //   the schedule: one u16 per octet (drone | second half << 8 | 16 lanes << 9);
 //   per octet of lanes: span table (a | b << 8 per row, 0x00FF = no red pixel, framed by two empty rows) and contour list; a
 //   16-lane group uses the space of its two octets.
@@ -45,9 +46,10 @@ struct PixPool {
     static constexpr int kTileWords = 4 * kTile * 4 * (int)(sizeof(T) / 4) + kTile * 4;       // corner block + results
     static constexpr int kRes = 4 * kTile * 4 * (int)(sizeof(T) / 4);                         // (inside a tile's block)
     static constexpr int kRun = TILES * kTileWords;
-    static constexpr int kSched = kRun + 128;
+    static constexpr int kCensus = kRun + 128;                                                // per tile 2 words of counts, then {octets, -}
+    static constexpr int kSched = kCensus + 2 * TILES + 2;
     static constexpr int kSchedWords = TILES * kTile;                                         // 2 octets per drone at most, u16 each
-    static constexpr int kOct = kSched + kSchedWords;
+    static constexpr int kOct = kSched + kSchedWords + 1;                                     // (+ a spare entry for lanes with nothing to enter)
     static constexpr int kTabWords = 34, kListWords = 4 * kPolyPoints;                        // per octet: 68 u16 of table, 8 kPolyPoints of list
     static constexpr int kOctWords = kTabWords + kListWords;
     static constexpr int kWords = (kOct + 8 * WAVES * kOctWords + 7) / 8 * 8;
@@ -116,9 +118,10 @@ struct DppGroup {
 
 // Owner lanes (one per drone): corners, slopes and row range of this lane's drone into its tile's corner block; a blob that
 // touches the border, lies behind the camera, beside the image or between two rows of pixel centres gets the empty range (1, 0).
-// The owners of tile 0 also write the pool's run-length table.
+// The owners of tile 0 also write the pool's run-length table.  Returns the number of rows of the lane's blob (<= 0: none) and
+// publishes the tile's census (pixel_tile_schedule below).
 template <typename T, int TILES, int WAVES>
-__device__ __forceinline__ void pixel_tile_setup(const Drone<T>& d, float* pool, int tile, int lane) {
+__device__ __forceinline__ int pixel_tile_setup(const Drone<T>& d, float* pool, int tile, int lane) {
     using P = PixPool<T, TILES, WAVES>;
     T u[4], v[4], sl[4], jlo, jhi;
     pixel_setup(d, u, v, sl, jlo, jhi);
@@ -133,58 +136,91 @@ __device__ __forceinline__ void pixel_tile_setup(const Drone<T>& d, float* pool,
         run[lane] = poly_run_length_q23(lane);
         run[kTile + lane] = poly_run_length_q23(kTile + lane);
     }
+    const int rows = (int)jhi - (int)jlo + 1;
+    if (WAVES > 1) {
+        const uint32_t c0 = (uint32_t)__popcll(__ballot(rows > 0)) | (uint32_t)__popcll(__ballot(rows > 16)) << 8 |
+                            (uint32_t)__popcll(__ballot(rows > 20)) << 16 | (uint32_t)__popcll(__ballot(rows > 24)) << 24;
+        const uint32_t c1 = (uint32_t)__popcll(__ballot(rows > 28)) | (uint32_t)__popcll(__ballot(rows > 36)) << 8;
+        if (lane == 0) {
+            uint32_t* cen = reinterpret_cast<uint32_t*>(pool + P::kCensus);
+            cen[2 * tile] = c0;
+            cen[2 * tile + 1] = c1;
+        }
+    }
+    return rows;
+}
+
+// Owner lanes of a pool of several waves, once every tile's census is in LDS (a workgroup barrier behind pixel_tile_setup): the
+// schedule entries of THIS tile's blobs.  Blobs of more than `big` rows get 16 lanes; `big` is the smallest of 16, 20, 24, 28 with
+// which one round serves every blob (8 WAVES octets), 36 when none does.  Octets: the tall blobs first, two each, tile by tile in
+// lane order; then the others.  Every owner wave derives the same bases from the same census; a lane with nothing to enter
+// writes the spare entry (no branch around the stores).  Round 4 had every wave of the pool derive the whole schedule for itself
+// behind barrier P — a microsecond of every wave's contour time for what 1/8 of it, on the owners, before the barrier, does.
+template <typename T, int TILES, int WAVES>
+__device__ __forceinline__ void pixel_tile_schedule(float* pool, int tile, int lane, int rows) {
+    using P = PixPool<T, TILES, WAVES>;
+    const uint32_t* cen = reinterpret_cast<const uint32_t*>(pool + P::kCensus);
+    int ncand = 0, n16 = 0, n20 = 0, n24 = 0, n28 = 0;
+    uint32_t c0[TILES], c1[TILES];
+#pragma unroll
+    for (int k = 0; k < TILES; ++k) {
+        c0[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)cen[2 * k]);
+        c1[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)cen[2 * k + 1]);
+        ncand += (int)(c0[k] & 255u); n16 += (int)((c0[k] >> 8) & 255u); n20 += (int)((c0[k] >> 16) & 255u);
+        n24 += (int)(c0[k] >> 24); n28 += (int)(c1[k] & 255u);
+    }
+    const int room = 8 * WAVES - ncand;                          // octets left for second halves
+    const int big = n16 <= room ? 16 : (n20 <= room ? 20 : (n24 <= room ? 24 : (n28 <= room ? 28 : 36)));
+    int nbig = 0, bb = 0, sb = 0;                                // all tall blobs; those / the others of the tiles before this one
+#pragma unroll
+    for (int k = 0; k < TILES; ++k) {
+        const int cand = (int)(c0[k] & 255u);
+        const int tall = (int)(big == 16 ? (c0[k] >> 8) & 255u : (big == 20 ? (c0[k] >> 16) & 255u : (big == 24 ? c0[k] >> 24 :
+                                                                 (big == 28 ? c1[k] & 255u : (c1[k] >> 8) & 255u))));
+        nbig += tall;
+        bb += k < tile ? tall : 0;
+        sb += k < tile ? cand - tall : 0;
+    }
+    const bool isb = rows > big, any = rows > 0;
+    const unsigned long long mb = __ballot(isb), ms = __ballot(any && !isb), below = (1ull << lane) - 1ull;
+    uint16_t* sched = reinterpret_cast<uint16_t*>(pool + P::kSched);
+    constexpr int kSpare = 2 * P::kSchedWords;                    // (one u16 behind the 2 TILES kTile entries a pool can need)
+    const uint32_t id = (uint32_t)(tile * kTile + lane);
+    const int o = isb ? 2 * (bb + __popcll(mb & below)) : 2 * nbig + sb + __popcll(ms & below);
+    sched[any ? o : kSpare] = (uint16_t)(id | (isb ? 1u << 9 : 0u));
+    sched[isb ? o + 1 : kSpare] = (uint16_t)(id | 1u << 8 | 1u << 9);
+    if (tile == 0 && lane == 0) reinterpret_cast<uint32_t*>(pool + P::kCensus)[2 * TILES] = (uint32_t)(ncand + nbig);   // octets
 }
 
 // Every lane of the pool's waves (wv = 0 .. WAVES - 1), once the corner blocks are complete: the blobs.
 template <typename T, int TILES, int WAVES>
 __device__ __forceinline__ void pixel_pool_contours(float* pool, int wv, int lane, uint64_t* probe = nullptr) {
     using P = PixPool<T, TILES, WAVES>;
-    // ---- the schedule, derived by every wave for itself (the waves write the same values to the same places).  Blobs of more
-    // than `big` rows get 16 lanes; `big` is the smallest of 16, 20, 24, 28, 36 with which one round serves every blob (8 WAVES
-    // octets), 36 when none does.  The six counts are summed over the wave as 10-bit fields of two words.
-    int rows[TILES], f0 = 0, f1 = 0;
-#pragma unroll
-    for (int k = 0; k < TILES; ++k) {
-        const Vec4<T> qr = reinterpret_cast<const Vec4<T>*>(pool + k * P::kTileWords)[3 * kTile + lane];
-        rows[k] = (int)qr.y - (int)qr.x + 1;
-        f0 += (rows[k] > 0 ? 1 : 0) + (rows[k] > 16 ? 1 << 10 : 0) + (rows[k] > 20 ? 1 << 20 : 0);
-        f1 += (rows[k] > 24 ? 1 : 0) + (rows[k] > 28 ? 1 << 10 : 0) + (rows[k] > 36 ? 1 << 20 : 0);
-    }
-    f0 = __builtin_amdgcn_readlane(wave_scan_inclusive(f0), 63);
-    f1 = __builtin_amdgcn_readlane(wave_scan_inclusive(f1), 63);
-    const int ncand = f0 & 1023, n16 = (f0 >> 10) & 1023, n20 = f0 >> 20, n24 = f1 & 1023, n28 = (f1 >> 10) & 1023;
-    const int room = 8 * WAVES - ncand;                          // octets left for second halves
-    const int big = n16 <= room ? 16 : (n20 <= room ? 20 : (n24 <= room ? 24 : (n28 <= room ? 28 : 36)));
-    int nbig = 0, nsmall = 0;
-    unsigned long long mbig[TILES], msmall[TILES];
-#pragma unroll
-    for (int k = 0; k < TILES; ++k) {
-        mbig[k] = __ballot(rows[k] > big);
-        msmall[k] = __ballot(rows[k] > 0 && rows[k] <= big);
-        nbig += __popcll(mbig[k]);
-        nsmall += __popcll(msmall[k]);
-    }
+    int octets;
     uint16_t* sched = reinterpret_cast<uint16_t*>(pool + P::kSched);
-    {
-        const unsigned long long below = (1ull << lane) - 1ull;
-        int bb = 0, sb = 2 * nbig;                               // first octet of tile k's big / small blobs
-#pragma unroll
-        for (int k = 0; k < TILES; ++k) {
-            const uint32_t id = (uint32_t)(k * kTile + lane);
-            if (rows[k] > big) {
-                const int o = bb + 2 * __popcll(mbig[k] & below);
-                sched[o] = (uint16_t)(id | 1u << 9);
-                sched[o + 1] = (uint16_t)(id | 1u << 8 | 1u << 9);
-            } else if (rows[k] > 0) {
-                sched[sb + __popcll(msmall[k] & below)] = (uint16_t)id;
-            }
-            bb += 2 * __popcll(mbig[k]);
-            sb += __popcll(msmall[k]);
-        }
+    if (WAVES > 1) {
+        // the owners wrote the schedule before the barrier in front of this call (pixel_tile_schedule)
+        octets = __builtin_amdgcn_readfirstlane((int)reinterpret_cast<const uint32_t*>(pool + P::kCensus)[2 * TILES]);
+    } else {
+        // ---- one wave, its own tile: the schedule derived on the spot (the wave's ballots ARE the census)
+        static_assert(WAVES > 1 || TILES == 1, "a pool of one wave holds one tile");
+        const Vec4<T> qr = reinterpret_cast<const Vec4<T>*>(pool)[3 * kTile + lane];
+        const int rows = (int)qr.y - (int)qr.x + 1;
+        const int ncand = __popcll(__ballot(rows > 0)), n16 = __popcll(__ballot(rows > 16)), n20 = __popcll(__ballot(rows > 20));
+        const int n24 = __popcll(__ballot(rows > 24)), n28 = __popcll(__ballot(rows > 28));
+        const int room = 8 * WAVES - ncand;                      // octets left for second halves
+        const int big = n16 <= room ? 16 : (n20 <= room ? 20 : (n24 <= room ? 24 : (n28 <= room ? 28 : 36)));
+        const bool isb = rows > big, any = rows > 0;
+        const unsigned long long mb = __ballot(isb), ms = __ballot(any && !isb), below = (1ull << lane) - 1ull;
+        constexpr int kSpare = 2 * P::kSchedWords;
+        const int nbig = __popcll(mb);
+        const int o = isb ? 2 * __popcll(mb & below) : 2 * nbig + __popcll(ms & below);
+        sched[any ? o : kSpare] = (uint16_t)((uint32_t)lane | (isb ? 1u << 9 : 0u));
+        sched[isb ? o + 1 : kSpare] = (uint16_t)((uint32_t)lane | 1u << 8 | 1u << 9);
+        octets = ncand + nbig;
     }
     pixel_wave_fence();
     if (probe && lane == 0) *probe = __builtin_amdgcn_s_memrealtime();      // (diagnostic builds only: the schedule is done)
-    const int octets = 2 * nbig + nsmall;
     const uint32_t* run = reinterpret_cast<const uint32_t*>(pool + P::kRun);
     for (int base = wv * 8; base < octets; base += 8 * WAVES) {                                   // (uniform over the wave)
         const int o = base + (lane >> 3);
@@ -241,7 +277,7 @@ template <typename T>
 using OneWavePixT = PixPool<T, 1, 1>;
 template <typename T>
 __device__ __forceinline__ bool camera_features_pixel_tile(const Drone<T>& d, float* pix, int lane, T& cx, T& cy, T& area, T& ratio) {
-    pixel_tile_setup<T, 1, 1>(d, pix, 0, lane);
+    (void)pixel_tile_setup<T, 1, 1>(d, pix, 0, lane);
     pixel_wave_fence();
     pixel_pool_contours<T, 1, 1>(pix, 0, lane);
     pixel_wave_fence();

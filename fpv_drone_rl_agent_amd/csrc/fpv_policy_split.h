@@ -64,16 +64,20 @@ struct SplitOut {
     float *obs_n, *action, *clipped, *value, *logp, *eps_out;
 };
 
-// One net (0: pi with the sampling epilogue, 1: V) for this lane's row d; the net's split image is in LDS at `img`, the head block
-// and the normaliser (mean[20], 1 / sigma[20]) at `head` / `nrm`.  Returns the clipped action (net 0; undefined for net 1).
-__device__ __forceinline__ f32x4 split_net_row(int net, const unsigned char* img, const float* head, const float* nrm, float clip,
-                                               const float* __restrict__ obs, int64_t d, bool live, int lane, const SplitOut& out,
-                                               const float* eps_in, uint64_t tick, bool deterministic, uint64_t seed, uint64_t id_offset) {
+// One net (0: pi with the sampling epilogue, 1: V) for this lane's row d, in two parts so that a caller can put work between them
+// (the one-kernel rollout step requests the next net's image there): split_net_hidden — observation, both hidden layers, the net's
+// split image in LDS at `img`, the normaliser (mean[20], 1 / sigma[20]) at `nrm`; returns tanh of layer 2 as four accumulator tiles —
+// and split_net_head — the head block at `head`: action head + sampling epilogue (net 0; returns the clipped action) or the value.
+struct SplitHidden {
+    f32x16 c[4];
+};
+
+__device__ __forceinline__ void split_net_hidden(const unsigned char* img, const float* nrm, float clip, const float* __restrict__ obs,
+                                                 int64_t d, bool live, int lane, float* obs_n_out, SplitHidden& hd) {
     const int h = lane >> 5;
     const bf16x8* w2img = reinterpret_cast<const bf16x8*>(img);
     const bf16x8* w1img = reinterpret_cast<const bf16x8*>(img + kW2Bytes);
     const float* bias = reinterpret_cast<const float*>(img + kW2Bytes + kW1Bytes);
-    f32x4 cl = f32x4{0.f, 0.f, 0.f, 0.f};
     // observation slice of this lane half (k = 12 h .. 12 h + 11), normalised
     float x[16];
     {
@@ -90,8 +94,8 @@ __device__ __forceinline__ f32x4 split_net_row(int net, const unsigned char* img
             if (k < kIn) x[j] = fminf(fmaxf((x[j] - nrm[k]) * nrm[20 + k], -clip), clip);
         }
         x[12] = x[13] = x[14] = x[15] = 0.0f;
-        if (out.obs_n && live) {                  // (the caller hands obs_n to ONE pass: the first net it evaluates)
-            f32x4* o = reinterpret_cast<f32x4*>(out.obs_n + d * kIn);
+        if (obs_n_out && live) {                  // (the caller hands obs_n to ONE pass: the first net it evaluates)
+            f32x4* o = reinterpret_cast<f32x4*>(obs_n_out + d * kIn);
 #pragma unroll
             for (int q = 0; q < 3; ++q)
                 if (h == 0 || q < 2) o[3 * h + q] = f32x4{x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
@@ -143,6 +147,16 @@ __device__ __forceinline__ f32x4 split_net_row(int net, const unsigned char* img
 #pragma unroll
         for (int r = 0; r < 16; ++r) c[m][r] = fast_tanh(c[m][r]);
 
+#pragma unroll
+    for (int m = 0; m < 4; ++m) hd.c[m] = c[m];
+}
+
+__device__ __forceinline__ f32x4 split_net_head(int net, const float* head, const SplitHidden& hd, int64_t d, bool live, int lane,
+                                                const SplitOut& out, const float* eps_in, uint64_t tick, bool deterministic,
+                                                uint64_t seed, uint64_t id_offset) {
+    const int h = lane >> 5;
+    const f32x16 (&c)[4] = hd.c;
+    f32x4 cl = f32x4{0.f, 0.f, 0.f, 0.f};
     // The two lane halves are combined with half_sum() (v_permlane32_swap, VALU only).  The first version went
     // through __shfl_xor -> ds_bpermute_b32 and about 1 row in 3 000 came out with a wrong FIRST head component
     // (1 311 bad rows in 3.9 x 10^6 with -DFPV_HALFSUM_BPERMUTE, 0 in 2 x 10^7 with the VALU swap; tools/stress_policy.py;
@@ -206,23 +220,45 @@ __device__ __forceinline__ f32x4 split_net_row(int net, const unsigned char* img
     return cl;
 }
 
-// this net's split image -> LDS (all requests in flight before the first LDS write); THREADS = workgroup size
+__device__ __forceinline__ f32x4 split_net_row(int net, const unsigned char* img, const float* head, const float* nrm, float clip,
+                                               const float* __restrict__ obs, int64_t d, bool live, int lane, const SplitOut& out,
+                                               const float* eps_in, uint64_t tick, bool deterministic, uint64_t seed, uint64_t id_offset) {
+    SplitHidden hd;
+    split_net_hidden(img, nrm, clip, obs, d, live, lane, out.obs_n, hd);
+    return split_net_head(net, head, hd, d, live, lane, out, eps_in, tick, deterministic, seed, id_offset);
+}
+
+// this net's split image -> LDS (all requests in flight before the first LDS write); THREADS = workgroup size.  In two halves for a
+// caller that has other work to do while the requests are under way: split_stage_request (global -> registers) and
+// split_stage_commit (registers -> LDS; the image's space must be free by then).
+template <int THREADS>
+struct SplitStage {
+    static constexpr int kGran = kNetBytes / 16, kPer = (kGran + THREADS - 1) / THREADS;
+    f32x4 v[kPer];
+};
+template <int THREADS>
+__device__ __forceinline__ void split_stage_request(const unsigned char* __restrict__ image, int net, SplitStage<THREADS>& st) {
+    const f32x4* src = reinterpret_cast<const f32x4*>(image + (size_t)net * kNetBytes);
+#pragma unroll
+    for (int q = 0; q < SplitStage<THREADS>::kPer; ++q) {
+        const int g = q * THREADS + threadIdx.x;
+        st.v[q] = src[g < SplitStage<THREADS>::kGran ? g : 0];
+    }
+}
+template <int THREADS>
+__device__ __forceinline__ void split_stage_commit(const SplitStage<THREADS>& st, unsigned char* lds_raw) {
+    f32x4* dst = reinterpret_cast<f32x4*>(lds_raw);
+#pragma unroll
+    for (int q = 0; q < SplitStage<THREADS>::kPer; ++q) {
+        const int g = q * THREADS + threadIdx.x;
+        if (g < SplitStage<THREADS>::kGran) dst[g] = st.v[q];
+    }
+}
 template <int THREADS>
 __device__ __forceinline__ void split_stage_image(const unsigned char* __restrict__ image, int net, unsigned char* lds_raw) {
-    const f32x4* src = reinterpret_cast<const f32x4*>(image + (size_t)net * kNetBytes);
-    f32x4* dst = reinterpret_cast<f32x4*>(lds_raw);
-    constexpr int kGran = kNetBytes / 16, kPer = (kGran + THREADS - 1) / THREADS;
-    f32x4 stage[kPer];
-#pragma unroll
-    for (int q = 0; q < kPer; ++q) {
-        const int g = q * THREADS + threadIdx.x;
-        stage[q] = src[g < kGran ? g : 0];
-    }
-#pragma unroll
-    for (int q = 0; q < kPer; ++q) {
-        const int g = q * THREADS + threadIdx.x;
-        if (g < kGran) dst[g] = stage[q];
-    }
+    SplitStage<THREADS> st;
+    split_stage_request<THREADS>(image, net, st);
+    split_stage_commit<THREADS>(st, lds_raw);
 }
 
 }  // namespace fpv

@@ -1390,8 +1390,9 @@ static int64_t ppo_stat_waves(int64_t rows, int cus) {
 }
 
 int64_t ppo_workspace_floats(int64_t rows, int cus) {
-    int rps;
-    const int slabs = ppo_slabs(rows, &rps);                     // >= the one-kernel path's slab count
+    int rps, frps;
+    const int two = ppo_slabs(rows, &rps), one = ppo_fused_slabs(rows, cus, &frps);
+    const int slabs = two > one ? two : one;                     // the partial blocks of whichever path writes more (cus > 256: the one-kernel path)
     return (int64_t)kTImage + 8 * rows * kHid + rows * 24 + rows * 4 + rows + ppo_stat_waves(rows, cus) * kWaveStats +
            2 * (int64_t)slabs * kPartStride + 64;
 }

@@ -277,7 +277,7 @@ struct TileRegs {
     float tmpl_lane;
 };
 
-// Called by all 512 threads after the clipped actions are in LDS (kRsAct) and a workgroup barrier.  Contains eight (eleven with the
+// Called by all 512 threads after the clipped actions are in LDS (kRsAct) and a workgroup barrier.  Contains eight (twelve with the
 // pixel detector) workgroup barriers on every path.  On return the four observation tiles (+ returns) are still in LDS (kRsTile).
 // (Measured and not kept: a two-party LDS arrival counter per tile in place of the workgroup barriers between a tile's two waves —
 // no waiting for the slowest of the four tiles at every hand-off, but each hand-off then costs an LDS poll: 68.45 vs 68.63 us per
@@ -320,6 +320,7 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
                 att[2 * kTile + lane] = f32x4{o7[5], o7[6], 0.f, 0.f};
             }
             if (o_.stamps && threadIdx.x == 256) o_.stamps[10] = __builtin_amdgcn_s_memrealtime();
+            lds_barrier();                                 // barrier P1 (the owner waves write the schedule behind it)
         }
     }
     // ---------------- physics wave, first part: the sub-steps, then the corners of its drones' panels
@@ -356,7 +357,9 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
             att[lane] = f32x4{d.qx, d.qy, d.qz, d.qw};
             att[kTile + lane] = f32x4{d.er, d.ep, d.eyaw, 0.f};
             lds_barrier();                                     // barrier P0: the helper converts the attitude from here on
-            pixel_tile_setup<float, 4, 8>(d, pix, tl, lane);
+            const int blob_rows = pixel_tile_setup<float, 4, 8>(d, pix, tl, lane);
+            lds_barrier();                                     // barrier P1: the four tiles' census words are in LDS
+            pixel_tile_schedule<float, 4, 8>(pix, tl, lane, blob_rows);      // this tile's octets of the workgroup's schedule
             if (o_.stamps && threadIdx.x == 0) o_.stamps[4] = __builtin_amdgcn_s_memrealtime();
         }
     }
@@ -364,6 +367,12 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
     if (s.detector) {
         lds_barrier();                                         // barrier P: the four tiles' corner blocks are in LDS
         if (o_.stamps && threadIdx.x == 0) o_.stamps[6] = __builtin_amdgcn_s_memrealtime();
+#ifdef FPV_CONTOUR_PRIO
+        // A SIMD serves its older wave first: with the same instruction stream on both, the helper wave (the younger one) ends a
+        // microsecond behind the physics wave, and barrier R waits for it.  FPV_CONTOUR_PRIO raises the helper's priority for
+        // the length of the contour phase (A/B switch; DESIGN §5b has the measurement).
+        if (helper) __builtin_amdgcn_s_setprio(FPV_CONTOUR_PRIO);
+#endif
 #ifdef FPV_CONTOUR_PROBE
         if (o_.stamps && lane == 0) o_.stamps[36 + wave] = __builtin_amdgcn_s_memrealtime();                  // s[40 + w]: wave w past P
         pixel_pool_contours<float, 4, 8>(pix, wave, lane, o_.stamps ? o_.stamps + 44 + wave : nullptr);      // s[48 + w]: schedule done
@@ -376,6 +385,9 @@ __device__ __forceinline__ void rs_tail(const StepArgs<float>& s, float* lds, Ti
         }
 #else
         pixel_pool_contours<float, 4, 8>(pix, wave, lane);
+#endif
+#ifdef FPV_CONTOUR_PRIO
+        if (helper) __builtin_amdgcn_s_setprio(0);
 #endif
         if (o_.stamps && (threadIdx.x & 255) == 0) o_.stamps[helper ? 11 : 7] = __builtin_amdgcn_s_memrealtime();
         lds_barrier();                                         // barrier R: every blob's result is in LDS
@@ -751,6 +763,9 @@ struct RollStepSplitArgs {
     uint64_t* stamps;
 };
 constexpr int kRsSplitLdsBytes = (kRsPix + RsPix::kWords) * 4 > kSplitLdsBytes ? (kRsPix + RsPix::kWords) * 4 : kSplitLdsBytes;
+#ifndef FPV_SPLIT_STAGE_EARLY
+#define FPV_SPLIT_STAGE_EARLY 0
+#endif
 
 #pragma clang fp contract(fast)
 __global__ __launch_bounds__(512) void rollout_step_split_kernel(RollStepSplitArgs p) {
@@ -764,6 +779,12 @@ __global__ __launch_bounds__(512) void rollout_step_split_kernel(RollStepSplitAr
     RSS_STAMP(0);
     for (int q = threadIdx.x; q < kHeadFloats; q += 512)
         head[q] = reinterpret_cast<const float*>(p.image + 2 * (size_t)kNetBytes)[q];
+    // pi's image is requested BEFORE the statistics merge and written to LDS behind it: the merge waits for the 90 KB row table of
+    // the previous step (every workgroup the same rows), the image for 121 KB out of L2 — one wait instead of two in a row
+    SplitStage<512> stage;
+#if FPV_SPLIT_STAGE_EARLY
+    split_stage_request<512>(p.image, 0, stage);
+#endif
     if (p.mg.rows) {                            // fold the previous env step's tile sums into the statistics first
         MergeRegs mr;
         merge_request(p.mg, mr);
@@ -776,18 +797,27 @@ __global__ __launch_bounds__(512) void rollout_step_split_kernel(RollStepSplitAr
     const uint64_t tick = p.st.tick[(int64_t)blockIdx.x * 4];       // this workgroup's own tile's copy (rollout_step_kernel)
     const SplitOut out{p.obs_n, p.action, p.clipped, p.value, p.logp, nullptr};
     f32x4 cl = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int net = 0; net < 2; ++net) {
-        __syncthreads();   // everyone is done with the previous image (and the head block / normaliser are written)
-        split_stage_image<512>(p.image, net, lds_raw);
-        __syncthreads();
-        if (net == 0) RSS_STAMP(1);
-        SplitOut o = out;
-        if (net) o.obs_n = nullptr;                    // (the normalised row is written once, by the first pass)
-        const f32x4 r = split_net_row(net, lds_raw, head, nrm, clip, p.st.obs, d, d < p.st.n, lane, o, nullptr, tick, false, p.pol_seed,
-                                      p.pol_id_offset);
-        if (net == 0) cl = r;
-    }
+#if !FPV_SPLIT_STAGE_EARLY
+    split_stage_request<512>(p.image, 0, stage);
+#endif
+    split_stage_commit<512>(stage, lds_raw);           // (the image's LDS is disjoint from the head block and the merge's exchange)
+    __syncthreads();                                   // pi's image, the head block and the normaliser are in LDS
+    RSS_STAMP(1);
+    SplitHidden hd;
+    split_net_hidden(lds_raw, nrm, clip, p.st.obs, d, d < p.st.n, lane, p.obs_n, hd);
+    // V's image is requested as soon as this wave's matrix work on pi is over and lands under pi's head / sampling arithmetic
+#if FPV_SPLIT_STAGE_EARLY
+    split_stage_request<512>(p.image, 1, stage);
+#endif
+    cl = split_net_head(0, head, hd, d, d < p.st.n, lane, out, nullptr, tick, false, p.pol_seed, p.pol_id_offset);
+    __syncthreads();                                   // every wave is done with pi's image
+#if !FPV_SPLIT_STAGE_EARLY
+    split_stage_request<512>(p.image, 1, stage);
+#endif
+    split_stage_commit<512>(stage, lds_raw);
+    __syncthreads();
+    split_net_hidden(lds_raw, nrm, clip, p.st.obs, d, d < p.st.n, lane, nullptr, hd);
+    (void)split_net_head(1, head, hd, d, d < p.st.n, lane, out, nullptr, tick, false, p.pol_seed, p.pol_id_offset);
     TileRegs tr;
     rs_load_tile(p.st, tr);
     lds_barrier();                                     // every wave is done with the image: its space is free

@@ -185,10 +185,11 @@ class FusedPolicy:
                  path: str | None = None):
         """Gradient of SB3's PPO minibatch loss w.r.t. every parameter of the module, written into the parameters'
         .grad tensors by fpv_ppo_grad (forward, loss derivatives and backward as hand-written MFMA kernels; no torch
-        autograd involved).  index: optional int64 row indices into the five arrays.  storage: "f32" (exact) or "bf16"
-        (the activations / deltas pass between the kernels in bf16: half the HBM traffic, gradients within ~1e-3 of their
-        max-norm; two-kernel path only).  path: "one_kernel" (FPV_PPO_ONE_KERNEL: forward, backward and weight gradients of a row
-        in one kernel, nothing stored; the default with fp32 storage), "two_kernels" (the activations / deltas pass through memory;
+        autograd involved).  index: optional int64 row indices into the five arrays.  storage: what the two-kernel paths write between
+        their kernels — "f32" words or "bf16" (half the HBM traffic, gradients within ~1e-3 of their max-norm; two-kernel path
+        only); a storage format, not an arithmetic.  path: "one_kernel" (FPV_PPO_ONE_KERNEL: forward, backward and weight gradients
+        of a row in one kernel, nothing stored, the three 128 x 128 products per row as 6-term bf16 splits with fp32 accumulation —
+        fp32-level, golden error 4.5e-7, not exact fp32-input MFMA; the default with fp32 storage), "two_kernels" (the activations / deltas pass through memory;
         the default with bf16 storage) or "two_kernels_bf16x6" (as before, the weight-gradient products on the bf16 MFMA with every
         fp32 operand cut into three bf16 pieces, six piece products per product: fp32-level error; "two_kernels_bf16x3": three piece
         products, weight gradients to ~5e-6 of their max-norm — on record, not for use).

@@ -414,10 +414,14 @@ typedef struct {
     float* stats;             /* [4] out: policy-gradient loss, value loss (MSE), approx KL, clip fraction */
     void* workspace;          /* device scratch, >= fpv_ppo_workspace_bytes(rows), 16-byte aligned */
     int64_t workspace_bytes;
-    int32_t storage;          /* 0: activations / deltas pass between the kernels in fp32 (exact, default); 1: in bf16 —  */
-                              /* half the HBM traffic of the update, gradients within ~1e-3 of their max-norm          */
+    int32_t storage;          /* what the two-kernel paths write between their kernels: 0 = fp32 words (default), 1 = bf16 —  */
+                              /* half the HBM traffic of the update, gradients within ~1e-3 of their max-norm.  (A storage */
+                              /* format, not an arithmetic: which pipe multiplies is `path`'s business.)                   */
     int32_t path;             /* FPV_PPO_ONE_KERNEL (0, default): forward, backward and the weight gradients of a row in  */
-                              /* one kernel, the activations / deltas never leave the CU (fp32; storage must be 0).       */
+                              /* one kernel, the activations / deltas never leave the CU (storage must be 0).  Its three   */
+                              /* 128 x 128 products per row run as 6-term bf16 splits of the fp32 operands with fp32      */
+                              /* accumulation and its tanh is the fast form: fp32-LEVEL (golden error 4.5e-7 of a tensor's  */
+                              /* max-norm), not the exact fp32-input MFMA of path 1.                                       */
                               /* FPV_PPO_TWO_KERNELS (1): they pass through memory between two kernels (`storage`).        */
                               /* FPV_PPO_TWO_KERNELS_BF16X6 (2): as 1 with the weight-gradient products on the bf16 MFMA, */
                               /* every fp32 operand cut into three bf16 pieces, six piece products per product (fp32      */

@@ -135,7 +135,7 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did():
     """`python bench.py --gpus 2` with a clean environment (no RANK / WORLD_SIZE): the parent touches no GPU, starts the two ranks
     through torch.distributed.run itself, relays rank 0's ONE line and the ranks' exit code — what the reference does with
     make_vec_env(..., n_envs=16, vec_env_cls=SubprocVecEnv) (simulation/train_hover.py:41-42).  GPU-free plumbing mode here; the
-    -m gpu twin runs real kernels (tests/test_facades_gpu.py)."""
+    -m gpu twin runs real kernels (tests/test_bench_gpu.py)."""
     import json
     import subprocess
     import sys
@@ -149,7 +149,7 @@ def test_bench_starts_its_own_ranks_when_no_launcher_did():
     assert len(lines) == 1, out.stdout                       # nothing but the one line on stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["total_drones"] == 2 * 65536 and rec["plumbing"]["gathered_rows"] == 2
-    # a failing rank fails the parent: --drones 0 is refused by the ranks' own argument check
+    # a failing rank fails the parent: --n-steps 0 is refused by the ranks' own argument check
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--n-steps", "0",
                           "--plumbing-only"], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0

@@ -1,8 +1,8 @@
 #!/bin/bash
-# gpurun_out/session (tools/gpu_session.sh) -> the tracked summaries under profiles/, named <TAG>_* (default r04)
+# gpurun_out/session (tools/gpu_session.sh) -> the tracked summaries under profiles/, named <TAG>_* (default r05)
 set -e
 cd "$(dirname "$0")/.."
-TAG=${1:-r04}
+TAG=${1:-r05}
 O=gpurun_out/session
 last() { tail -n 1 "$1"; }
 last $O/bench.json > profiles/${TAG}_bench_line.json
@@ -14,7 +14,11 @@ last $O/bench_gpus2_gloo.json > profiles/${TAG}_bench_line_gpus2_gloo_one_gpu.js
 cp $O/phases_step.json profiles/${TAG}_rollout_step_phases.json
 cp $O/phases_step_analytic.json profiles/${TAG}_rollout_step_phases_analytic.json
 cp $O/c_host_one.json profiles/${TAG}_c_host.json
-cp gpurun_out/pixel_flip_rate.json profiles/${TAG}_pixel_flip_rate.json
+cp $O/flip_rates.json profiles/${TAG}_flip_rates.json
+[ -s $O/hostmode.txt ] && cp $O/hostmode.txt profiles/${TAG}_hostmode.txt
+last $O/bench_f32.json > profiles/${TAG}_bench_line_exact_fp32_policy.json
+last $O/bench_f32_s20.json > profiles/${TAG}_bench_line_exact_fp32_policy_s20.json
+[ -f $O/census.npz ] && python tests/detector_census_report.py $O/census.npz > profiles/${TAG}_detector_census.json
 cp $O/step_sweep_pixel.json profiles/${TAG}_step_sweep_pixel.json
 cp $O/step_quad_sweep.json profiles/${TAG}_step_quad_sweep.json
 cp $O/fp32_vs_fp64_trajectory.json profiles/${TAG}_fp32_vs_fp64_trajectory.json

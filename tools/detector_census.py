@@ -36,7 +36,7 @@ def dump(path):
     for _ in range(4):
         col.collect()
     grid = n // 256
-    words = 64 if os.environ.get("FPV_LIB_VARIANT") == "contour_probe" else 16     # (the probe build's stamp rows: fpv_rollstep.hip)
+    words = 64 if "probe" in os.environ.get("FPV_LIB_VARIANT", "") else 16     # (the probe build's stamp rows: fpv_rollstep.hip)
     stamps = torch.zeros((grid, words), dtype=torch.int64, device="cuda")
     L.load().fpv_debug_rollout_stamps(eng._h, C.c_void_p(stamps.data_ptr()))
     col._graph = None

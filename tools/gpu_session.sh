@@ -1,5 +1,5 @@
 #!/bin/bash
-# The measurement set behind profiles/<TAG>_* (TAG = r04 by default): GPU suite, bench lines (default = pixel detector; the driver's
+# The measurement set behind profiles/<TAG>_* (TAG = r05 by default): GPU suite, bench lines (default = pixel detector; the driver's
 # --steps 20 shape; analytic; yaw; two-kernel; rehearsed ranks), phase stamps, C host, rocprofv3 kernel statistics, the rollout
 # boundary from a kernel trace, the PMC traffic passes and the SQ counters of the rollout-step kernel, env-step sweeps over drone
 # counts, the fp32-vs-fp64 trajectory record, PPO update profile.
@@ -11,6 +11,8 @@ timeout -k 10 900 python -m pytest tests -x -q -m gpu > $O/tests.txt 2>&1 || { t
 tail -2 $O/tests.txt
 python bench.py > $O/bench.json 2> $O/bench.err
 python bench.py --steps 20 --warmup 5 > $O/bench_s20.json 2> $O/bench_s20.err
+python bench.py --policy-gemm f32 --no-cpu-baseline --no-split-extra --no-host-mode --no-f64-rollout > $O/bench_f32.json 2> $O/bench_f32.err
+python bench.py --policy-gemm f32 --steps 20 --warmup 5 --no-cpu-baseline --no-split-extra --no-host-mode > $O/bench_f32_s20.json 2> $O/bench_f32_s20.err
 python bench.py --detector analytic --no-cpu-baseline --no-split-extra --no-host-mode --no-f64-rollout > $O/bench_analytic.json 2> $O/bench_analytic.err
 python bench.py --two-launch --no-cpu-baseline --no-split-extra --no-host-mode --no-f64-rollout > $O/bench_two.json 2> $O/bench_two.err
 python bench.py --task yaw --no-cpu-baseline --no-host-mode > $O/bench_yaw.json 2> $O/bench_yaw.err
@@ -30,6 +32,9 @@ bash tools/pmc_rollstep.sh > $O/pmc_k0.txt 2>&1
 python tools/step_sweep.py $O/step_sweep_pixel.json pixel > /dev/null 2>&1
 python tools/step_quad_sweep.py $O/step_quad_sweep.json > /dev/null 2>&1
 python tools/trajectory_drift.py > $O/fp32_vs_fp64_trajectory.json 2> /dev/null
+python tools/flip_rates.py > $O/flip_rates.json 2> /dev/null
+python tools/detector_census.py $O/census.npz > /dev/null 2>&1
+python tools/microbench_hostmode.py > $O/hostmode.txt 2> /dev/null || true
 # PPO training end to end (learning curve + wall clock), the default update path and the two-kernel one
 python examples/train_hover.py --drones 16384 --timesteps 3e8 --log-every 20 > $O/train_16384.log 2>&1
 python examples/train_hover.py --drones 65536 --timesteps 6e8 --log-every 20 > $O/train_65536.log 2>&1

@@ -7,6 +7,8 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01_final"
 s = json.load(open(f"profiles/{tag}_summary.json"))
 f, w = s["pmc_raw_KB_per_launch"]["FETCH_SIZE"], s["pmc_raw_KB_per_launch"]["WRITE_SIZE"]
 want = {"fpv::rollout_step_kernel": "rollout_step_kernel",
+        "fpv::rollout_step_split_kernel": "rollout_step_split_kernel",
+        "fpv::policy_split_forward_kernel": "policy_split_forward_kernel",
         "fpv::policy_forward_kernel": "policy_forward_kernel<512>",
         "fpv::step_quad_kernel": "step_quad_kernel",
         "fpv::step_kernel<float,true,true>": "step_kernel<float, true, true",

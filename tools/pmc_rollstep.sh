@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counters of the rollout-step kernel (one kernel per step, 65 536 drones, pixel detector): two rocprofv3 --pmc passes of eight
-# counters over the bench command, per-launch means of fpv::rollout_step_kernel -> gpurun_out/pmc_k0/summary.json
+# counters over the bench command, per-launch means of the rollout-step kernel (fpv::rollout_step_split_kernel by default) -> gpurun_out/pmc_k0/summary.json
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/pmc_k0; mkdir -p $O
@@ -12,7 +12,7 @@ import collections, csv, glob, json
 acc = collections.defaultdict(list)
 for f in glob.glob("gpurun_out/pmc_k0/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "rollout_step_kernel" in r["Kernel_Name"]:
+        if "rollout_step_kernel" in r["Kernel_Name"] or "rollout_step_split_kernel" in r["Kernel_Name"]:     # (whichever the default runs)
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {k: {"launches": len(v), "mean": sum(v) / len(v)} for k, v in sorted(acc.items())}
 json.dump(out, open("gpurun_out/pmc_k0/summary.json", "w"), indent=1)
