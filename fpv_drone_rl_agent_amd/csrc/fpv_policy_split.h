@@ -59,6 +59,46 @@ __device__ __forceinline__ f32x16 mfma6(const bf16x8* __restrict__ wfrag /* 3 pa
     return acc;
 }
 
+// The same for FOUR accumulator tiles (the four 32-row output tiles of a layer's k-step), piece by piece across the tiles: two
+// products into one accumulator are then four products apart — a 32 x 32 x 16 product holds its accumulator for 16 passes, so six
+// products in a row into the same tile (mfma6 tile after tile) wait for each other.  The order of the six terms per tile is
+// mfma6's, so the sums are the same bits.
+// A scheduling fence behind every k-step keeps hipcc from hoisting the next k-steps' weight fragments over this one's products.
+// The stand-alone kernel (fpv_policy_split.hip: a chunk loop around the nets) needs it — without it 571 registers spill to scratch
+// —; the one-kernel rollout step (fpv_rollstep.hip: one chunk, no loop) is 1.4 us faster in its policy phase without (no spill:
+// 226 registers) and defines the macro empty before it includes this header.  A fence moves no arithmetic: same bits.
+#ifndef FPV_SPLIT_FENCE
+#define FPV_SPLIT_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifndef FPV_SPLIT_MFMA_TILEWISE
+#define FPV_SPLIT_MFMA_TILEWISE 0     // 1: mfma6 tile after tile (round 4's order; A/B switch)
+#endif
+__device__ __forceinline__ void mfma6x4(const bf16x8* __restrict__ wfrag /* tile m at wfrag + m * tile_stride */, int tile_stride, int lane,
+                                        const bf16x8& x1, const bf16x8& x2, const bf16x8& x3, f32x16 (&acc)[4]) {
+#if FPV_SPLIT_MFMA_TILEWISE
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = mfma6(wfrag + m * tile_stride, lane, x1, x2, x3, acc[m]);
+#else
+    bf16x8 w1[4], w2[4], w3[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        w1[m] = wfrag[m * tile_stride + lane]; w2[m] = wfrag[m * tile_stride + 64 + lane]; w3[m] = wfrag[m * tile_stride + 128 + lane];
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3[m], x1, acc[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[m], x3, acc[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2[m], x2, acc[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2[m], x1, acc[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[m], x2, acc[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[m], x1, acc[m], 0, 0, 0);
+#endif
+}
+
 // Which outputs a pass over one net writes for its row (each pointer may be null)
 struct SplitOut {
     float *obs_n, *action, *clipped, *value, *logp, *eps_out;
@@ -114,9 +154,8 @@ __device__ __forceinline__ void split_net_hidden(const unsigned char* img, const
         for (int j = 0; j < 8; ++j) v[j] = x[8 * s + j];
         bf16x8 x1, x2, x3;
         split8(v, x1, x2, x3);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) a[m] = mfma6(w1img + (m * 2 + s) * 3 * 64, lane, x1, x2, x3, a[m]);
-        __builtin_amdgcn_sched_barrier(0);
+        mfma6x4(w1img + s * 3 * 64, 2 * 3 * 64, lane, x1, x2, x3, a);
+        FPV_SPLIT_FENCE();
     }
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -137,10 +176,8 @@ __device__ __forceinline__ void split_net_hidden(const unsigned char* img, const
             for (int j = 0; j < 8; ++j) v[j] = a[kt][8 * s + j];
             bf16x8 x1, x2, x3;
             split8(v, x1, x2, x3);
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-                c[m] = mfma6(w2img + ((m * 4 + kt) * 2 + s) * 3 * 64, lane, x1, x2, x3, c[m]);
-            __builtin_amdgcn_sched_barrier(0);   // keep the next k-step's 12 weight fragments from being hoisted here
+            mfma6x4(w2img + (kt * 2 + s) * 3 * 64, 4 * 2 * 3 * 64, lane, x1, x2, x3, c);
+            FPV_SPLIT_FENCE();                   // keep the next k-step's weight fragments from being hoisted here
         }
 #pragma unroll
     for (int m = 0; m < 4; ++m)

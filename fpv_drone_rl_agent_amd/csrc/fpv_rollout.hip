@@ -635,19 +635,25 @@ __global__ __launch_bounds__(256) void ledger_scan_kernel(LedgerScanArgs a) {
         typedef float f32x4 __attribute__((ext_vector_type(4)));
         // r_norm[t][i] = clip(r[t][i] / sqrt(var_t + eps)), var_t = snapshots[t][42]: reward_finalize_kernel on this launch's spare
         // workgroups; 16 bytes per lane and trip
+        // ([T][n] is one flat array: the workgroups stride over ALL of it, the step of an element is its index / n)
+        const int64_t total = (int64_t)a.T * a.fin_n, fb = (int64_t)blockIdx.x - a.scan_blocks, nfb = (int64_t)gridDim.x - a.scan_blocks;
         const bool vec = (a.fin_n & 3) == 0 && ((reinterpret_cast<uintptr_t>(a.fin_raw) | reinterpret_cast<uintptr_t>(a.fin_out)) & 15) == 0;
-        const int64_t quads = vec ? a.fin_n / 4 : 0, fb = (int64_t)blockIdx.x - a.scan_blocks, nfb = (int64_t)gridDim.x - a.scan_blocks;
-        for (int64_t t = 0; t < a.T; ++t) {
-            const float inv = (float)(1.0 / sqrt(a.fin_snap[t * a.fin_stride + 42] + (double)a.fin_eps));
-            const f32x4* src = reinterpret_cast<const f32x4*>(a.fin_raw + t * a.fin_n);
-            f32x4* dst = reinterpret_cast<f32x4*>(a.fin_out + t * a.fin_n);
-            for (int64_t q = fb * 256 + threadIdx.x; q < quads; q += nfb * 256) {
-                const f32x4 v = src[q];
-                dst[q] = f32x4{fminf(fmaxf(v.x * inv, -a.fin_clip), a.fin_clip), fminf(fmaxf(v.y * inv, -a.fin_clip), a.fin_clip),
-                               fminf(fmaxf(v.z * inv, -a.fin_clip), a.fin_clip), fminf(fmaxf(v.w * inv, -a.fin_clip), a.fin_clip)};
-            }
-            for (int64_t i = quads * 4 + fb * 256 + threadIdx.x; i < a.fin_n; i += nfb * 256)
-                a.fin_out[t * a.fin_n + i] = fminf(fmaxf(a.fin_raw[t * a.fin_n + i] * inv, -a.fin_clip), a.fin_clip);
+        const int64_t quads = vec ? total / 4 : 0;
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.fin_raw);
+        f32x4* dst = reinterpret_cast<f32x4*>(a.fin_out);
+        int64_t t_have = -1;
+        float inv = 0.f;
+        for (int64_t q = fb * 256 + threadIdx.x; q < quads; q += nfb * 256) {
+            const int64_t t = (4 * q) / a.fin_n;                 // (n % 4 == 0: a quad never straddles two steps)
+            if (t != t_have) { inv = (float)(1.0 / sqrt(a.fin_snap[t * a.fin_stride + 42] + (double)a.fin_eps)); t_have = t; }
+            const f32x4 v = src[q];
+            dst[q] = f32x4{fminf(fmaxf(v.x * inv, -a.fin_clip), a.fin_clip), fminf(fmaxf(v.y * inv, -a.fin_clip), a.fin_clip),
+                           fminf(fmaxf(v.z * inv, -a.fin_clip), a.fin_clip), fminf(fmaxf(v.w * inv, -a.fin_clip), a.fin_clip)};
+        }
+        for (int64_t i = quads * 4 + fb * 256 + threadIdx.x; i < total; i += nfb * 256) {
+            const int64_t t = i / a.fin_n;
+            if (t != t_have) { inv = (float)(1.0 / sqrt(a.fin_snap[t * a.fin_stride + 42] + (double)a.fin_eps)); t_have = t; }
+            a.fin_out[i] = fminf(fmaxf(a.fin_raw[i] * inv, -a.fin_clip), a.fin_clip);
         }
         return;
     }
@@ -838,9 +844,9 @@ hipError_t launch_ledger_scan(const uint32_t* led_count, const int32_t* led_idx,
                                                                     // the 64 KB a workgroup gets without asking are the waves' lists)
     a.scan_blocks = (int32_t)((slots + per_block - 1) / per_block);
     int64_t fin_blocks = 0;
-    if (fin_raw) {                                   // ~8 KB of rewards per workgroup and step, at most 1 024 workgroups
-        fin_blocks = (fin_n + 2047) / 2048;
-        if (fin_blocks > 1024) fin_blocks = 1024;
+    if (fin_raw) {                                   // 16 KB of rewards per workgroup and trip, at most 512 workgroups
+        fin_blocks = ((int64_t)T * fin_n + 4095) / 4096;
+        if (fin_blocks > 512) fin_blocks = 512;
         if (fin_blocks < 1) fin_blocks = 1;
     }
     hipLaunchKernelGGL(ledger_scan_kernel, dim3((unsigned)(a.scan_blocks + fin_blocks)), dim3(256),

@@ -23,6 +23,9 @@
 #include "fpv_mlp.h"
 #include "fpv_policy_image.h"
 #pragma clang fp contract(fast)
+#ifndef FPV_ROLLSTEP_KEEP_SPLIT_FENCE
+#define FPV_SPLIT_FENCE()            // the rollout-step kernel schedules its k-steps freely (fpv_policy_split.h; A/B: -DFPV_ROLLSTEP_KEEP_SPLIT_FENCE)
+#endif
 #include "fpv_policy_split.h"   // (the split policy arithmetic is compiled as in fpv_policy_split.hip: contract fast)
 #pragma clang fp contract(on)
 #include "fpv_pixel_tile.h"
