@@ -112,10 +112,10 @@ struct SplitHidden {
     f32x16 c[4];
 };
 
-__device__ __forceinline__ void split_net_hidden(const unsigned char* img, const float* nrm, float clip, const float* __restrict__ obs,
-                                                 int64_t d, bool live, int lane, float* obs_n_out, SplitHidden& hd) {
+// (layer 1 reads the image's W1 + bias block only, layer 2 W2 and the bias block: a caller may run layer 1 while W2 is on its way)
+__device__ __forceinline__ void split_net_layer1(const unsigned char* img, const float* nrm, float clip, const float* __restrict__ obs,
+                                                 int64_t d, bool live, int lane, float* obs_n_out, f32x16 (&a)[4]) {
     const int h = lane >> 5;
-    const bf16x8* w2img = reinterpret_cast<const bf16x8*>(img);
     const bf16x8* w1img = reinterpret_cast<const bf16x8*>(img + kW2Bytes);
     const float* bias = reinterpret_cast<const float*>(img + kW2Bytes + kW1Bytes);
     // observation slice of this lane half (k = 12 h .. 12 h + 11), normalised
@@ -142,7 +142,6 @@ __device__ __forceinline__ void split_net_hidden(const unsigned char* img, const
         }
     }
     // ---- layer 1 (K = 20 padded to 32: two k-steps)
-    f32x16 a[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -161,6 +160,12 @@ __device__ __forceinline__ void split_net_hidden(const unsigned char* img, const
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) a[m][r] = fast_tanh(a[m][r]);
+}
+
+__device__ __forceinline__ void split_net_layer2(const unsigned char* img, int lane, const f32x16 (&a)[4], SplitHidden& hd) {
+    const int h = lane >> 5;
+    const bf16x8* w2img = reinterpret_cast<const bf16x8*>(img);
+    const float* bias = reinterpret_cast<const float*>(img + kW2Bytes + kW1Bytes);
     // ---- layer 2: accumulator tiles of layer 1 are the B operands (registers 8 s .. 8 s + 7 per k-step)
     f32x16 c[4];
 #pragma unroll
@@ -186,6 +191,13 @@ __device__ __forceinline__ void split_net_hidden(const unsigned char* img, const
 
 #pragma unroll
     for (int m = 0; m < 4; ++m) hd.c[m] = c[m];
+}
+
+__device__ __forceinline__ void split_net_hidden(const unsigned char* img, const float* nrm, float clip, const float* __restrict__ obs,
+                                                 int64_t d, bool live, int lane, float* obs_n_out, SplitHidden& hd) {
+    f32x16 a[4];
+    split_net_layer1(img, nrm, clip, obs, d, live, lane, obs_n_out, a);
+    split_net_layer2(img, lane, a, hd);
 }
 
 __device__ __forceinline__ f32x4 split_net_head(int net, const float* head, const SplitHidden& hd, int64_t d, bool live, int lane,
@@ -268,34 +280,37 @@ __device__ __forceinline__ f32x4 split_net_row(int net, const unsigned char* img
 // this net's split image -> LDS (all requests in flight before the first LDS write); THREADS = workgroup size.  In two halves for a
 // caller that has other work to do while the requests are under way: split_stage_request (global -> registers) and
 // split_stage_commit (registers -> LDS; the image's space must be free by then).
-template <int THREADS>
+template <int THREADS, int OFF = 0, int BYTES = kNetBytes>      // bytes [OFF, OFF + BYTES) of a net's image
 struct SplitStage {
-    static constexpr int kGran = kNetBytes / 16, kPer = (kGran + THREADS - 1) / THREADS;
+    static constexpr int kGran = BYTES / 16, kPer = (kGran + THREADS - 1) / THREADS;
+    static_assert(OFF % 16 == 0 && BYTES % 16 == 0, "16-byte granules");
     f32x4 v[kPer];
 };
-template <int THREADS>
-__device__ __forceinline__ void split_stage_request(const unsigned char* __restrict__ image, int net, SplitStage<THREADS>& st) {
-    const f32x4* src = reinterpret_cast<const f32x4*>(image + (size_t)net * kNetBytes);
+template <int THREADS, int OFF, int BYTES>
+__device__ __forceinline__ void split_stage_request(const unsigned char* __restrict__ image, int net, SplitStage<THREADS, OFF, BYTES>& st) {
+    using S = SplitStage<THREADS, OFF, BYTES>;
+    const f32x4* src = reinterpret_cast<const f32x4*>(image + (size_t)net * kNetBytes + OFF);
 #pragma unroll
-    for (int q = 0; q < SplitStage<THREADS>::kPer; ++q) {
+    for (int q = 0; q < S::kPer; ++q) {
         const int g = q * THREADS + threadIdx.x;
-        st.v[q] = src[g < SplitStage<THREADS>::kGran ? g : 0];
+        st.v[q] = src[g < S::kGran ? g : 0];
     }
 }
-template <int THREADS>
-__device__ __forceinline__ void split_stage_commit(const SplitStage<THREADS>& st, unsigned char* lds_raw) {
-    f32x4* dst = reinterpret_cast<f32x4*>(lds_raw);
+template <int THREADS, int OFF, int BYTES>
+__device__ __forceinline__ void split_stage_commit(const SplitStage<THREADS, OFF, BYTES>& st, unsigned char* lds_raw) {
+    using S = SplitStage<THREADS, OFF, BYTES>;
+    f32x4* dst = reinterpret_cast<f32x4*>(lds_raw + OFF);
 #pragma unroll
-    for (int q = 0; q < SplitStage<THREADS>::kPer; ++q) {
+    for (int q = 0; q < S::kPer; ++q) {
         const int g = q * THREADS + threadIdx.x;
-        if (g < SplitStage<THREADS>::kGran) dst[g] = st.v[q];
+        if (g < S::kGran) dst[g] = st.v[q];
     }
 }
 template <int THREADS>
 __device__ __forceinline__ void split_stage_image(const unsigned char* __restrict__ image, int net, unsigned char* lds_raw) {
     SplitStage<THREADS> st;
-    split_stage_request<THREADS>(image, net, st);
-    split_stage_commit<THREADS>(st, lds_raw);
+    split_stage_request(image, net, st);
+    split_stage_commit(st, lds_raw);
 }
 
 }  // namespace fpv

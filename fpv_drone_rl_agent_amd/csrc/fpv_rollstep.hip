@@ -766,9 +766,6 @@ struct RollStepSplitArgs {
     uint64_t* stamps;
 };
 constexpr int kRsSplitLdsBytes = (kRsPix + RsPix::kWords) * 4 > kSplitLdsBytes ? (kRsPix + RsPix::kWords) * 4 : kSplitLdsBytes;
-#ifndef FPV_SPLIT_STAGE_EARLY
-#define FPV_SPLIT_STAGE_EARLY 0
-#endif
 
 #pragma clang fp contract(fast)
 __global__ __launch_bounds__(512) void rollout_step_split_kernel(RollStepSplitArgs p) {
@@ -782,12 +779,6 @@ __global__ __launch_bounds__(512) void rollout_step_split_kernel(RollStepSplitAr
     RSS_STAMP(0);
     for (int q = threadIdx.x; q < kHeadFloats; q += 512)
         head[q] = reinterpret_cast<const float*>(p.image + 2 * (size_t)kNetBytes)[q];
-    // pi's image is requested BEFORE the statistics merge and written to LDS behind it: the merge waits for the 90 KB row table of
-    // the previous step (every workgroup the same rows), the image for 121 KB out of L2 — one wait instead of two in a row
-    SplitStage<512> stage;
-#if FPV_SPLIT_STAGE_EARLY
-    split_stage_request<512>(p.image, 0, stage);
-#endif
     if (p.mg.rows) {                            // fold the previous env step's tile sums into the statistics first
         MergeRegs mr;
         merge_request(p.mg, mr);
@@ -800,27 +791,26 @@ __global__ __launch_bounds__(512) void rollout_step_split_kernel(RollStepSplitAr
     const uint64_t tick = p.st.tick[(int64_t)blockIdx.x * 4];       // this workgroup's own tile's copy (rollout_step_kernel)
     const SplitOut out{p.obs_n, p.action, p.clipped, p.value, p.logp, nullptr};
     f32x4 cl = f32x4{0.f, 0.f, 0.f, 0.f};
-#if !FPV_SPLIT_STAGE_EARLY
-    split_stage_request<512>(p.image, 0, stage);
-#endif
-    split_stage_commit<512>(stage, lds_raw);           // (the image's LDS is disjoint from the head block and the merge's exchange)
-    __syncthreads();                                   // pi's image, the head block and the normaliser are in LDS
-    RSS_STAMP(1);
+    // Each net's whole image in front of the net.  Measured and not kept: pi's image requested before the statistics
+    // merge (+0.4 us per step), V's requested before pi's head arithmetic (same), and the image in two parts — W1 + biases first,
+    // layer 1 on it while W2 is on its way — (+1.8 us: two more workgroup barriers and 48 registers in flight cost more than the
+    // fetch they hide).
     SplitHidden hd;
-    split_net_hidden(lds_raw, nrm, clip, p.st.obs, d, d < p.st.n, lane, p.obs_n, hd);
-    // V's image is requested as soon as this wave's matrix work on pi is over and lands under pi's head / sampling arithmetic
-#if FPV_SPLIT_STAGE_EARLY
-    split_stage_request<512>(p.image, 1, stage);
-#endif
-    cl = split_net_head(0, head, hd, d, d < p.st.n, lane, out, nullptr, tick, false, p.pol_seed, p.pol_id_offset);
-    __syncthreads();                                   // every wave is done with pi's image
-#if !FPV_SPLIT_STAGE_EARLY
-    split_stage_request<512>(p.image, 1, stage);
-#endif
-    split_stage_commit<512>(stage, lds_raw);
-    __syncthreads();
-    split_net_hidden(lds_raw, nrm, clip, p.st.obs, d, d < p.st.n, lane, nullptr, hd);
-    (void)split_net_head(1, head, hd, d, d < p.st.n, lane, out, nullptr, tick, false, p.pol_seed, p.pol_id_offset);
+    {
+        SplitStage<512> stage;
+        split_stage_request(p.image, 0, stage);
+        split_stage_commit(stage, lds_raw);
+        __syncthreads();                               // pi's image, the head block and the normaliser are in LDS
+        RSS_STAMP(1);
+        split_net_hidden(lds_raw, nrm, clip, p.st.obs, d, d < p.st.n, lane, p.obs_n, hd);
+        cl = split_net_head(0, head, hd, d, d < p.st.n, lane, out, nullptr, tick, false, p.pol_seed, p.pol_id_offset);
+        __syncthreads();                               // every wave is done with pi's image
+        split_stage_request(p.image, 1, stage);
+        split_stage_commit(stage, lds_raw);
+        __syncthreads();
+        split_net_hidden(lds_raw, nrm, clip, p.st.obs, d, d < p.st.n, lane, nullptr, hd);
+        (void)split_net_head(1, head, hd, d, d < p.st.n, lane, out, nullptr, tick, false, p.pol_seed, p.pol_id_offset);
+    }
     TileRegs tr;
     rs_load_tile(p.st, tr);
     lds_barrier();                                     // every wave is done with the image: its space is free
