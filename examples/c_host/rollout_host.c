@@ -49,6 +49,9 @@ int main(int argc, char** argv) {
     /* 4th argument 2: policy forward and env step as two kernels per step; default 1: fpv_rollout_step, both in one kernel
      * (served when n is a multiple of 256) */
     const int one_kernel = (argc > 4 ? atoi(argv[4]) : 1) == 1 && n % 256 == 0;
+    /* 5th argument: fpv_policy_set_gemm's mode — 1 (default): the 128-wide products as 6-term bf16 splits with fp32 accumulation, the
+     * arithmetic the Python collector runs by default since round 5; 0: exact fp32-input MFMA */
+    const int gemm = argc > 5 ? atoi(argv[5]) : 1;
     const float gamma = 0.99f, lam = 0.95f;
     if (fpv_version() != FPV_ABI_VERSION) {          /* struct layouts differ between versions: refuse another library build */
         fprintf(stderr, "libfpv_env.so is ABI version %d, this host was compiled against %d\n", fpv_version(), FPV_ABI_VERSION);
@@ -77,6 +80,7 @@ int main(int argc, char** argv) {
     }
     fpv_policy* pol = NULL;
     CK(fpv_policy_create(0, &pol));
+    CK(fpv_policy_set_gemm(pol, gemm));
     CK(fpv_policy_load(pol, w, s));
 
     /* buffers */
@@ -146,8 +150,9 @@ int main(int argc, char** argv) {
         vio.n = n; vio.obs = raw_obs; vio.rms = stats[0]; vio.obs_n = cur_obs; vio.value = last_val;
         vio.deterministic = 1; vio.nets = 2; vio.clip_obs = 10.f; vio.eps_norm = 1e-8f;
         CK(fpv_policy_forward(pol, &vio, s));
-        CK(fpv_reward_finalize(T, n, raw_rew, snap, 10.f, 1e-8f, buf_rew, s));
-        CK(fpv_ledger_scan(env, snap, 44, T, 10.f, 1e-8f, tobs, t_idx, d_idx, cap, counters, sums, 1, NULL, s));
+        /* the ledger scan and the deferred reward scaling (fpv_reward_finalize) as one launch */
+        CK(fpv_ledger_scan_finalize(env, snap, 44, T, 10.f, 1e-8f, tobs, t_idx, d_idx, cap, counters, sums, 1, NULL, raw_rew, snap, 44, 10.f,
+                                    1e-8f, buf_rew, s));
         fpv_policy_io lio;
         memset(&lio, 0, sizeof lio);
         lio.n = cap; lio.obs = tobs; lio.value = tvals; lio.deterministic = 1; lio.nets = 2; lio.n_dev = counters;
@@ -167,10 +172,10 @@ int main(int argc, char** argv) {
     HK(hipMemcpy(hm, mean_std, sizeof hm, hipMemcpyDeviceToHost));
     HK(hipMemcpy(hstats, stats[0], sizeof hstats, hipMemcpyDeviceToHost));
     const int ok = hc[3] == 0 && isfinite(hm[0]) && hm[1] > 0.0 && hstats[40] > (double)n * T * rollouts;
-    printf("{\"drones\": %lld, \"T\": %d, \"rollouts\": %d, \"kernels_per_step\": %d, \"env_steps_per_s\": %.4g, \"us_per_step\": %.2f, "
+    printf("{\"drones\": %lld, \"T\": %d, \"rollouts\": %d, \"kernels_per_step\": %d, \"policy_gemm\": %d, \"env_steps_per_s\": %.4g, \"us_per_step\": %.2f, "
            "\"episodes_last_rollout\": %d, \"truncated_last_rollout\": %d, \"ledger_flags\": %d, \"ep_len_mean\": %.1f, "
            "\"adv_mean\": %.4g, \"adv_std\": %.4g, \"obs_count\": %.0f, \"ok\": %s}\n",
-           (long long)n, T, rollouts, one_kernel ? 1 : 2, (double)n * T * rollouts / sec, sec * 1e6 / ((double)T * rollouts), hc[2], hc[0], hc[3],
+           (long long)n, T, rollouts, one_kernel ? 1 : 2, gemm, (double)n * T * rollouts / sec, sec * 1e6 / ((double)T * rollouts), hc[2], hc[0], hc[3],
            hc[1] ? hs[1] / hc[1] : 0.0, hm[0], hm[1], hstats[40], ok ? "true" : "false");
     CK(fpv_policy_destroy(pol));
     CK(fpv_destroy(env));
