@@ -31,17 +31,27 @@ __global__ void policy_split_pack_kernel(SplitParams p, unsigned char* __restric
         unsigned char* base = img + (size_t)net * kNetBytes;
         if (o < kW2Elems) {            // [m][kt][s][part][lane][j]
             const int j = o % 8, lane = (o / 8) % 64, part = (o / 512) % 3, s = (o / 1536) % 2, kt = (o / 3072) % 4, m = o / 12288;
-            const float w = w2[(m * 32 + (lane & 31)) * 128 + kt * 32 + frag_row(s, j, lane >> 5)];
+            float w = w2[(m * 32 + (lane & 31)) * 128 + kt * 32 + frag_row(s, j, lane >> 5)];
+            if (FPV_SPLIT_TANH_FOLD) w *= -2.0f * kTanhPrescale;     // layer 2 consumes r1 = (1 - tanh) / 2 and feeds a prescaled tanh (fpv_mlp.h)
             reinterpret_cast<__bf16*>(base)[o] = piece(w, part);
         } else if (o < kW2Elems + kW1Elems) {   // [m][s][part][lane][j]: input index k = 12 h + 8 s + j (< 12 per half, < 20)
             const int q = o - kW2Elems;
             const int j = q % 8, lane = (q / 8) % 64, part = (q / 512) % 3, s = (q / 1536) % 2, m = q / 3072;
             const int within = 8 * s + j, k = 12 * (lane >> 5) + within;
-            const float w = (within < 12 && k < kIn) ? w1[(m * 32 + (lane & 31)) * kIn + k] : 0.0f;
+            float w = (within < 12 && k < kIn) ? w1[(m * 32 + (lane & 31)) * kIn + k] : 0.0f;
+            if (FPV_SPLIT_TANH_FOLD) w *= kTanhPrescale;
             reinterpret_cast<__bf16*>(base + kW2Bytes)[q] = piece(w, part);
         } else {                                // biases in accumulator order [layer][m][h][r]
             const int q = o - kW2Elems - kW1Elems, layer = q / 128, z = q % 128, r = z % 16, h = (z / 16) % 2, m = z / 32;
-            reinterpret_cast<float*>(base + kW2Bytes + kW1Bytes)[q] = (layer ? b2 : b1)[m * 32 + acc_row(r, h)];
+            const int row = m * 32 + acc_row(r, h);
+            float bv_ = (layer ? b2 : b1)[row];
+            if (FPV_SPLIT_TANH_FOLD) {          // b + sum_k W_k for the layer that consumes r (in double, rounded once), both prescaled
+                double b = (double)bv_;
+                if (layer)
+                    for (int k = 0; k < 128; ++k) b += (double)w2[row * 128 + k];
+                bv_ = (float)b * kTanhPrescale;
+            }
+            reinterpret_cast<float*>(base + kW2Bytes + kW1Bytes)[q] = bv_;
         }
         return;
     }
@@ -51,11 +61,22 @@ __global__ void policy_split_pack_kernel(SplitParams p, unsigned char* __restric
     if (q < 512) {                              // Wa[h][kt][r][o]
         const int o = q % 4, r = (q / 4) % 16, kt = (q / 64) % 4, h = q / 256;
         v = p.wa[o * 128 + kt * 32 + acc_row(r, h)];
+        if (FPV_SPLIT_TANH_FOLD) v *= -2.0f;          // the heads consume r2
     } else if (q < 640) {
         const int z = q - 512, r = z % 16, kt = (z / 16) % 4, h = z / 64;
         v = p.wv[kt * 32 + acc_row(r, h)];
-    } else if (q < 644) v = p.ba[q - 640];
-    else if (q == 644) v = p.bv[0];
+        if (FPV_SPLIT_TANH_FOLD) v *= -2.0f;
+    } else if (q < 644) {
+        double b = (double)p.ba[q - 640];
+        if (FPV_SPLIT_TANH_FOLD)
+            for (int k = 0; k < 128; ++k) b += (double)p.wa[(q - 640) * 128 + k];
+        v = (float)b;
+    } else if (q == 644) {
+        double b = (double)p.bv[0];
+        if (FPV_SPLIT_TANH_FOLD)
+            for (int k = 0; k < 128; ++k) b += (double)p.wv[k];
+        v = (float)b;
+    }
     else if (q >= 648 && q < 652) v = p.log_std[q - 648];
     else if (q >= 652 && q < 656) v = expf(p.log_std[q - 652]);
     else if (q == 656) v = -(p.log_std[0] + p.log_std[1] + p.log_std[2] + p.log_std[3]) - 2.0f * 1.8378770664093453f;
