@@ -14,6 +14,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // weights and biases carry tanh's 2 log2 e, a hidden layer hands r = 1 / (1 + e^{2x}) = (1 - tanh x) / 2 to its consumer, whose image
 // holds -2 W (cut into pieces AFTER the scaling: one rounding of the weight, as in the fp32 image) and b + sum_k W_k (summed in
 // double, rounded once): a tanh is exp2, add, rcp — three vector instructions instead of five, 512 fewer per wave.
+#ifndef FPV_SPLIT_HEAD_PACKED
+#define FPV_SPLIT_HEAD_PACKED 1       // the heads' multiply-adds as v_pk_fma_f32 pairs (0: one v_fmac_f32 per output and hidden unit; A/B switch)
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef FPV_SPLIT_TANH_FOLD
 #define FPV_SPLIT_TANH_FOLD 1
 #endif
@@ -227,6 +231,24 @@ __device__ __forceinline__ f32x4 split_net_head(int net, const float* head, cons
     // cause unproven).
     if (net == 0) {
         // ---- action head on the VALU, sampling epilogue
+        // (the four outputs as two packed pairs: a hidden unit costs two v_pk_fma_f32 instead of four v_fmac_f32 — the same fused
+        // multiply-adds in the same order, so the same bits —, and a tile's sixteen weight quads are requested before the first is used)
+#if FPV_SPLIT_HEAD_PACKED
+        f32x2 mu01 = f32x2{0.f, 0.f}, mu23 = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            f32x4 w[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) w[r] = *reinterpret_cast<const f32x4*>(head + (((h * 4 + kt) * 16 + r) * 4));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const f32x2 v = f32x2{c[kt][r], c[kt][r]};
+                mu01 = __builtin_elementwise_fma(f32x2{w[r].x, w[r].y}, v, mu01);
+                mu23 = __builtin_elementwise_fma(f32x2{w[r].z, w[r].w}, v, mu23);
+            }
+        }
+        float mu[4] = {mu01.x, mu01.y, mu23.x, mu23.y};
+#else
         float mu[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
@@ -236,6 +258,7 @@ __device__ __forceinline__ f32x4 split_net_head(int net, const float* head, cons
                 const float v = c[kt][r];
                 mu[0] += w.x * v; mu[1] += w.y * v; mu[2] += w.z * v; mu[3] += w.w * v;
             }
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) mu[j] = half_sum(mu[j]) + head[640 + j];
         float eps[4] = {0.f, 0.f, 0.f, 0.f};
@@ -273,11 +296,28 @@ __device__ __forceinline__ f32x4 split_net_head(int net, const float* head, cons
             }
         }
     } else {
+#if FPV_SPLIT_HEAD_PACKED
+        // (two partial sums, even and odd hidden units of a quad pair, as packed multiply-adds: 32 instead of 64 instructions)
+        f32x2 vv = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            f32x4 w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] = *reinterpret_cast<const f32x4*>(head + 512 + (h * 4 + kt) * 16 + 4 * q);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                vv = __builtin_elementwise_fma(f32x2{w[q].x, w[q].y}, f32x2{c[kt][4 * q], c[kt][4 * q + 1]}, vv);
+                vv = __builtin_elementwise_fma(f32x2{w[q].z, w[q].w}, f32x2{c[kt][4 * q + 2], c[kt][4 * q + 3]}, vv);
+            }
+        }
+        float v = vv.x + vv.y;
+#else
         float v = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) v += head[512 + (h * 4 + kt) * 16 + r] * c[kt][r];
+#endif
         v = half_sum(v);
         if (live && h == 1) out.value[d] = v + head[644];
     }
