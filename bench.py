@@ -285,8 +285,8 @@ def main() -> None:
     eng = FpvEngine(n, dev, noise_ratio=0.02, seed=0, id_offset=rank * n, task=args.task, domain_rand=yaw,
                     ledger_capacity=n * max(2, T // 8), detector="analytic" if yaw else args.detector)
     col = RolloutCollector(eng, policy, n_steps=T, use_graph=not args.no_graph, one_launch=False if args.two_launch else None,
-                           policy_gemm=None if yaw else args.policy_gemm)
-    gemm = col.policy_gemm                                   # "bf16x6" for the hover task unless --policy-gemm f32
+                           policy_gemm=args.policy_gemm)
+    gemm = col.policy_gemm                                   # "bf16x6" unless --policy-gemm f32
     col.start()
     if not yaw:
         eng.set_state(torch.from_numpy(synthetic_states(n, seed=rank)))  # staggered step counts => staggered dones

@@ -599,7 +599,8 @@ int fpv_policy_load(fpv_policy* p, const float* const* weights, void* stream) {
 #ifdef FPV_EXPERIMENTS
     if (p->in_dim <= 20) FPV_HIP(launch_policy16_pack(weights, p->image16, p->in_dim, p->act_dim, (hipStream_t)stream));
 #endif
-    if (p->in_dim == 20 && p->act_dim == 4) FPV_HIP(launch_policy_split_pack(weights, p->split_image, (hipStream_t)stream));
+    if ((p->in_dim == 20 && p->act_dim == 4) || (p->in_dim == 12 && p->act_dim == 1))      // the widths the split kernels are built for
+        FPV_HIP(launch_policy_split_pack(weights, p->split_image, p->in_dim, p->act_dim, (hipStream_t)stream));
     return FPV_OK;
 }
 
@@ -651,12 +652,13 @@ int fpv_policy_forward(fpv_policy* p, const fpv_policy_io* io, void* stream) {
             return fail(FPV_ERR_ARG, "fpv_policy_forward: scatter needs the V net, scatter_t, scatter_d and a positive scatter_stride");
         sc = ScatterArgs{io->scatter_t, io->scatter_d, io->scatter_out, io->scatter_stride, io->scatter_scale};
     }
-    // the bf16-split kernel evaluates the hover widths' nets (both, or one: the rollout tail's V(s_T)) in 512-thread workgroups over
+    // the bf16-split kernels (built for the two tasks' widths, 20 -> 4 and 12 -> 1) evaluate the nets (both, or one: the rollout tail's V(s_T)) in 512-thread workgroups over
     // a host-side row count; any other request is served by the exact-fp32 kernel (its image is always packed)
-    if (p->gemm == 1 && p->in_dim == 20 && p->act_dim == 4 && !io->narrow && !io->n_dev && !sc.out) {
+    const bool hover_w = p->in_dim == 20 && p->act_dim == 4, yaw_w = p->in_dim == 12 && p->act_dim == 1;
+    if (p->gemm == 1 && (hover_w || yaw_w) && !io->narrow && !io->n_dev && !sc.out) {
         FPV_HIP(launch_policy_split_forward(p->split_image, io->obs, io->rms, io->eps_in, io->tick, io->obs_n, io->action,
                                             io->clipped, io->value, io->logp, io->eps_out, io->n, io->seed, io->id_offset,
-                                            io->clip_obs, io->eps_norm, io->deterministic, p->cus, nets, mg, (hipStream_t)stream));
+                                            io->clip_obs, io->eps_norm, io->deterministic, p->cus, nets, yaw_w ? 1 : 0, mg, (hipStream_t)stream));
         return FPV_OK;
     }
 #ifdef FPV_EXPERIMENTS
@@ -686,8 +688,8 @@ int fpv_rollout_step(fpv_env* e, fpv_policy* p, const fpv_policy_io* io, float* 
     if (e->cfg.num_envs % 256 != 0) return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: num_envs must be a multiple of 256");
     if (io->n != e->cfg.num_envs) return fail(FPV_ERR_ARG, "fpv_rollout_step: io->n must equal num_envs");
     const bool yaw = e->cfg.task == FPV_TASK_YAW;
-    if (p->in_dim != e->obs_words || p->act_dim != e->act_words || (p->gemm != 0 && !(p->gemm == 1 && !yaw)))
-        return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: policy widths must be the task's (%d / %d), gemm mode 0 (or 1, the bf16 split, for the hover task)",
+    if (p->in_dim != e->obs_words || p->act_dim != e->act_words || (p->gemm != 0 && p->gemm != 1))
+        return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: policy widths must be the task's (%d / %d), gemm mode 0 or 1 (the bf16 split)",
                     e->obs_words, e->act_words);
     if (io->eps_in || io->eps_out || io->deterministic || io->narrow || io->n_dev || io->scatter_out || (io->nets != 0 && io->nets != 3))
         return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: eps_in / eps_out / deterministic / narrow / n_dev / scatter / single nets are not served");
@@ -728,7 +730,7 @@ int fpv_rollout_step(fpv_env* e, fpv_policy* p, const fpv_policy_io* io, float* 
     a.mg_count = (double)e->cfg.num_envs;
     if (p->gemm == 1)
         FPV_HIP(launch_rollout_step_split(p->split_image, io->rms, io->obs_n, io->action, io->clipped, io->value, io->logp, io->seed,
-                                          io->id_offset, io->clip_obs, io->eps_norm, mg, a, e->stamps, (hipStream_t)stream));
+                                          io->id_offset, io->clip_obs, io->eps_norm, mg, a, yaw ? 1 : 0, e->stamps, (hipStream_t)stream));
     else
         FPV_HIP(launch_rollout_step(p->image, io->rms, io->obs_n, io->action, io->clipped, io->value, io->logp, io->seed, io->id_offset,
                                     io->clip_obs, io->eps_norm, mg, a, yaw ? 1 : 0, e->stamps, (hipStream_t)stream));

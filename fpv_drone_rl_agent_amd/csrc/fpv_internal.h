@@ -341,7 +341,7 @@ hipError_t launch_rollout_step(const float* image, const double* rms, float* obs
                                const MergeArgs& merge, const StepArgs<float>& st, int yaw, uint64_t* stamps, hipStream_t s);
 hipError_t launch_rollout_step_split(const unsigned char* image, const double* rms, float* obs_n, float* action, float* clipped, float* value,
                                      float* logp, uint64_t pol_seed, uint64_t pol_id_offset, float clip_obs, float eps_norm,
-                                     const MergeArgs& merge, const StepArgs<float>& st, uint64_t* stamps, hipStream_t s);
+                                     const MergeArgs& merge, const StepArgs<float>& st, int yaw, uint64_t* stamps, hipStream_t s);
 struct RollPersistHost {     // host-side description of a T-step launch (fpv_rollout_steps); fields as RollPersistArgs, fpv_rollstep.hip
     const float* image;
     uint64_t pol_seed, pol_id_offset;
@@ -370,11 +370,11 @@ hipError_t launch_adam_clip(float* param, const float* grad, float* exp_avg, flo
                             float* grad_norm, int64_t n, float lr, float beta1, float beta2, float eps, float max_norm,
                             hipStream_t s);
 // fpv_policy_split.hip
-hipError_t launch_policy_split_pack(const float* const* w, unsigned char* image, hipStream_t s);
+hipError_t launch_policy_split_pack(const float* const* w, unsigned char* image, int in_dim, int act_dim, hipStream_t s);
 hipError_t launch_policy_split_forward(const unsigned char* image, const float* obs, const double* rms, const float* eps_in,
                                        const uint64_t* tick, float* obs_n, float* action, float* clipped, float* value,
                                        float* logp, float* eps_out, int64_t n, uint64_t seed, uint64_t id_offset,
-                                       float clip_obs, float eps_norm, int deterministic, int max_blocks, int nets,
+                                       float clip_obs, float eps_norm, int deterministic, int max_blocks, int nets, int yaw_widths,
                                        const MergeArgs& merge, hipStream_t s);
 int policy_split_image_bytes();
 

@@ -132,32 +132,35 @@ struct SplitHidden {
 };
 
 // (layer 1 reads the image's W1 + bias block only, layer 2 W2 and the bias block: a caller may run layer 1 while W2 is on its way)
+// IN: observation words (20 hover, 12 yaw): lane half h supplies k = 12 h + j, j < 12, as far as k < IN (the image's W1 holds zeros beyond)
+template <int IN = kIn>
 __device__ __forceinline__ void split_net_layer1(const unsigned char* img, const float* nrm, float clip, const float* __restrict__ obs,
                                                  int64_t d, bool live, int lane, float* obs_n_out, f32x16 (&a)[4]) {
+    static_assert(IN % 4 == 0 && IN <= 24, "observation rows are whole 16-byte quads");
     const int h = lane >> 5;
     const bf16x8* w1img = reinterpret_cast<const bf16x8*>(img + kW2Bytes);
     const float* bias = reinterpret_cast<const float*>(img + kW2Bytes + kW1Bytes);
     // observation slice of this lane half (k = 12 h .. 12 h + 11), normalised
     float x[16];
     {
-        const f32x4* row = reinterpret_cast<const f32x4*>(obs + (live ? d : 0) * kIn);
+        const f32x4* row = reinterpret_cast<const f32x4*>(obs + (live ? d : 0) * IN);
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            const bool have = live && (h == 0 || q < 2);
+            const bool have = live && 12 * h + 4 * q < IN;
             const f32x4 v = have ? row[3 * h + q] : f32x4{0.f, 0.f, 0.f, 0.f};
             x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
         }
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
             const int k = 12 * h + j;
-            if (k < kIn) x[j] = fminf(fmaxf((x[j] - nrm[k]) * nrm[20 + k], -clip), clip);
+            if (k < IN) x[j] = fminf(fmaxf((x[j] - nrm[k]) * nrm[20 + k], -clip), clip);
         }
         x[12] = x[13] = x[14] = x[15] = 0.0f;
         if (obs_n_out && live) {                  // (the caller hands obs_n to ONE pass: the first net it evaluates)
-            f32x4* o = reinterpret_cast<f32x4*>(obs_n_out + d * kIn);
+            f32x4* o = reinterpret_cast<f32x4*>(obs_n_out + d * IN);
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-                if (h == 0 || q < 2) o[3 * h + q] = f32x4{x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+                if (12 * h + 4 * q < IN) o[3 * h + q] = f32x4{x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
         }
     }
     // ---- layer 1 (K = 20 padded to 32: two k-steps)
@@ -212,13 +215,16 @@ __device__ __forceinline__ void split_net_layer2(const unsigned char* img, int l
     for (int m = 0; m < 4; ++m) hd.c[m] = c[m];
 }
 
+template <int IN = kIn>
 __device__ __forceinline__ void split_net_hidden(const unsigned char* img, const float* nrm, float clip, const float* __restrict__ obs,
                                                  int64_t d, bool live, int lane, float* obs_n_out, SplitHidden& hd) {
     f32x16 a[4];
-    split_net_layer1(img, nrm, clip, obs, d, live, lane, obs_n_out, a);
+    split_net_layer1<IN>(img, nrm, clip, obs, d, live, lane, obs_n_out, a);
     split_net_layer2(img, lane, a, hd);
 }
 
+// ACT: action words (4 hover, 1 yaw; the head block holds zeros beyond)
+template <int ACT = 4>
 __device__ __forceinline__ f32x4 split_net_head(int net, const float* head, const SplitHidden& hd, int64_t d, bool live, int lane,
                                                 const SplitOut& out, const float* eps_in, uint64_t tick, bool deterministic,
                                                 uint64_t seed, uint64_t id_offset) {
@@ -264,8 +270,13 @@ __device__ __forceinline__ f32x4 split_net_head(int net, const float* head, cons
         float eps[4] = {0.f, 0.f, 0.f, 0.f};
         if (!deterministic) {
             if (eps_in) {
-                const f32x4 e = live ? reinterpret_cast<const f32x4*>(eps_in)[d] : f32x4{0.f, 0.f, 0.f, 0.f};
-                eps[0] = e.x; eps[1] = e.y; eps[2] = e.z; eps[3] = e.w;
+                if constexpr (ACT == 4) {
+                    const f32x4 e = live ? reinterpret_cast<const f32x4*>(eps_in)[d] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    eps[0] = e.x; eps[1] = e.y; eps[2] = e.z; eps[3] = e.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < ACT; ++j) eps[j] = live ? eps_in[d * ACT + j] : 0.f;
+                }
             } else {
                 uint32_t xr[4];
                 philox4x32_10((uint32_t)(id_offset + (uint64_t)d), (uint32_t)tick, (uint32_t)(tick >> 32), 0x504F4C31u,
@@ -282,17 +293,31 @@ __device__ __forceinline__ f32x4 split_net_head(int net, const float* head, cons
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             act[j] = __builtin_fmaf(head[652 + j], eps[j], mu[j]);      // (explicit fmas: the same instructions in every kernel this
-            lp = __builtin_fmaf(-0.5f * eps[j], eps[j], lp);             // function is inlined into, whatever contraction would choose)
+            if (j < ACT) lp = __builtin_fmaf(-0.5f * eps[j], eps[j], lp);   // function is inlined into, whatever contraction would choose)
         }
         cl = f32x4{fminf(fmaxf(act[0], -1.f), 1.f), fminf(fmaxf(act[1], -1.f), 1.f), fminf(fmaxf(act[2], -1.f), 1.f),
                    fminf(fmaxf(act[3], -1.f), 1.f)};
         if (live) {
             if (h == 0) {
-                if (out.action) reinterpret_cast<f32x4*>(out.action)[d] = f32x4{act[0], act[1], act[2], act[3]};
-                if (out.clipped) reinterpret_cast<f32x4*>(out.clipped)[d] = cl;
+                if constexpr (ACT == 4) {
+                    if (out.action) reinterpret_cast<f32x4*>(out.action)[d] = f32x4{act[0], act[1], act[2], act[3]};
+                    if (out.clipped) reinterpret_cast<f32x4*>(out.clipped)[d] = cl;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < ACT; ++j) {
+                        if (out.action) out.action[d * ACT + j] = act[j];
+                        if (out.clipped) out.clipped[d * ACT + j] = cl[j];
+                    }
+                }
             } else {
                 if (out.logp) out.logp[d] = lp;
-                if (out.eps_out) reinterpret_cast<f32x4*>(out.eps_out)[d] = f32x4{eps[0], eps[1], eps[2], eps[3]};
+                if constexpr (ACT == 4) {
+                    if (out.eps_out) reinterpret_cast<f32x4*>(out.eps_out)[d] = f32x4{eps[0], eps[1], eps[2], eps[3]};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < ACT; ++j)
+                        if (out.eps_out) out.eps_out[d * ACT + j] = eps[j];
+                }
             }
         }
     } else {
@@ -324,12 +349,13 @@ __device__ __forceinline__ f32x4 split_net_head(int net, const float* head, cons
     return cl;
 }
 
+template <int IN = kIn, int ACT = 4>
 __device__ __forceinline__ f32x4 split_net_row(int net, const unsigned char* img, const float* head, const float* nrm, float clip,
                                                const float* __restrict__ obs, int64_t d, bool live, int lane, const SplitOut& out,
                                                const float* eps_in, uint64_t tick, bool deterministic, uint64_t seed, uint64_t id_offset) {
     SplitHidden hd;
-    split_net_hidden(img, nrm, clip, obs, d, live, lane, out.obs_n, hd);
-    return split_net_head(net, head, hd, d, live, lane, out, eps_in, tick, deterministic, seed, id_offset);
+    split_net_hidden<IN>(img, nrm, clip, obs, d, live, lane, out.obs_n, hd);
+    return split_net_head<ACT>(net, head, hd, d, live, lane, out, eps_in, tick, deterministic, seed, id_offset);
 }
 
 // this net's split image -> LDS (all requests in flight before the first LDS write); THREADS = workgroup size.  In two halves for a

@@ -17,6 +17,7 @@ namespace fpv {
 struct SplitParams {
     const float *pi_w1, *pi_b1, *pi_w2, *pi_b2, *wa, *ba, *log_std;
     const float *vf_w1, *vf_b1, *vf_w2, *vf_b2, *wv, *bv;
+    int in_dim, act_dim;      // 20 / 4 hover, 12 / 1 yaw: W1's k and the action head's rows beyond them are zero in the image
 };
 
 __global__ void policy_split_pack_kernel(SplitParams p, unsigned char* __restrict__ img) {
@@ -38,7 +39,7 @@ __global__ void policy_split_pack_kernel(SplitParams p, unsigned char* __restric
             const int q = o - kW2Elems;
             const int j = q % 8, lane = (q / 8) % 64, part = (q / 512) % 3, s = (q / 1536) % 2, m = q / 3072;
             const int within = 8 * s + j, k = 12 * (lane >> 5) + within;
-            float w = (within < 12 && k < kIn) ? w1[(m * 32 + (lane & 31)) * kIn + k] : 0.0f;
+            float w = (within < 12 && k < p.in_dim) ? w1[(m * 32 + (lane & 31)) * p.in_dim + k] : 0.0f;
             if (FPV_SPLIT_TANH_FOLD) w *= kTanhPrescale;
             reinterpret_cast<__bf16*>(base + kW2Bytes)[q] = piece(w, part);
         } else {                                // biases in accumulator order [layer][m][h][r]
@@ -60,15 +61,15 @@ __global__ void policy_split_pack_kernel(SplitParams p, unsigned char* __restric
     float v = 0.0f;
     if (q < 512) {                              // Wa[h][kt][r][o]
         const int o = q % 4, r = (q / 4) % 16, kt = (q / 64) % 4, h = q / 256;
-        v = p.wa[o * 128 + kt * 32 + acc_row(r, h)];
+        v = o < p.act_dim ? p.wa[o * 128 + kt * 32 + acc_row(r, h)] : 0.0f;
         if (FPV_SPLIT_TANH_FOLD) v *= -2.0f;          // the heads consume r2
     } else if (q < 640) {
         const int z = q - 512, r = z % 16, kt = (z / 16) % 4, h = z / 64;
         v = p.wv[kt * 32 + acc_row(r, h)];
         if (FPV_SPLIT_TANH_FOLD) v *= -2.0f;
     } else if (q < 644) {
-        double b = (double)p.ba[q - 640];
-        if (FPV_SPLIT_TANH_FOLD)
+        double b = q - 640 < p.act_dim ? (double)p.ba[q - 640] : 0.0;
+        if (FPV_SPLIT_TANH_FOLD && q - 640 < p.act_dim)
             for (int k = 0; k < 128; ++k) b += (double)p.wa[(q - 640) * 128 + k];
         v = (float)b;
     } else if (q == 644) {
@@ -77,9 +78,12 @@ __global__ void policy_split_pack_kernel(SplitParams p, unsigned char* __restric
             for (int k = 0; k < 128; ++k) b += (double)p.wv[k];
         v = (float)b;
     }
-    else if (q >= 648 && q < 652) v = p.log_std[q - 648];
-    else if (q >= 652 && q < 656) v = expf(p.log_std[q - 652]);
-    else if (q == 656) v = -(p.log_std[0] + p.log_std[1] + p.log_std[2] + p.log_std[3]) - 2.0f * 1.8378770664093453f;
+    else if (q >= 648 && q < 652) v = q - 648 < p.act_dim ? p.log_std[q - 648] : 0.0f;
+    else if (q >= 652 && q < 656) v = q - 652 < p.act_dim ? expf(p.log_std[q - 652]) : 0.0f;
+    else if (q == 656) {                        // -sum log_std - act_dim * 0.5 ln 2 pi
+        if (p.act_dim == 4) v = -(p.log_std[0] + p.log_std[1] + p.log_std[2] + p.log_std[3]) - 2.0f * 1.8378770664093453f;
+        else for (int j = 0; j < p.act_dim; ++j) v -= p.log_std[j] + 0.5f * 1.8378770664093453f;
+    }
     reinterpret_cast<float*>(img + 2 * (size_t)kNetBytes)[q] = v;
 }
 
@@ -99,6 +103,7 @@ struct SplitArgs {
     MergeArgs mg;
 };
 
+template <int IN, int ACT>
 __global__ __launch_bounds__(kSplitThreads) void policy_split_forward_kernel(SplitArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float* head = reinterpret_cast<float*>(lds_raw + kNetBytes);            // kHeadFloats, then mean[20], inv[20]
@@ -113,9 +118,9 @@ __global__ __launch_bounds__(kSplitThreads) void policy_split_forward_kernel(Spl
         MergeRegs mr;
         merge_request(p.mg, mr);
         merge_prologue(p.mg, mr, p.rms, reinterpret_cast<double*>(nrm + 40), p.eps_norm, nrm, nrm + 20);
-    } else if (threadIdx.x < kIn) {
+    } else if (threadIdx.x < IN) {
         nrm[threadIdx.x] = p.rms ? (float)p.rms[threadIdx.x] : 0.0f;
-        nrm[20 + threadIdx.x] = p.rms ? (float)(1.0 / sqrt(p.rms[kIn + threadIdx.x] + (double)p.eps_norm)) : 1.0f;
+        nrm[20 + threadIdx.x] = p.rms ? (float)(1.0 / sqrt(p.rms[IN + threadIdx.x] + (double)p.eps_norm)) : 1.0f;
     }
 
 #pragma unroll 1
@@ -127,13 +132,13 @@ __global__ __launch_bounds__(kSplitThreads) void policy_split_forward_kernel(Spl
         const uint64_t tick = p.tick ? p.tick[0] : 0ull;
         for (int64_t base = (int64_t)blockIdx.x * kSplitDrones; base < p.n; base += (int64_t)gridDim.x * kSplitDrones) {
             const int64_t d = base + wave * 32 + col;
-            split_net_row(net, lds_raw, head, nrm, clip, p.obs, d, d < p.n, lane, out, p.eps_in, tick, p.deterministic != 0, p.seed, p.id_offset);
+            split_net_row<IN, ACT>(net, lds_raw, head, nrm, clip, p.obs, d, d < p.n, lane, out, p.eps_in, tick, p.deterministic != 0, p.seed, p.id_offset);
         }
     }
 }
 
-hipError_t launch_policy_split_pack(const float* const* w, unsigned char* image, hipStream_t s) {
-    SplitParams p{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12]};
+hipError_t launch_policy_split_pack(const float* const* w, unsigned char* image, int in_dim, int act_dim, hipStream_t s) {
+    SplitParams p{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], in_dim, act_dim};
     constexpr int elems = 2 * (kW2Bytes / 2 + kW1Bytes / 2 + 256) + kHeadFloats;
     hipLaunchKernelGGL(policy_split_pack_kernel, dim3((elems + 255) / 256), dim3(256), 0, s, p, image);
     return hipGetLastError();
@@ -142,15 +147,18 @@ hipError_t launch_policy_split_pack(const float* const* w, unsigned char* image,
 hipError_t launch_policy_split_forward(const unsigned char* image, const float* obs, const double* rms, const float* eps_in,
                                        const uint64_t* tick, float* obs_n, float* action, float* clipped, float* value,
                                        float* logp, float* eps_out, int64_t n, uint64_t seed, uint64_t id_offset,
-                                       float clip_obs, float eps_norm, int deterministic, int max_blocks, int nets,
+                                       float clip_obs, float eps_norm, int deterministic, int max_blocks, int nets, int yaw_widths,
                                        const MergeArgs& merge, hipStream_t s) {
     static bool attr_tab[64] = {};                    // hipFuncSetAttribute holds for one device: one flag per ordinal
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
     bool& attr_set = attr_tab[dev_ & 63];
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)policy_split_forward_kernel,
+        hipError_t e = hipFuncSetAttribute((const void*)policy_split_forward_kernel<kIn, 4>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLdsBytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)policy_split_forward_kernel<kYawObsWords, 1>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLdsBytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -158,7 +166,8 @@ hipError_t launch_policy_split_forward(const unsigned char* image, const float* 
                 n, seed, id_offset, clip_obs, eps_norm, deterministic, (nets & 1) ? 0 : 1, nets == 3 ? 2 : 1, merge};
     int64_t blocks = (n + kSplitDrones - 1) / kSplitDrones;
     if (blocks > max_blocks) blocks = max_blocks;
-    hipLaunchKernelGGL(policy_split_forward_kernel, dim3((unsigned)blocks), dim3(kSplitThreads), kSplitLdsBytes, s, p);
+    if (yaw_widths) hipLaunchKernelGGL((policy_split_forward_kernel<kYawObsWords, 1>), dim3((unsigned)blocks), dim3(kSplitThreads), kSplitLdsBytes, s, p);
+    else hipLaunchKernelGGL((policy_split_forward_kernel<kIn, 4>), dim3((unsigned)blocks), dim3(kSplitThreads), kSplitLdsBytes, s, p);
     return hipGetLastError();
 }
 

@@ -36,7 +36,7 @@ namespace fpv {
 
 struct RollStepArgs {
     // ---- policy side (fpv_policy_io)
-    const float* image;      // packed weights (kImageFloats), hover widths 20 / 4
+    const float* image;      // packed weights (kImageFloats; the split image for the split kernels), the task's widths (20 / 4 or 12 / 1)
     const double* rms;       // VecNormalize statistics BEFORE this launch's merge, or null
     float* obs_n;            // [n][20] normalised observation out (rollout buffer), may be null
     float* action;           // [n][4] sampled action, may be null
@@ -768,7 +768,9 @@ struct RollStepSplitArgs {
 constexpr int kRsSplitLdsBytes = (kRsPix + RsPix::kWords) * 4 > kSplitLdsBytes ? (kRsPix + RsPix::kWords) * 4 : kSplitLdsBytes;
 
 #pragma clang fp contract(fast)
+template <int TASK>                                    // 0: hover (20 -> 4), 1: yaw (12 -> 1; round 5)
 __global__ __launch_bounds__(512) void rollout_step_split_kernel(RollStepSplitArgs p) {
+    constexpr int IN = TASK == 0 ? kIn : kYawObsWords, ACT = TASK == 0 ? kAct : 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     unsigned char* lds_raw = reinterpret_cast<unsigned char*>(lds);
     float* head = reinterpret_cast<float*>(lds_raw + kNetBytes);            // kHeadFloats, then mean[20], inv[20]
@@ -783,9 +785,9 @@ __global__ __launch_bounds__(512) void rollout_step_split_kernel(RollStepSplitAr
         MergeRegs mr;
         merge_request(p.mg, mr);
         merge_prologue(p.mg, mr, p.rms, reinterpret_cast<double*>(nrm + 40), p.eps_norm, nrm, nrm + 20);
-    } else if ((int)threadIdx.x < kIn) {
+    } else if ((int)threadIdx.x < IN) {
         nrm[threadIdx.x] = p.rms ? (float)p.rms[threadIdx.x] : 0.0f;
-        nrm[20 + threadIdx.x] = p.rms ? (float)(1.0 / sqrt(p.rms[kIn + threadIdx.x] + (double)p.eps_norm)) : 1.0f;
+        nrm[20 + threadIdx.x] = p.rms ? (float)(1.0 / sqrt(p.rms[IN + threadIdx.x] + (double)p.eps_norm)) : 1.0f;
     }
     const int64_t d = (int64_t)blockIdx.x * 256 + wave * 32 + col;
     const uint64_t tick = p.st.tick[(int64_t)blockIdx.x * 4];       // this workgroup's own tile's copy (rollout_step_kernel)
@@ -802,24 +804,27 @@ __global__ __launch_bounds__(512) void rollout_step_split_kernel(RollStepSplitAr
         split_stage_commit(stage, lds_raw);
         __syncthreads();                               // pi's image, the head block and the normaliser are in LDS
         RSS_STAMP(1);
-        split_net_hidden(lds_raw, nrm, clip, p.st.obs, d, d < p.st.n, lane, p.obs_n, hd);
-        cl = split_net_head(0, head, hd, d, d < p.st.n, lane, out, nullptr, tick, false, p.pol_seed, p.pol_id_offset);
+        split_net_hidden<IN>(lds_raw, nrm, clip, p.st.obs, d, d < p.st.n, lane, p.obs_n, hd);
+        cl = split_net_head<ACT>(0, head, hd, d, d < p.st.n, lane, out, nullptr, tick, false, p.pol_seed, p.pol_id_offset);
         __syncthreads();                               // every wave is done with pi's image
         split_stage_request(p.image, 1, stage);
         split_stage_commit(stage, lds_raw);
         __syncthreads();
-        split_net_hidden(lds_raw, nrm, clip, p.st.obs, d, d < p.st.n, lane, nullptr, hd);
-        (void)split_net_head(1, head, hd, d, d < p.st.n, lane, out, nullptr, tick, false, p.pol_seed, p.pol_id_offset);
+        split_net_hidden<IN>(lds_raw, nrm, clip, p.st.obs, d, d < p.st.n, lane, nullptr, hd);
+        (void)split_net_head<ACT>(1, head, hd, d, d < p.st.n, lane, out, nullptr, tick, false, p.pol_seed, p.pol_id_offset);
     }
     TileRegs tr;
-    rs_load_tile(p.st, tr);
+    YawTileRegs ytr;
+    if constexpr (TASK == 0) rs_load_tile(p.st, tr);
+    else rs_load_tile_yaw(p.st, ytr);
     lds_barrier();                                     // every wave is done with the image: its space is free
     RSS_STAMP(2);
     if (lane < 32) reinterpret_cast<f32x4*>(lds + kRsAct)[wave * 32 + lane] = cl;
     lds_barrier();
     const TailOut to{p.st.reward, p.st.terminated, p.st.truncated, p.st.done, p.st.partials, true, false, true,
                      p.stamps ? p.stamps + (int64_t)blockIdx.x * kStampStride + 4 : nullptr};
-    rs_tail(p.st, lds, tr, to);
+    if constexpr (TASK == 0) rs_tail(p.st, lds, tr, to);
+    else rs_tail_yaw(p.st, lds, ytr, to);
     RSS_STAMP(3);
 #undef RSS_STAMP
 }
@@ -1122,18 +1127,21 @@ hipError_t launch_rollout_step(const float* image, const double* rms, float* obs
 
 hipError_t launch_rollout_step_split(const unsigned char* image, const double* rms, float* obs_n, float* action, float* clipped, float* value,
                                      float* logp, uint64_t pol_seed, uint64_t pol_id_offset, float clip_obs, float eps_norm,
-                                     const MergeArgs& merge, const StepArgs<float>& st, uint64_t* stamps, hipStream_t s) {
+                                     const MergeArgs& merge, const StepArgs<float>& st, int yaw, uint64_t* stamps, hipStream_t s) {
     static bool attr_tab[64] = {};                    // hipFuncSetAttribute holds for one device: one flag per ordinal
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
     bool& attr_set = attr_tab[dev_ & 63];
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)rollout_step_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kRsSplitLdsBytes);
+        hipError_t e = hipFuncSetAttribute((const void*)rollout_step_split_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kRsSplitLdsBytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)rollout_step_split_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kRsSplitLdsBytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     RollStepSplitArgs p{image, rms, obs_n, action, clipped, value, logp, pol_seed, pol_id_offset, clip_obs, eps_norm, merge, st, stamps};
-    hipLaunchKernelGGL(rollout_step_split_kernel, dim3((unsigned)(st.n / 256)), dim3(512), (size_t)kRsSplitLdsBytes, s, p);
+    if (yaw) hipLaunchKernelGGL(rollout_step_split_kernel<1>, dim3((unsigned)(st.n / 256)), dim3(512), (size_t)kRsSplitLdsBytes, s, p);
+    else hipLaunchKernelGGL(rollout_step_split_kernel<0>, dim3((unsigned)(st.n / 256)), dim3(512), (size_t)kRsSplitLdsBytes, s, p);
     return hipGetLastError();
 }
 

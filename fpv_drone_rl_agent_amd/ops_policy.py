@@ -45,8 +45,8 @@ class FusedPolicy:
             raise ValueError("gemm must be 'f32', 'bf16x6' or 'f32_w16'")
         if gemm == "f32_w16":
             L.require_experiments("policy_gemm='f32_w16' (the 16-wave policy kernel)")
-        if gemm == "bf16x6" and (self.obs_dim, self.act_dim) != (20, 4):
-            raise ValueError("the bf16 split kernel takes the hover task's widths (20 -> 4) only")
+        if gemm == "bf16x6" and (self.obs_dim, self.act_dim) not in ((20, 4), (12, 1)):
+            raise ValueError("the bf16 split kernels are built for the hover task's widths (20 -> 4) and the yaw task's (12 -> 1)")
         L.check(self.lib.fpv_policy_set_gemm(self._h, modes[gemm]), "fpv_policy_set_gemm")
         self.gemm = gemm
 

@@ -160,10 +160,10 @@ class RolloutCollector:
             self.env_rew = torch.zeros((T, N), dtype=torch.float64, device=dev)
         # policy_gemm=None, the default (round 5): the hidden 128 x 128 products of pi and V as 6-term bf16 splits with
         # fp32 accumulation ("bf16x6": every row at fp32 rounding level against an fp64 evaluation, tests/test_policy_gpu.py) wherever
-        # that kernel exists — the hover task's widths on the fused path; "f32" (exact fp32-input MFMA) stays selectable and is what the
-        # experiment shapes (persistent, overlap_critic) and the other widths run on
+        # that kernel exists — both tasks' widths on the fused path; "f32" (exact fp32-input MFMA) stays selectable and is what the
+        # experiment shapes (persistent, overlap_critic) and any other widths run on
         if policy_gemm is None:
-            policy_gemm = "bf16x6" if (fused and fused_policy and (O, A) == (20, 4) and not persistent and not overlap_critic) else "f32"
+            policy_gemm = "bf16x6" if (fused and fused_policy and (O, A) in ((20, 4), (12, 1)) and not persistent and not overlap_critic) else "f32"
         self.policy_gemm = policy_gemm
         self.fused = bool(fused)
         self._one_launch = self._one_launch_ok = False
@@ -199,14 +199,14 @@ class RolloutCollector:
             # bit-identical results.  Served for both tasks with motor noise, drone counts that are multiples of 256 up
             # to 256 x 1 024, the exact-fp32 policy, and the statistics merge in the launch prologue (or no normalisation).
             norm = self.norm_obs or self.norm_reward
-            # (hover also with policy_gemm="bf16x6": rollout_step_split_kernel)
-            self._one_launch_gemms = ("f32", "bf16x6") if engine.task == "hover" else ("f32",)
+            # (either arithmetic: rollout_step_kernel<TASK> / rollout_step_split_kernel<TASK>)
+            self._one_launch_gemms = ("f32", "bf16x6")
             can = (engine.noise_ratio > 0.0 and N % 256 == 0 and N // 256 <= 1024
                    and policy_gemm in self._one_launch_gemms and not self.overlap_critic and not self._merge_in_step
                    and (self._merge_in_policy or not norm))
             if one_launch and not can:
-                raise ValueError("one_launch needs motor noise, num_envs a multiple of 256 (<= 262 144), policy_gemm='f32' (or 'bf16x6' "
-                                 "for the hover task) and the default statistics-merge placement")
+                raise ValueError("one_launch needs motor noise, num_envs a multiple of 256 (<= 262 144), policy_gemm 'f32' or 'bf16x6' "
+                                 "and the default statistics-merge placement")
             # Default: where every workgroup finds a CU of its own (num_envs <= 256 x CUs).  Beyond that the second round of
             # workgroups stages the weight image again, while the two-kernel shape's policy kernel keeps it in LDS across its
             # chunks: measured 128.2 vs 126.3 us per step at 131 072 drones, 257.2 vs 234.9 at 262 144.

@@ -363,7 +363,8 @@ typedef struct {
 int fpv_policy_forward(fpv_policy* pol, const fpv_policy_io* io, void* stream);
 /* Hidden-layer GEMM arithmetic: 0 (default) = v_mfma_f32_32x32x2_f32, bit-exact fp32 fma chains; 1 = each fp32
  * operand cut into three bf16 pieces and the six piece products of order <= 4 summed on v_mfma_f32_32x32x16_bf16
- * in fp32 accumulators (error at the level of one fp32 rounding, 2.7x fewer matrix-pipe cycles); 2 = the arithmetic of
+ * in fp32 accumulators (error at the level of one fp32 rounding, 2.7x fewer matrix-pipe cycles; built for the two tasks'
+ * widths, 20 -> 4 and 12 -> 1 — a handle of other widths keeps answering with mode 0's kernel); 2 = the arithmetic of
  * mode 0 on v_mfma_f32_16x16x4_f32 with four waves per SIMD (fpv_policy_w16.hip) for the rollout's launch shape (both
  * nets, in-kernel sampling, no merge prologue): another summation order, so it agrees with mode 0 to rounding, not bit
  * for bit.  Kept as the measured alternative: it is not faster — vector instructions do not co-execute

@@ -98,13 +98,29 @@ def test_vecnormalize_matches_sb3_arithmetic_and_roundtrips(oracle, tmp_path):
     assert np.allclose(o, ref.reset(obs_ref), atol=1e-4)
     cfg = oracle.make_cfg(noise_ratio=0.0)
     rng = np.random.default_rng(1)
+    seen_terminal, t_got, t_want = 0, [], []
     for t in range(40):
         a = rng.uniform(-1, 1, (n, 4)).astype(np.float32)
         o, r, d, infos = venv.step(a)
-        o_raw, r_raw, te, tr, _ = oracle.step_batch(cfg, st, a.astype(np.float64), t)
+        led = oracle.Ledger(n)
+        o_raw, r_raw, te, tr, _ = oracle.step_batch(cfg, st, a.astype(np.float64), t, ledger=led)
         o_ref, r_ref = ref.step(o_raw, r_raw, (te | tr) > 0)
         parity.rows_close(o, o_ref, atol=2e-3, what=f"normalised obs, step {t}")
         parity.rows_close(r, r_ref, atol=1e-4, what=f"normalised reward, step {t}")
+        # SB3's VecNormalize.step_wait normalises infos[i]["terminal_observation"] with the statistics as they stand AFTER this
+        # step's update; here that happens on the device, inside the launch that packs the done ledger (fpv_ledger_pack)
+        for k, i in enumerate(led.rows()[0]):
+            seen_terminal += 1
+            keep = [j for j in range(20) if j not in parity.FEATURE_OBS]      # (one-pixel flips of the fp32 path aside)
+            got = infos[i]["terminal_observation"]
+            assert got.dtype == np.float32 and got.shape == (20,)
+            t_got.append(got[keep]); t_want.append(ref.normalize_obs(led.rows()[3][k])[keep])
+            assert set(infos[i]) >= {"terminal_observation", "TimeLimit.truncated", "episode", "out_of_bounds", "on_floor"}
+        for i in np.nonzero(~d)[0]:
+            assert infos[i] == {"out_of_bounds": False, "collision": False, "env_complete": False, "on_floor": False}
+    assert seen_terminal > 0
+    # (an fp32 trajectory of a tumbling drone leaves the fp64 one within tens of steps: a small share of the late episode ends may differ)
+    parity.rows_close(np.array(t_got), np.array(t_want), atol=5e-3, max_bad_frac=0.1, what="normalised terminal observations")
     path = os.path.join(tmp_path, "hover.pkl")            # train_hover.py:27 naming
     with pytest.raises(ValueError, match="pickle"):        # a .pkl path gets this build's npz archive only on request
         venv.save(path)

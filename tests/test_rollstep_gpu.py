@@ -136,9 +136,11 @@ def test_default_collector_takes_the_one_launch_path_where_served():
                 RolloutCollector(FpvEngine(4096, 0, detector="analytic"), _policy(), n_steps=4, **kw)
     from fpv_drone_rl_agent_amd.policy import ActorCritic
     yaw = RolloutCollector(FpvEngine(4096, 0, task="yaw"), ActorCritic(obs_dim=12, act_dim=1).cuda(), n_steps=4)
-    assert yaw._one_launch
-    with pytest.raises(ValueError):                       # the split kernel takes the hover widths only
-        yaw.set_policy_gemm("bf16x6")
+    assert yaw._one_launch and yaw.policy_gemm == "bf16x6"     # (round 5: the split kernels are built for the yaw widths too)
+    yaw.set_policy_gemm("f32"); assert yaw._one_launch
+    from fpv_drone_rl_agent_amd.ops_policy import FusedPolicy
+    with pytest.raises(ValueError):                       # other widths: the exact fp32-input MFMA only
+        FusedPolicy(ActorCritic(obs_dim=8, act_dim=2).cuda(), gemm="bf16x6")
     with pytest.raises(ValueError):
         RolloutCollector(FpvEngine(4000, 0), _policy(), n_steps=4, one_launch=True)
 
@@ -277,9 +279,11 @@ def test_persistent_rollout_gives_up_cleanly_when_a_grid_wait_times_out(oracle):
     assert col.episodes["count"] >= 0            # status words clean
 
 
-def test_yaw_task_one_launch_equals_policy_then_step():
+@pytest.mark.parametrize("gemm", ["f32", "bf16x6"])
+def test_yaw_task_one_launch_equals_policy_then_step(gemm):
     """The yaw task (12-word observations, one action, domain-randomised airframes, in-kernel Philox reset) through
-    fpv_rollout_step against fpv_policy_forward + fpv_step_fused: everything bit for bit over 60 steps with episode ends."""
+    fpv_rollout_step against fpv_policy_forward + fpv_step_fused: everything bit for bit over 60 steps with episode ends, on
+    either policy arithmetic (rollout_step_kernel<1> / rollout_step_split_kernel<1>)."""
     from fpv_drone_rl_agent_amd.engine import FpvEngine
     from fpv_drone_rl_agent_amd.ops_policy import FusedPolicy
     from fpv_drone_rl_agent_amd.policy import ActorCritic
@@ -288,7 +292,7 @@ def test_yaw_task_one_launch_equals_policy_then_step():
     pol = ActorCritic(obs_dim=12, act_dim=1).cuda()
     with torch.no_grad():
         pol.log_std.fill_(-0.2)
-    fp = FusedPolicy(pol, seed=17)
+    fp = FusedPolicy(pol, seed=17, gemm=gemm)
     engs = [FpvEngine(n, 0, seed=8, task="yaw", domain_rand=True, ledger_capacity=4 * n) for _ in range(2)]
     g = torch.Generator(device="cuda").manual_seed(2)
     steps0 = torch.randint(0, 401, (n,), device="cuda", generator=g).float()

@@ -114,7 +114,9 @@ def test_yaw_single_env_surface():
 
 
 @pytest.mark.gpu
-def test_yaw_fused_policy_matches_torch_and_collects():
+@pytest.mark.parametrize("gemm", ["f32", "bf16x6"])
+def test_yaw_fused_policy_matches_torch_and_collects(gemm):
+    import copy
     import torch
     from fpv_drone_rl_agent_amd.engine import FpvEngine
     from fpv_drone_rl_agent_amd.ops_policy import FusedPolicy
@@ -126,7 +128,7 @@ def test_yaw_fused_policy_matches_torch_and_collects():
         for p in m.parameters():
             if p.dim() == 1:
                 p.add_(torch.randn_like(p) * 0.3)
-    fp = FusedPolicy(m)
+    fp = FusedPolicy(m, gemm=gemm)
     n = 5000
     obs = torch.randn(n, 12, device="cuda")
     eps = torch.randn(n, 1, device="cuda")
@@ -140,10 +142,26 @@ def test_yaw_fused_policy_matches_torch_and_collects():
     assert torch.allclose(out["obs_n"], ref_obs, atol=1e-5) and torch.allclose(out["action"], a, atol=2e-4, rtol=1e-4)
     assert torch.allclose(out["value"], v, atol=2e-4, rtol=1e-4) and torch.allclose(out["logp"], lp, atol=1e-4)
     assert torch.equal(out["clipped"], out["action"].clamp(-1, 1))
-    # the collector picks the fused policy for the yaw task (stand-alone env / normaliser kernels) and stays finite
+    # every row against an fp64 evaluation of the module: fp32 rounding level on either arithmetic (the 6-term bf16 split at the
+    # yaw widths is the same chain as at the hover widths, with the observation's K padded from 12 and one head column in use)
+    m64 = copy.deepcopy(m).double()
+    big = torch.randn(65536, 12, device="cuda") * 2
+    with torch.no_grad():
+        mu64, v64 = m64.mean_value(big.double())
+    a1 = torch.zeros(65536, 1, device="cuda")
+    r = fp.forward(big, action=a1, deterministic=True)
+    assert float((a1.double() - mu64).abs().max()) <= 4e-6 * max(1.0, float(mu64.abs().max()))
+    assert float((r["value"].double() - v64).abs().max()) <= 1e-5
+    # nets = "pi" / "v" against the joint launch, bit for bit
+    o2 = {k: torch.zeros_like(t) for k, t in out.items() if k in ("obs_n", "action", "clipped")}
+    lp2 = torch.zeros(n, device="cuda")
+    fp.forward(obs, rms=rms, eps_in=eps, logp=lp2, nets="pi", **o2)
+    v2 = fp.forward(o2["obs_n"], nets="v", deterministic=True)["value"]
+    assert all(torch.equal(o2[k], out[k]) for k in o2) and torch.equal(lp2, out["logp"]) and torch.equal(v2, out["value"])
+    # the collector picks the fused policy for the yaw task (one launch per step) and stays finite
     eng = FpvEngine(2048, 0, task="yaw", domain_rand=True, ledger_capacity=8192)
-    col = RolloutCollector(eng, m, n_steps=16)
-    assert col.fused_policy and col.fused
+    col = RolloutCollector(eng, m, n_steps=16, policy_gemm=gemm)
+    assert col.fused_policy and col.fused and col._one_launch and col.policy_gemm == gemm
     b = col.collect()
     assert torch.isfinite(b["advantages"]).all() and torch.isfinite(b["returns"]).all() and float(b["adv_std"]) > 0
     eng.close()
