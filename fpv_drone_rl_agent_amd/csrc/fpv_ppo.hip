@@ -34,6 +34,12 @@ constexpr int kTImage = kTHead + kHeadFloats;
 constexpr int kPW1 = 0, kPB1 = 3072, kPW2 = 3200, kPB2 = 19584, kPWh = 19712, kPBh = 20224, kPartStride = 20232;
 constexpr int kFwdBwdThreads = FPV_PPO_THREADS;          // U1 workgroup: 256 = one wave per SIMD (512 measured slower: 175 vs 133 us)
 constexpr int kWaveStats = 8;                           // pg, vl, kl, clip fraction, d log_std[4]
+// W2 cut into bf16 pieces once per update for the one-kernel path (U0 writes it behind the training image's users): per net the
+// A operands of layer 2 (dir 0) and of its transpose on the way back (dir 1), [dir][k-step 8][tile 4][piece 3][lane 64] x 16 bytes
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kPieceStep = 4 * 3 * 64;                  // 16-byte words per k-step: four tiles x three pieces x 64 lanes (12 KB)
+constexpr int kPieceNet = 2 * 8 * kPieceStep;           // per net (192 KB)
+constexpr int kPieceFloats = 2 * kPieceNet * 4;         // both nets, in floats of workspace
 
 // Storage type of the activation / delta matrices that U1 hands to U2 through memory: float (default, exact) or bf16
 // (`fpv_ppo_io.storage = 1`).  The matrices are 4 KB per row in fp32 — U1 writes and U2 reads 268 MB per 65 536-row
@@ -85,6 +91,52 @@ __device__ __forceinline__ void load_tile(const bf16_bits* __restrict__ mat, int
     }
 }
 
+// ---- fp32 operands as three bf16 pieces (the 6-term split of fpv_policy_split.h, cut where the operand is used)
+typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
+struct Pieces { pbf16x8 p1, p2, p3; };
+__device__ __forceinline__ Pieces pieces_of(const float (&v)[8]) {
+    Pieces o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 a = (__bf16)v[j];
+        const float r1 = v[j] - (float)a;
+        const __bf16 b = (__bf16)r1;
+        o.p1[j] = a; o.p2[j] = b; o.p3[j] = (__bf16)(r1 - (float)b);
+    }
+    return o;
+}
+// TERMS = 6: every piece product down to 2^-24 of the product; TERMS = 3 (FPV_PPO_TWO_KERNELS_BF16X3, kept to have its error on
+// record): w2 x1 + w1 x2 + w1 x1 only — operands good to 16 bits, products to ~2^-16
+template <int TERMS>
+__device__ __forceinline__ f32x16 mfma6_pieces(const Pieces& w, const Pieces& x, f32x16 acc) {
+    if (TERMS == 6) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p3, x.p1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p1, x.p3, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p2, x.p2, acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p2, x.p1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p1, x.p2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p1, x.p1, acc, 0, 0, 0);
+    return acc;
+}
+
+// the same six products for four accumulator tiles that share x, piece by piece ACROSS the tiles: two products into one tile are
+// four apart in the instruction stream (the order per tile is mfma6_pieces<6>'s: the same bits)
+__device__ __forceinline__ void mfma6x4_pieces(const Pieces (&w)[4], const Pieces& x, f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[m].p3, x.p1, acc[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[m].p1, x.p3, acc[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[m].p2, x.p2, acc[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[m].p2, x.p1, acc[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[m].p1, x.p2, acc[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[m].p1, x.p1, acc[m], 0, 0, 0);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------- U0: training image
@@ -94,7 +146,26 @@ struct PpoParams {
     int in_dim, act_dim;
 };
 
-__global__ void ppo_pack_kernel(PpoParams p, float* __restrict__ img) {
+constexpr int kPackBlocks = (kTImage + 255) / 256;      // the training image; 2 * kPieceNet / (3 * 256) more workgroups cut W2 into pieces
+
+__global__ __launch_bounds__(256) void ppo_pack_kernel(PpoParams p, float* __restrict__ img, u32x4* __restrict__ pieces) {
+    if ((int)blockIdx.x >= kPackBlocks) {       // one thread per (net, dir, k-step, tile, lane): its eight fp32 weights -> 3 x 16 bytes
+        const int q = ((int)blockIdx.x - kPackBlocks) * 256 + (int)threadIdx.x;
+        const int lane = q & 63, m = (q >> 6) & 3, ks = (q >> 8) & 7, dir = (q >> 11) & 1, net = q >> 12;
+        const int col = lane & 31, h = lane >> 5;
+        const float* w2 = net ? p.vf_w2 : p.pi_w2;
+        float av[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3);          // the k-step's summation index held by this lane half
+            av[j] = dir == 0 ? w2[(32 * m + col) * kHid + k]                  // layer 2: A = row 32 m + col of W2
+                             : w2[k * kHid + 32 * m + col];                   // on the way back: A = column 32 m + col
+        }
+        const Pieces o = pieces_of(av);
+        u32x4* dst = pieces + (size_t)net * kPieceNet + ((dir * 8 + ks) * 4 + m) * 192 + lane;
+        dst[0] = (u32x4)o.p1; dst[64] = (u32x4)o.p2; dst[128] = (u32x4)o.p3;
+        return;
+    }
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= kTImage) return;
     float v = 0.0f;
@@ -566,34 +637,6 @@ __global__ __launch_bounds__(512) void ppo_wgrad_kernel(WgradArgs p) {
 // work split as above (wave w of a set: output rows 32 w .. of dW2 / dW1, columns 32 w .. of the head gradient), the two sets
 // take alternate 16-row groups, set 0 + set 1 through LDS, the same partial layout: U3 does not know which kernel ran.
 // fp32 storage only (a bf16-stored operand has one piece: that combination keeps the fp32-MFMA kernel).
-typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
-struct Pieces { pbf16x8 p1, p2, p3; };
-__device__ __forceinline__ Pieces pieces_of(const float (&v)[8]) {
-    Pieces o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const __bf16 a = (__bf16)v[j];
-        const float r1 = v[j] - (float)a;
-        const __bf16 b = (__bf16)r1;
-        o.p1[j] = a; o.p2[j] = b; o.p3[j] = (__bf16)(r1 - (float)b);
-    }
-    return o;
-}
-// TERMS = 6: every piece product down to 2^-24 of the product; TERMS = 3 (FPV_PPO_TWO_KERNELS_BF16X3, kept to have its error on
-// record): w2 x1 + w1 x2 + w1 x1 only — operands good to 16 bits, products to ~2^-16
-template <int TERMS>
-__device__ __forceinline__ f32x16 mfma6_pieces(const Pieces& w, const Pieces& x, f32x16 acc) {
-    if (TERMS == 6) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p3, x.p1, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p1, x.p3, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p2, x.p2, acc, 0, 0, 0);
-    }
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p2, x.p1, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p1, x.p2, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p1, x.p1, acc, 0, 0, 0);
-    return acc;
-}
-
 template <int TERMS>
 __global__ __launch_bounds__(512) void ppo_wgrad_split_kernel(WgradArgs p) {
     extern __shared__ __attribute__((aligned(16))) float xch[];     // [4 waves][99][64 lanes]
@@ -717,17 +760,17 @@ __global__ __launch_bounds__(512) void ppo_wgrad_split_kernel(WgradArgs p) {
 // order LDS traffic only.  The three 128 x 128 products per row — layer 2, its transpose on the way back, dW2 — run as 6-term bf16
 // splits of fp32 operands cut into pieces where they are used (fp32-level: the golden-vector error is the fp32 kernels'), everything
 // else on the fp32-input MFMA; no atomics: bitwise reproducible for a given launch shape.
-constexpr int kFRow = 132;                      // floats per row of the W2 image and of the staged matrix
-constexpr int kFOffB1 = 0, kFOffB2 = 128, kFOffW2 = 256, kFOffHead = kFOffW2 + kHid * kFRow;
+constexpr int kFRow = 132;                      // floats per row of the staged matrix
+constexpr int kFOffB1 = 0, kFOffB2 = 128, kFOffRing = 256, kFOffHead = kFOffRing + 2 * kPieceStep * 4;
 constexpr int kFOffX = (kFOffHead + kHeadFloats + 3) / 4 * 4;
 constexpr int kFOffDo = kFOffX + 128 * 24, kFOffM = kFOffDo + 128 * 4;
 constexpr int kFusedFloats = kFOffM + 128 * kFRow;
 static_assert(kFusedFloats * 4 <= 160 * 1024, "the fused PPO kernel's LDS image");
-static_assert(kFOffX % 4 == 0 && kFOffM % 4 == 0 && kFOffHead % 4 == 0, "16-byte rows");
+static_assert(kFOffX % 4 == 0 && kFOffM % 4 == 0 && kFOffHead % 4 == 0 && kFOffRing % 4 == 0, "16-byte rows");
 
 struct FusedArgs {
     const float* image;       // U0's training image: W1p, b1, b2 and the head block are taken from it
-    const float* w2[2];       // the live [128][128] second-layer weights of pi and V
+    const u32x4* pieces;      // U0's piece image of W2 (both nets, both directions)
     const int64_t* index;
     const float *obs, *actions, *old_logp, *adv, *ret;
     float* part;              // [2][slabs][kPartStride]
@@ -784,19 +827,41 @@ __global__ __launch_bounds__(256) void ppo_fused_kernel(FusedArgs p) {
     PPO_STAMP(0);
     const float* const img = p.image + (size_t)net * kTNet;
 
-    // ---- the net's image: b1 | b2 from U0's image, W2 from the live tensor, the head block
+    // ---- the net's image: b1 | b2 and the head block from U0's image
     {
         for (int g = threadIdx.x; g < kHid / 4; g += 256) {
             reinterpret_cast<f32x4*>(lds + kFOffB1)[g] = reinterpret_cast<const f32x4*>(img + kTOffB1)[g];
             reinterpret_cast<f32x4*>(lds + kFOffB2)[g] = reinterpret_cast<const f32x4*>(img + kTOffB2)[g];
         }
-        const f32x4* w2 = reinterpret_cast<const f32x4*>(p.w2[net]);
-#pragma unroll 4
-        for (int g = threadIdx.x; g < kHid * kHid / 4; g += 256)
-            *reinterpret_cast<f32x4*>(lds + kFOffW2 + (g >> 5) * kFRow + 4 * (g & 31)) = w2[g];
         for (int g = threadIdx.x; g < kHeadFloats / 4; g += 256)
             reinterpret_cast<f32x4*>(hb)[g] = reinterpret_cast<const f32x4*>(p.image + kTHead)[g];
     }
+    // ---- W2's pieces stream through a two-slot LDS ring, one k-step (12 KB: four tiles x three pieces) per slot: step t of a chunk
+    // (t = 0..7 layer 2, 8..15 the way back) is read from slot t & 1 by all four waves; wave w fetched its tile's quarter of step
+    // t + 1 from U0's piece image two steps ahead (registers G) and lays it down in the other slot while step t is multiplied; the
+    // barrier that ends a step publishes the slot and frees the one just read.  The stream is cyclic (step 16 = the next chunk's 0).
+    u32x4* const ring = reinterpret_cast<u32x4*>(lds + kFOffRing);
+    const u32x4* wstream = p.pieces + (size_t)net * kPieceNet + wave * 192 + lane;
+    u32x4 G[3];
+    auto stream_load = [&](int t) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) G[pc] = wstream[(t & 15) * kPieceStep + pc * 64];
+    };
+    auto ring_put = [&](int slot) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) ring[slot * kPieceStep + (wave * 3 + pc) * 64 + lane] = G[pc];
+    };
+    auto ring_get = [&](int slot, Pieces (&w)[4]) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            w[m].p1 = (pbf16x8)ring[slot * kPieceStep + (m * 3 + 0) * 64 + lane];
+            w[m].p2 = (pbf16x8)ring[slot * kPieceStep + (m * 3 + 1) * 64 + lane];
+            w[m].p3 = (pbf16x8)ring[slot * kPieceStep + (m * 3 + 2) * 64 + lane];
+        }
+    };
+    stream_load(0);
+    ring_put(0);
+    stream_load(1);
     // W1's A operands: the same for every chunk, but 48 registers are not to be had across a chunk: read again per chunk (the
     // opaque zero keeps the reads inside the loop), during the previous chunk's last products
     float w1r[48];
@@ -839,6 +904,11 @@ __global__ __launch_bounds__(256) void ppo_fused_kernel(FusedArgs p) {
         // ================================================================ phase A: this wave's 32 rows (as ppo_fwd_bwd_kernel)
         const int64_t n = base + srow;
         [[maybe_unused]] const int ck = 4 + 16 * (int)((base - n0) >> 7);
+        {                                                        // (the stream's addresses repeat chunk after chunk: an opaque zero keeps
+            int zero;                                            // its reads inside the loop, as for W1 below)
+            asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+            wstream = p.pieces + (size_t)net * kPieceNet + wave * 192 + lane + zero;
+        }
         const bool live = n < n1;
         const int64_t src = src_next;
         // the row's other inputs: asked for now, used after the forward (a gathered row is an HBM miss)
@@ -874,21 +944,18 @@ __global__ __launch_bounds__(256) void ppo_fused_kernel(FusedArgs p) {
         bias_init(c, lds + kFOffB2, h);
         {
             // layer 2 on the bf16 pipe: k-step (kt, sp) sums over hidden units 32 kt + 16 sp + 8 (j >> 2) + 4 h + (j & 3), j = 0..7 — what
-            // registers 8 sp .. 8 sp + 7 of accumulator tile kt hold in lane half h.  B = those eight values of H1, A = the same eight
-            // columns of W2's row 32 m + col (two 16-byte reads); both are cut into three bf16 pieces HERE (LDS has no room for W2 as
-            // pieces), six piece products: fp32-level results at 6/16 of the matrix cycles, paid for with ~7.5 vector instructions per
-            // product (the cut).  Laying the cut out one fragment ahead of its products and interleaving them by scheduling groups was
-            // measured: the same time, and on the way back (four tile sets live) slower for its registers.
-            const float* wrow = lds + kFOffW2 + col * kFRow + 4 * h;
+            // registers 8 sp .. 8 sp + 7 of accumulator tile kt hold in lane half h.  B = those eight values of H1, cut into three bf16
+            // pieces here; A = the same eight columns of W2's row 32 m + col, already in pieces (U0's piece image, through the ring):
+            // six piece products per tile, issued piece by piece across the four tiles — fp32-level results at 6/16 of the matrix
+            // cycles.  (Until round 5 W2 lay in LDS as fp32 and every wave cut its A operands again per chunk: 64 cuts of eight values
+            // per wave and chunk, more vector work than everything else in the chunk together.)
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 const int kt = ks >> 1, sp = ks & 1;
-                f32x4 lo[4], hi[4];
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    lo[m] = *reinterpret_cast<const f32x4*>(wrow + 32 * m * kFRow + 16 * ks);
-                    hi[m] = *reinterpret_cast<const f32x4*>(wrow + 32 * m * kFRow + 16 * ks + 8);
-                }
+                Pieces wa[4];
+                ring_get(ks & 1, wa);
+                ring_put((ks + 1) & 1);
+                stream_load(ks + 2);
                 float bv[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) bv[j] = a.t[kt][8 * sp + j];
@@ -897,12 +964,8 @@ __global__ __launch_bounds__(256) void ppo_fused_kernel(FusedArgs p) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) a.t[kt + 1][8 * sp + j] = fast_tanh(a.t[kt + 1][8 * sp + j]);
                 }
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const float av[8] = {lo[m].x, lo[m].y, lo[m].z, lo[m].w, hi[m].x, hi[m].y, hi[m].z, hi[m].w};
-                    c.t[m] = mfma6_pieces<6>(pieces_of(av), pb, c.t[m]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                mfma6x4_pieces(wa, pb, c.t);
+                lds_barrier();
             }
         }
         PPO_STAMP(ck + 0);
@@ -994,23 +1057,20 @@ __global__ __launch_bounds__(256) void ppo_fused_kernel(FusedArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) e.t[m][r] = 0.f;
         {
-            // the same on the way back: A = column 32 m + col of W2 at the k-step's eight rows (eight dword reads), B = D2
-            const float* wcol = lds + kFOffW2 + 4 * h * kFRow + col;
+            // the same on the way back: A = column 32 m + col of W2 at the k-step's eight rows (steps 8..15 of the stream), B = D2
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 const int kt = ks >> 1, sp = ks & 1;
-                float av[4][8];
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) av[m][j] = wcol[(16 * ks + 8 * (j >> 2) + (j & 3)) * kFRow + 32 * m];
+                Pieces wa[4];
+                ring_get(ks & 1, wa);
+                ring_put((ks + 1) & 1);
+                stream_load(8 + ks + 2);
                 float bv[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) bv[j] = g.t[kt][8 * sp + j];
                 const Pieces pb = pieces_of(bv);
-#pragma unroll
-                for (int m = 0; m < 4; ++m) e.t[m] = mfma6_pieces<6>(pieces_of(av[m]), pb, e.t[m]);
-                __builtin_amdgcn_sched_barrier(0);
+                mfma6x4_pieces(wa, pb, e.t);
+                lds_barrier();
             }
         }
 #pragma unroll
@@ -1394,7 +1454,7 @@ int64_t ppo_workspace_floats(int64_t rows, int cus) {
     const int two = ppo_slabs(rows, &rps), one = ppo_fused_slabs(rows, cus, &frps);
     const int slabs = two > one ? two : one;                     // the partial blocks of whichever path writes more (cus > 256: the one-kernel path)
     return (int64_t)kTImage + 8 * rows * kHid + rows * 24 + rows * 4 + rows + ppo_stat_waves(rows, cus) * kWaveStats +
-           2 * (int64_t)slabs * kPartStride + 64;
+           kPieceFloats + 2 * (int64_t)slabs * kPartStride + 64;
 }
 
 template <typename ST>
@@ -1435,14 +1495,15 @@ static hipError_t launch_ppo_grad_t(const float* const* w, float* const* grads, 
     float* dmu = xg + rows * 24;
     float* dv = dmu + rows * 4;
     float* wave_stats = dv + (rows + 3) / 4 * 4;
-    float* part = wave_stats + (size_t)ppo_stat_waves(rows, cus) * kWaveStats;
+    u32x4* pieces = reinterpret_cast<u32x4*>(wave_stats + (size_t)ppo_stat_waves(rows, cus) * kWaveStats);
+    float* part = reinterpret_cast<float*>(pieces) + kPieceFloats;
 
     PpoParams pp{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11], w[12], in_dim, act_dim};
-    hipLaunchKernelGGL(ppo_pack_kernel, dim3((kTImage + 255) / 256), dim3(256), 0, s, pp, image);
+    hipLaunchKernelGGL(ppo_pack_kernel, dim3(kPackBlocks + 2 * kPieceNet / (3 * 256)), dim3(256), 0, s, pp, image, pieces);
     if (path == FPV_PPO_ONE_KERNEL && sizeof(ST) == 4) {
         int frps;
         const int fslabs = ppo_fused_slabs(rows, cus, &frps);
-        FusedArgs f{image, {w[2], w[9]}, index, obs, actions, old_logp, adv, ret, part, wave_stats,
+        FusedArgs f{image, pieces, index, obs, actions, old_logp, adv, ret, part, wave_stats,
                     rows, clip_range, vf_coef, 1.0f / (float)rows, frps, fslabs, in_dim, act_dim};
         hipLaunchKernelGGL(ppo_fused_kernel, dim3(fslabs, 2), dim3(256), kFusedFloats * sizeof(float), s, f);
         ReduceArgs r{part, wave_stats, {}, stats, fslabs, 2 * fslabs * 4, in_dim, act_dim, 1.0f / (float)rows, ent_coef};
