@@ -137,6 +137,22 @@ __device__ __forceinline__ void mfma6x4_pieces(const Pieces (&w)[4], const Piece
     for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[m].p1, x.p1, acc[m], 0, 0, 0);
 }
 
+// ... and for four tiles that share w
+__device__ __forceinline__ void mfma6x4_pieces_b(const Pieces& w, const Pieces (&x)[4], f32x16 (&acc)[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p3, x[m].p1, acc[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p1, x[m].p3, acc[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p2, x[m].p2, acc[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p2, x[m].p1, acc[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p1, x[m].p2, acc[m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.p1, x[m].p1, acc[m], 0, 0, 0);
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------- U0: training image
@@ -764,7 +780,9 @@ constexpr int kFRow = 132;                      // floats per row of the staged 
 constexpr int kFOffB1 = 0, kFOffB2 = 128, kFOffRing = 256, kFOffHead = kFOffRing + 2 * kPieceStep * 4;
 constexpr int kFOffX = (kFOffHead + kHeadFloats + 3) / 4 * 4;
 constexpr int kFOffDo = kFOffX + 128 * 24, kFOffM = kFOffDo + 128 * 4;
-constexpr int kFusedFloats = kFOffM + 128 * kFRow;
+constexpr int kH1PieceBytes = 128 * 256;         // one piece of the chunk's H1 as bf16, 256-byte rows
+constexpr int kFusedFloats = kFOffM + 3 * kH1PieceBytes / 4;    // the staged matrix [128][132] fp32 lies in the same place at other times
+static_assert(128 * kFRow <= 3 * kH1PieceBytes / 4, "the fp32 matrix fits into the piece image's room");
 static_assert(kFusedFloats * 4 <= 160 * 1024, "the fused PPO kernel's LDS image");
 static_assert(kFOffX % 4 == 0 && kFOffM % 4 == 0 && kFOffHead % 4 == 0 && kFOffRing % 4 == 0, "16-byte rows");
 
@@ -942,6 +960,7 @@ __global__ __launch_bounds__(256) void ppo_fused_kernel(FusedArgs p) {
         for (int r = 0; r < 16; ++r) a.t[0][r] = fast_tanh(a.t[0][r]);
         Hidden c;
         bias_init(c, lds + kFOffB2, h);
+        PPO_STAMP(ck + 15);                                      // (layer 1 is behind us)
         {
             // layer 2 on the bf16 pipe: k-step (kt, sp) sums over hidden units 32 kt + 16 sp + 8 (j >> 2) + 4 h + (j & 3), j = 0..7 — what
             // registers 8 sp .. 8 sp + 7 of accumulator tile kt hold in lane half h.  B = those eight values of H1, cut into three bf16
@@ -1151,28 +1170,74 @@ __global__ __launch_bounds__(256) void ppo_fused_kernel(FusedArgs p) {
         }
         PPO_STAMP(ck + 8);
         lds_barrier();
-        stage_tile_rows(M, srow, a, h);                          // H1 of the chunk
+        {
+            // H1 of the chunk as bf16 PIECES, row-major [piece][chunk row][128 units] with 256-byte rows: the cut is made once, by the
+            // wave that holds the row (eight cuts; each wave used to cut all of H1 again for its own products, 32 cuts), and dW2's B
+            // operand — eight ROWS of one unit per lane — comes back through ds_read_b64_tr_b16, which hands a lane four rows of one
+            // column out of four 8-byte row segments.  16-byte chunk ch of row r lies at 256 r + 16 (ch ^ ((r & 3) << 2 | (r >> 2) & 3)):
+            // the transposed reads (one 32-lane half = 4 rows x 64 bytes) fall on 64 banks; the 8-byte writes of 16 rows are 2-way.
+            unsigned char* const HP = reinterpret_cast<unsigned char*>(M);
+            int fr = ((srow & 3) << 2) | ((srow >> 2) & 3);
+            asm volatile("" : "+v"(fr));                         // (formed here, not ahead of the chunk loop: 16 addresses would be spilled)
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const int kt = ks >> 1, sp = ks & 1;
+                float bv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    bv[j] = a.t[kt][8 * sp + j];
+                    asm volatile("" : "+v"(bv[j]));              // cut again: kept from the forward pass, the 96 piece registers went to scratch
+                }
+                const Pieces pv = pieces_of(bv);
+                const u32x4 q1 = (u32x4)pv.p1, q2 = (u32x4)pv.p2, q3 = (u32x4)pv.p3;
+                // j = 0..3: units 16 ks + 4 h + 0..3 (chunk 2 ks, bytes 8 h ..); j = 4..7: units 16 ks + 8 + 4 h + 0..3 (chunk 2 ks + 1)
+                unsigned char* w0 = HP + 256 * srow + 16 * ((2 * ks) ^ fr) + 8 * h;
+                unsigned char* w1 = HP + 256 * srow + 16 * ((2 * ks + 1) ^ fr) + 8 * h;
+                *reinterpret_cast<uint2*>(w0) = uint2{q1.x, q1.y}; *reinterpret_cast<uint2*>(w1) = uint2{q1.z, q1.w};
+                *reinterpret_cast<uint2*>(w0 + kH1PieceBytes) = uint2{q2.x, q2.y}; *reinterpret_cast<uint2*>(w1 + kH1PieceBytes) = uint2{q2.z, q2.w};
+                *reinterpret_cast<uint2*>(w0 + 2 * kH1PieceBytes) = uint2{q3.x, q3.y}; *reinterpret_cast<uint2*>(w1 + 2 * kH1PieceBytes) = uint2{q3.z, q3.w};
+            }
+        }
         PPO_STAMP(ck + 9);
         lds_barrier();
         PPO_STAMP(ck + 10);
         {                                                        // dW2 += D2^T H1, six piece products per product (as layer 2 above)
-            struct Grp { float b[4][8]; };
-            const float* B = M + 8 * kk * kFRow + i;
+            // lane l of a 16-lane group: q = (l & 15) >> 2 names the block's row, pp = l & 3 its 8-byte segment; the block = rows
+            // 16 S + 8 kk + 4 half + 0..3, units 32 jt + 16 gb + 0..15 (gb = the group's parity): element q of the result is row q of
+            // unit 32 jt + (l & 31).  With the row's swizzle f = 4 q + 2 kk + half the chunk index is ((jt ^ q) << 2) | (2 gb + (pp >> 1)) ^ (2 kk + half).
+            typedef __bf16 pbf16x4 __attribute__((ext_vector_type(4)));
+            typedef pbf16x4 __attribute__((address_space(3))) * lds_b4_ptr;
+            const int pp = lane & 3, gb = (lane >> 4) & 1;
+            int qq = (lane & 15) >> 2, lo0 = (2 * gb + (pp >> 1)) ^ (2 * kk);
+            asm volatile("" : "+v"(qq), "+v"(lo0));
+            int opaque0;                                         // (keeps the 192 read addresses from being formed ahead of the chunk loop and spilled)
+            asm volatile("s_mov_b32 %0, 0" : "=s"(opaque0));
+            const unsigned hp0 = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)(M)) + 256 * (8 * kk + qq) + 8 * (pp & 1) + opaque0;
+            struct Grp { Pieces b[4]; };
             auto load = [&](Grp& o, int S) {
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt)
+                for (int jt = 0; jt < 4; ++jt) {
+                    pbf16x4 v[3][2];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) o.b[jt][j] = B[(16 * S + j) * kFRow + 32 * jt];
+                    for (int half = 0; half < 2; ++half) {
+                        const unsigned ad = hp0 + 4096 * S + 1024 * half + 16 * ((((jt ^ qq) << 2)) | (lo0 ^ half));
+#pragma unroll
+                        for (int pc = 0; pc < 3; ++pc)
+                            v[pc][half] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_ptr)(size_t)(ad + pc * kH1PieceBytes));
+                    }
+                    o.b[jt].p1 = __builtin_shufflevector(v[0][0], v[0][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    o.b[jt].p2 = __builtin_shufflevector(v[1][0], v[1][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    o.b[jt].p3 = __builtin_shufflevector(v[2][0], v[2][1], 0, 1, 2, 3, 4, 5, 6, 7);
+                }
             };
             auto fma = [&](const Grp& o, int S) {
                 float t8[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) t8[j] = a2r[8 * S + j];
                 const Pieces pa = pieces_of(t8);
-#pragma unroll
-                for (int jt = 0; jt < 4; ++jt) w2s[jt] = mfma6_pieces<6>(pa, pieces_of(o.b[jt]), w2s[jt]);
+                mfma6x4_pieces_b(pa, o.b, w2s);
             };
-            Grp P, Q;
+            Grp P, Q;                                            // two register sets: step S + 1's reads are under way while step S is multiplied
             load(P, 0);
 #pragma unroll
             for (int S = 0; S < 8; S += 2) {

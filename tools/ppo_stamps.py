@@ -28,5 +28,6 @@ for wg in range(2):
         for c in range(4):
             ck = 4 + 16 * c
             prev = r[1] if c == 0 else r[ck - 16 + 14]
-            print("   chunk", c, " ".join("%.2f" % (r[ck + k] - (prev if k == 0 else r[ck + k - 1])) for k in range(15)))
+            print("   chunk", c, " ".join("%.2f" % (r[ck + k] - (prev if k == 0 else r[ck + k - 1])) for k in range(15)),
+                  "| of the first: until layer 1 is done %.2f, layer 2 %.2f" % (r[ck + 15] - prev, r[ck] - r[ck + 15]))
 print("columns:", "; ".join(names[:15]))
