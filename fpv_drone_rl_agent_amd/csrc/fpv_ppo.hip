@@ -898,7 +898,9 @@ __global__ __launch_bounds__(256) void ppo_fused_kernel(FusedArgs p) {
     for (int r = 0; r < 16; ++r) {
         w2s[0][r] = 0.f; w2s[1][r] = 0.f; w2s[2][r] = 0.f; w2s[3][r] = 0.f; w1s[r] = 0.f;
     }
-    float hd4[4] = {0.f, 0.f, 0.f, 0.f}, sb4[4] = {0.f, 0.f, 0.f, 0.f};      // head gradient of hidden unit 32 wave + i, head bias
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 hd01 = {0.f, 0.f}, hd23 = {0.f, 0.f};                  // head gradient of hidden unit 32 wave + i (outputs 0,1 and 2,3)
+    float sb4[4] = {0.f, 0.f, 0.f, 0.f};                         // head bias gradient: this lane's rows' d out (lane half 0 counts)
     float sb2 = 0.f, sb1 = 0.f;
     float* const M = lds + kFOffM;
     float* const XS = lds + kFOffX;
@@ -1068,7 +1070,11 @@ __global__ __launch_bounds__(256) void ppo_fused_kernel(FusedArgs p) {
         lds_barrier();
         PPO_STAMP(ck + 2);
         stage_tile_rows(M, srow, c, h);
-        if (h == 0) reinterpret_cast<f32x4*>(DO)[srow] = f32x4{dout[0], dout[1], dout[2], dout[3]};
+        if (h == 0) {
+            reinterpret_cast<f32x4*>(DO)[srow] = f32x4{dout[0], dout[1], dout[2], dout[3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sb4[j] += dout[j];
+        }
         // ---- dH1^T = W2^T . D2^T (the W2 column reads), D1 = dH1 (1 - H1^2)
         Hidden e;
 #pragma unroll
@@ -1134,11 +1140,12 @@ __global__ __launch_bounds__(256) void ppo_fused_kernel(FusedArgs p) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) { hh[u] = HH[2 * (s0 + u) * kFRow]; d[u] = DV[2 * (s0 + u)]; }
             };
-            auto use = [&](const float (&hh)[8], const f32x4 (&d)[8]) {
-#pragma unroll
+            auto use = [&](const float (&hh)[8], const f32x4 (&d)[8]) {      // two packed fmas per row (the head BIAS gradient is summed
+#pragma unroll                                                                        // row by row where d out is formed, not here)
                 for (int u = 0; u < 8; ++u) {
-                    hd4[0] += d[u].x * hh[u]; hd4[1] += d[u].y * hh[u]; hd4[2] += d[u].z * hh[u]; hd4[3] += d[u].w * hh[u];
-                    sb4[0] += d[u].x; sb4[1] += d[u].y; sb4[2] += d[u].z; sb4[3] += d[u].w;
+                    const f32x2 h2 = {hh[u], hh[u]};
+                    hd01 = __builtin_elementwise_fma(f32x2{d[u].x, d[u].y}, h2, hd01);
+                    hd23 = __builtin_elementwise_fma(f32x2{d[u].z, d[u].w}, h2, hd23);
                 }
             };
             load(hP, dP, 0);
@@ -1315,9 +1322,22 @@ __global__ __launch_bounds__(256) void ppo_fused_kernel(FusedArgs p) {
             for (int jt = 0; jt < 4; ++jt) out[kPW2 + o * kHid + 32 * jt + i] = w2s[jt][r];
             if (x_on) out[kPW1 + o * p.in_dim + i] = w1s[r];
         }
+        float hd4[4] = {hd01.x, hd01.y, hd23.x, hd23.y};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            hd4[j] = half_sum(hd4[j]); sb4[j] = half_sum(sb4[j]);
+            hd4[j] = half_sum(hd4[j]);
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) sb4[j] += __shfl_xor(sb4[j], off);      // over the wave's 32 rows (lane half 0)
+        }
+        // the four waves' head-bias sums, added in wave order by wave 0 (the staged-matrix room is free: every wave is past its last read)
+        __syncthreads();
+        if (lane == 0) reinterpret_cast<f32x4*>(M)[wave] = f32x4{sb4[0], sb4[1], sb4[2], sb4[3]};
+        __syncthreads();
+        if (wave == 0) {
+            const f32x4 s0 = reinterpret_cast<f32x4*>(M)[0], s1 = reinterpret_cast<f32x4*>(M)[1], s2 = reinterpret_cast<f32x4*>(M)[2],
+                        s3 = reinterpret_cast<f32x4*>(M)[3];
+            sb4[0] = ((s0.x + s1.x) + s2.x) + s3.x; sb4[1] = ((s0.y + s1.y) + s2.y) + s3.y;
+            sb4[2] = ((s0.z + s1.z) + s2.z) + s3.z; sb4[3] = ((s0.w + s1.w) + s2.w) + s3.w;
         }
         sb2 = half_sum(sb2); sb1 = half_sum(sb1);
         if (kk == 0) {
