@@ -1448,20 +1448,41 @@ __global__ __launch_bounds__(1024) void adam_clip_kernel(AdamArgs p) {
     __shared__ float red[16];
     __shared__ float bc[3];
     float ss[4] = {0.f, 0.f, 0.f, 0.f};
-    int64_t i = threadIdx.x;
-    for (; i + 3 * 1024 < p.n; i += 4 * 1024) {
-        const float g0 = p.grad[i], g1 = p.grad[i + 1024], g2 = p.grad[i + 2048], g3 = p.grad[i + 3072];
-        ss[0] += g0 * g0; ss[1] += g1 * g1; ss[2] += g2 * g2; ss[3] += g3 * g3;
-    }
-    for (; i < p.n; i += 1024) {
-        const float g = p.grad[i];
-        ss[0] += g * g;
+    constexpr int kPer = 40;                    // the policy's 39 049 parameters: every read of the gradient in flight at once (the
+    if (p.n <= (int64_t)kPer * 1024) {          // loop below waits for memory ten times in a row: 7 of the kernel's 8.8 us)
+        float g[kPer];
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const int64_t e = (int64_t)threadIdx.x + 1024 * q;
+            g[q] = e < p.n ? p.grad[e] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {        // the loop's order of additions: whole groups of four into ss[0..3], the rest into ss[0]
+            const bool whole = (int64_t)threadIdx.x + 4096 * (q >> 2) + 3072 < p.n;
+            const float sq = g[q] * g[q];
+            if ((q & 3) == 0) ss[0] += sq;      // (a zero for an element past the end)
+            else { ss[q & 3] += whole ? sq : 0.f; ss[0] += whole ? 0.f : sq; }
+        }
+    } else {
+        int64_t i = threadIdx.x;
+        for (; i + 3 * 1024 < p.n; i += 4 * 1024) {
+            const float g0 = p.grad[i], g1 = p.grad[i + 1024], g2 = p.grad[i + 2048], g3 = p.grad[i + 3072];
+            ss[0] += g0 * g0; ss[1] += g1 * g1; ss[2] += g2 * g2; ss[3] += g3 * g3;
+        }
+        for (; i < p.n; i += 1024) {
+            const float g = p.grad[i];
+            ss[0] += g * g;
+        }
     }
     float s = (ss[0] + ss[1]) + (ss[2] + ss[3]);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     const int64_t step = p.step[0] + 1;
+    // the two bias corrections do not wait for the norm: one lane of two other waves each takes a powf (a microsecond of one lane's
+    // dependent instructions apiece) while wave 0 sums
+    if (threadIdx.x == 64) bc[1] = p.lr / (1.0f - powf(p.beta1, (float)step));
+    if (threadIdx.x == 128) bc[2] = 1.0f / sqrtf(1.0f - powf(p.beta2, (float)step));
     __syncthreads();
     if (threadIdx.x == 0) {
         float t = 0.f;
@@ -1469,19 +1490,20 @@ __global__ __launch_bounds__(1024) void adam_clip_kernel(AdamArgs p) {
         const float norm = sqrtf(t);
         if (p.grad_norm && blockIdx.x == 0) *p.grad_norm = norm;
         bc[0] = p.max_norm > 0.f ? fminf(p.max_norm / (norm + 1e-6f), 1.0f) : 1.0f;
-        bc[1] = p.lr / (1.0f - powf(p.beta1, (float)step));
-        bc[2] = 1.0f / sqrtf(1.0f - powf(p.beta2, (float)step));
     }
+    // this thread's element: asked for before the barrier that publishes the clip factor
+    const int64_t k = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    float g_k = 0.f, m_k = 0.f, v_k = 0.f, p_k = 0.f;
+    if (k < p.n) { g_k = p.grad[k]; m_k = p.exp_avg[k]; v_k = p.exp_avg_sq[k]; p_k = p.param[k]; }
     __syncthreads();
     const float coef = bc[0], step_size = bc[1], inv_bc2 = bc[2];
-    const int64_t k = (int64_t)blockIdx.x * 1024 + threadIdx.x;
     if (k < p.n) {
-        const float g = p.grad[k] * coef;
-        const float m = p.beta1 * p.exp_avg[k] + (1.0f - p.beta1) * g;
-        const float v = p.beta2 * p.exp_avg_sq[k] + (1.0f - p.beta2) * g * g;
+        const float g = g_k * coef;
+        const float m = p.beta1 * m_k + (1.0f - p.beta1) * g;
+        const float v = p.beta2 * v_k + (1.0f - p.beta2) * g * g;
         p.exp_avg[k] = m;
         p.exp_avg_sq[k] = v;
-        p.param[k] -= step_size * m / (sqrtf(v) * inv_bc2 + p.eps);
+        p.param[k] = p_k - step_size * m / (sqrtf(v) * inv_bc2 + p.eps);
     }
     // every workgroup has read step[0] above; the one that arrives last publishes the new count
     __syncthreads();
