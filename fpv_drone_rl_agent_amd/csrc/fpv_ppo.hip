@@ -1376,12 +1376,30 @@ __global__ __launch_bounds__(256) void ppo_reduce_kernel(ReduceArgs p) {
     if (blockIdx.x == gridDim.x - 1) {          // statistics + d log_std: thread = (wave subset j, statistic k)
         const int k = threadIdx.x & 7, j = threadIdx.x >> 3;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int wv = j;
-        for (; wv + 96 < p.waves; wv += 128) {
-            s0 += p.wave_stats[(size_t)wv * kWaveStats + k]; s1 += p.wave_stats[(size_t)(wv + 32) * kWaveStats + k];
-            s2 += p.wave_stats[(size_t)(wv + 64) * kWaveStats + k]; s3 += p.wave_stats[(size_t)(wv + 96) * kWaveStats + k];
+        constexpr int kPer = 32;                 // 1 024 waves' statistics (256 workgroups of the one-kernel path): every read in flight at
+        if (p.waves <= 32 * kPer) {              // once — this workgroup's eight dependent rounds of reads were the kernel's duration
+            float v[kPer];
+#pragma unroll
+            for (int m = 0; m < kPer; ++m) {
+                const int wv = j + 32 * m;
+                v[m] = wv < p.waves ? p.wave_stats[(size_t)wv * kWaveStats + k] : 0.f;
+            }
+#pragma unroll
+            for (int m = 0; m < kPer; ++m) {     // the loop's order of additions: whole groups of four into s0..s3, the rest into s0
+                const bool whole = j + 128 * (m >> 2) + 96 < p.waves;
+                if ((m & 3) == 0) s0 += v[m];
+                else if ((m & 3) == 1) { s1 += whole ? v[m] : 0.f; s0 += whole ? 0.f : v[m]; }
+                else if ((m & 3) == 2) { s2 += whole ? v[m] : 0.f; s0 += whole ? 0.f : v[m]; }
+                else { s3 += whole ? v[m] : 0.f; s0 += whole ? 0.f : v[m]; }
+            }
+        } else {
+            int wv = j;
+            for (; wv + 96 < p.waves; wv += 128) {
+                s0 += p.wave_stats[(size_t)wv * kWaveStats + k]; s1 += p.wave_stats[(size_t)(wv + 32) * kWaveStats + k];
+                s2 += p.wave_stats[(size_t)(wv + 64) * kWaveStats + k]; s3 += p.wave_stats[(size_t)(wv + 96) * kWaveStats + k];
+            }
+            for (; wv < p.waves; wv += 32) s0 += p.wave_stats[(size_t)wv * kWaveStats + k];
         }
-        for (; wv < p.waves; wv += 32) s0 += p.wave_stats[(size_t)wv * kWaveStats + k];
         sm[k][j] = (s0 + s1) + (s2 + s3);
         __syncthreads();
         if (threadIdx.x < kWaveStats) {

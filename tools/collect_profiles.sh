@@ -10,6 +10,8 @@ last $O/bench_s20.json > profiles/${TAG}_bench_line_s20.json
 last $O/bench_analytic.json > profiles/${TAG}_bench_line_analytic.json
 last $O/bench_two.json > profiles/${TAG}_bench_line_two.json
 last $O/bench_yaw.json > profiles/${TAG}_bench_line_yaw.json
+[ -s $O/bench_yaw_f32.json ] && last $O/bench_yaw_f32.json > profiles/${TAG}_bench_line_yaw_exact_fp32_policy.json
+[ -s $O/ppo_ab.txt ] && { echo "# PPO update, 65 536-row minibatch, this build (default) against round 4's fpv_ppo.hip (ppo_v1) inside one call: tools/ab_ppo.sh"; cat $O/ppo_ab.txt; } > profiles/${TAG}_ppo_update_ab.txt
 last $O/bench_gpus2_gloo.json > profiles/${TAG}_bench_line_gpus2_gloo_one_gpu.json
 cp $O/phases_step.json profiles/${TAG}_rollout_step_phases.json
 cp $O/phases_step_analytic.json profiles/${TAG}_rollout_step_phases_analytic.json

@@ -16,6 +16,7 @@ python bench.py --policy-gemm f32 --steps 20 --warmup 5 --no-cpu-baseline --no-s
 python bench.py --detector analytic --no-cpu-baseline --no-split-extra --no-host-mode --no-f64-rollout > $O/bench_analytic.json 2> $O/bench_analytic.err
 python bench.py --two-launch --no-cpu-baseline --no-split-extra --no-host-mode --no-f64-rollout > $O/bench_two.json 2> $O/bench_two.err
 python bench.py --task yaw --no-cpu-baseline --no-host-mode > $O/bench_yaw.json 2> $O/bench_yaw.err
+python bench.py --task yaw --policy-gemm f32 --no-cpu-baseline --no-host-mode > $O/bench_yaw_f32.json 2> $O/bench_yaw_f32.err
 FPV_REHEARSE_RANKS=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29581 python bench.py --no-cpu-baseline --no-split-extra --no-host-mode --no-f64-rollout > $O/bench_rehearsed_ranks.json 2> $O/bench_rehearsed_ranks.err
 FPV_DIST_BACKEND=gloo python bench.py --gpus 2 --drones 32768 --steps 64 --warmup 32 --no-cpu-baseline --no-split-extra --no-host-mode --no-f64-rollout --repeats 3 > $O/bench_gpus2_gloo.json 2> $O/bench_gpus2_gloo.err
 python tools/rollout_phases.py > $O/phases_step.json 2> /dev/null
@@ -47,6 +48,8 @@ python tools/microbench_ppo.py 65536 524288 50 bf16 two_kernels >> $O/ppo_events
 python tools/microbench_ppo.py 262144 2097152 20 f32 one_kernel >> $O/ppo_events.json 2> /dev/null
 python tools/microbench_ppo.py 262144 2097152 20 f32 two_kernels >> $O/ppo_events.json 2> /dev/null
 bash tools/ppo_rows_sweep.sh > /dev/null 2>&1; cp gpurun_out/ppo_sweep/sweep.jsonl $O/ppo_rows_sweep.jsonl
+# the update against round 4's build (variants/ppo_v1.so: python -m fpv_drone_rl_agent_amd.build ppo_v1 on round 4's fpv_ppo.hip), same call
+if [ -f variants/ppo_v1.so ]; then bash tools/ab_ppo.sh ppo_v1 > $O/ppo_ab.txt 2>&1; fi
 # phase stamps of the one-kernel gradient: the diagnostic build (FPV_EXTRA_HIPCC_FLAGS=-DFPV_PPO_STAMPS=1, kept as variants/ppo_stamps.so)
 if [ -f variants/ppo_stamps.so ]; then
   FPV_LIB_VARIANT=ppo_stamps python tools/ppo_stamps.py > $O/ppo_stamps.txt 2> /dev/null
