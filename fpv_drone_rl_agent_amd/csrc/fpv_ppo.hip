@@ -2,6 +2,7 @@
 // simulation/train_hover.py:47-60) for the MlpPolicy of fpv_policy.hip, as hand-written gfx950 kernels:
 //
 //   U0 ppo_pack_kernel     live nn.Linear tensors -> MFMA-ordered training image (forward operands + W2^T, Wa^T)
+//                          and, for the one-kernel path, W2 cut into bf16 pieces as MFMA A fragments (both directions)
 //   U1 ppo_fwd_bwd_kernel  per row: pi and V forward, clipped-surrogate / value-loss derivatives, backward through the
 //                          heads and layer 2 — all in registers, transposed like the rollout kernel (drones on the MFMA
 //                          column, an accumulator tile is the next product's B operand as it stands, in both directions).
@@ -766,16 +767,18 @@ __global__ __launch_bounds__(512) void ppo_wgrad_split_kernel(WgradArgs p) {
 //            sets live, not four;
 //   phase B  the weight gradients of the chunk's 128 rows as in U2 — K = the row index, wave w owns output rows 32 w .. 32 w + 31 of
 //            dW2 and dW1 and columns 32 w .. of the head gradient — with the operands read from ONE row-major LDS matrix
-//            [128 rows][132] that all four waves fill together, four times: H2 (head gradient, with d out), D2 (each wave takes
-//            its 64 A operands into registers), H1 (dW2 += D2^T H1), D1 (with x: dW1 += D1^T x).  The transposition U2 got from
-//            the row-major matrices in memory is the LDS write here.
-// LDS holds W2 ONCE, row-major with 132-float rows: the forward reads four consecutive k of a row (one 16-byte read, as from the
-// packed image), the backward reads a column (consecutive lanes, consecutive addresses).  W1's 48 A operands per lane come from
-// U0's image in memory (the same for every chunk; asked for during the previous chunk's last products).  The partial sums of a
-// slab stay in registers over its rows and are written once, in U2's layout: U3 does not know which kernel ran.  The barriers
-// order LDS traffic only.  The three 128 x 128 products per row — layer 2, its transpose on the way back, dW2 — run as 6-term bf16
-// splits of fp32 operands cut into pieces where they are used (fp32-level: the golden-vector error is the fp32 kernels'), everything
-// else on the fp32-input MFMA; no atomics: bitwise reproducible for a given launch shape.
+//            [128 rows][132] that all four waves fill together, three times: H2 (head gradient, with d out), D2 (each wave takes
+//            its 64 A operands into registers), D1 (with x: dW1 += D1^T x); H1, dW2's B operand (dW2 += D2^T H1), is laid down
+//            in the same room as bf16 PIECES and read back transposed (ds_read_b64_tr_b16).  The transposition U2 got from the
+//            row-major matrices in memory is the LDS write (or that read) here.
+// W2 is not held in LDS: U0 cuts it once per update into a piece image (both directions' MFMA A fragments), and the kernel streams
+// that image through a two-slot ring, one k-step per slot (round 5; until then W2 lay in LDS as fp32 and every wave cut its
+// fragments again in every chunk).  W1's 48 A operands per lane come from U0's image in memory (the same for every chunk; asked
+// for during the previous chunk's last products).  The partial sums of a slab stay in registers over its rows and are written once,
+// in U2's layout: U3 does not know which kernel ran.  The barriers order LDS traffic only.  The three 128 x 128 products per row —
+// layer 2, its transpose on the way back, dW2 — run as 6-term bf16 splits of fp32 operands (fp32-level: the golden-vector error is
+// the fp32 kernels'): the weights' pieces from U0, H1's cut once per chunk by the wave that holds the row, a wave's own activations
+// and deltas cut where they are used; everything else on the fp32-input MFMA; no atomics: bitwise reproducible for a given launch shape.
 constexpr int kFRow = 132;                      // floats per row of the staged matrix
 constexpr int kFOffB1 = 0, kFOffB2 = 128, kFOffRing = 256, kFOffHead = kFOffRing + 2 * kPieceStep * 4;
 constexpr int kFOffX = (kFOffHead + kHeadFloats + 3) / 4 * 4;
