@@ -413,7 +413,8 @@ typedef struct {
     const float* weights[13];
     float* grads[13];
     float* stats;             /* [4] out: policy-gradient loss, value loss (MSE), approx KL, clip fraction */
-    void* workspace;          /* device scratch, >= fpv_ppo_workspace_bytes(rows), 16-byte aligned */
+    void* workspace;          /* device scratch, >= fpv_ppo_workspace_bytes(rows), 16-byte aligned (round 5: 384 KB more than   */
+                              /* before — the one-kernel path's image of W2 cut into bf16 pieces; ask again, do not cache a size) */
     int64_t workspace_bytes;
     int32_t storage;          /* what the two-kernel paths write between their kernels: 0 = fp32 words (default), 1 = bf16 —  */
                               /* half the HBM traffic of the update, gradients within ~1e-3 of their max-norm.  (A storage */
