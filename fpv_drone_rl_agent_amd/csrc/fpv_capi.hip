@@ -844,5 +844,12 @@ int fpv_adam_clip_step(float* param, const float* grad, float* exp_avg, float* e
     return FPV_OK;
 }
 
+int fpv_shuffle_indices(int64_t* out, int64_t n, uint64_t seed, uint64_t counter, void* stream) {
+    if (!out || n <= 0) return fail(FPV_ERR_ARG, "fpv_shuffle_indices: null argument or n <= 0");
+    if (n > ((int64_t)1 << 40)) return fail(FPV_ERR_UNSUPPORTED, "fpv_shuffle_indices: n <= 2^40");
+    FPV_HIP(launch_shuffle_indices(out, n, seed, counter, (hipStream_t)stream));
+    return FPV_OK;
+}
+
 }  // extern "C"
 #pragma GCC visibility pop

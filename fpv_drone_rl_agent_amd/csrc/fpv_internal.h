@@ -366,6 +366,7 @@ hipError_t launch_ppo_grad(const float* const* w, float* const* grads, const int
                            const float* actions, const float* old_logp, const float* adv, const float* ret, int64_t rows,
                            float clip_range, float vf_coef, float ent_coef, float* stats, float* ws, int in_dim, int act_dim,
                            int cus, int storage, int path, hipStream_t s);
+hipError_t launch_shuffle_indices(int64_t* out, int64_t n, uint64_t seed, uint64_t counter, hipStream_t s);
 hipError_t launch_adam_clip(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t* step,
                             float* grad_norm, int64_t n, float lr, float beta1, float beta2, float eps, float max_norm,
                             hipStream_t s);

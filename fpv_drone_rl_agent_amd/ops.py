@@ -198,6 +198,16 @@ def noop(device) -> None:
     L.check(L.load().fpv_noop(_stream(torch.device(device))), "fpv_noop")
 
 
+def shuffle_indices(out: torch.Tensor, seed: int, counter: int) -> torch.Tensor:
+    """out[i] = the i-th row of a PPO epoch's order: a permutation of 0..n-1 chosen by (seed, counter) (fpv_shuffle_indices: a keyed
+    bijection, one launch without memory reads — where torch.randperm sorts 2 x 10^6 random keys)."""
+    if out.dtype != torch.int64 or not out.is_contiguous() or not out.is_cuda or out.dim() != 1:
+        raise ValueError("shuffle_indices needs a contiguous 1-D int64 device tensor")
+    L.check(L.load().fpv_shuffle_indices(_ptr(out), out.numel(), C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint64(counter & (2 ** 64 - 1)),
+                                         _stream(out.device)), "fpv_shuffle_indices")
+    return out
+
+
 class FusedAdam:
     """clip_grad_norm_ + torch.optim.Adam.step() for ONE flat fp32 parameter tensor as a single launch
     (fpv_adam_clip_step).  state_dict() has torch.optim.Adam's shape ({"state": {0: {step, exp_avg, exp_avg_sq}},

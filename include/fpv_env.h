@@ -31,8 +31,8 @@ extern "C" {
  * (FPV_DETECTOR_PIXEL = 0 is the default, debug hooks moved to fpv_env_debug.h); 3 = fpv_ledger_scan(status_out),
  * fpv_policy_io.scatter_*, the whole-rollout launch moved to fpv_env_experiments.h; 4 = round 4: fpv_ppo_io.reserved1 became
  * fpv_ppo_io.path (same layout; 0 now selects the one-kernel gradient), fpv_ppo_workspace_bytes covers every path; 5 = round 5:
- * fpv_ledger_pack and fpv_ledger_scan_finalize added (no layout changed). */
-#define FPV_ABI_VERSION 5
+ * fpv_ledger_pack and fpv_ledger_scan_finalize added (no layout changed); 6 = fpv_shuffle_indices added (no layout changed). */
+#define FPV_ABI_VERSION 6
 
 #define FPV_STATE_WORDS 36 /* docs/SPEC.md §2 canonical order */
 #define FPV_OBS_WORDS 20   /* simulation/hover.py:63-70 */
@@ -442,6 +442,12 @@ int fpv_ppo_grad(fpv_policy* pol, const fpv_ppo_io* io, void* stream);
 int fpv_adam_clip_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t* step,
                        float* grad_norm, int64_t n, float lr, float beta1, float beta2, float eps, float max_grad_norm,
                        void* stream);
+
+/* The row order of a PPO epoch (SB3 PPO.train draws np.random.permutation(buffer rows) per epoch — stable_baselines3's
+ * RolloutBuffer.get, the learner SURVEY §8(f) N1 puts in place of train_hover.py:47-60's): out[i], i = 0..n-1, is a permutation of
+ * 0..n-1 chosen by (seed, counter) — a keyed bijection (8-round Feistel network on the index bits with cycle walking), one thread per
+ * element, instead of a sort of random keys.  Every call with another counter gives another order; the same (seed, counter) the same. */
+int fpv_shuffle_indices(int64_t* out, int64_t n, uint64_t seed, uint64_t counter, void* stream);
 
 /* Diagnostic hooks (phase stamps, launch-shape switches, calibration launches) are declared in fpv_env_debug.h: they are not
  * part of the product interface. */

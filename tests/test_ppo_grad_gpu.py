@@ -294,3 +294,45 @@ def test_ppo_grad_paths_against_the_float64_golden_vector():
             assert eo <= 1e-4 and eo <= 3 * e32 + 2e-7, (other, n, e32, eo)
     print("golden errors (relative to each tensor's max-norm):",
           {k: max(v[0].values()) for k, v in errs.items()})
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 4096, 100000, 2097152, 3000001])
+def test_shuffle_indices_is_a_permutation_that_depends_on_the_key(n):
+    """fpv_shuffle_indices (the epoch's row order of the fused update): every index exactly once for powers of two and for sizes the
+    cycle walking has to fold; another counter or seed, another order; the same key, the same order."""
+    from fpv_drone_rl_agent_amd.ops import shuffle_indices
+    dev = torch.device("cuda:0")
+    a = shuffle_indices(torch.empty(n, dtype=torch.int64, device=dev), 1234, 1)
+    assert torch.equal(torch.sort(a).values, torch.arange(n, device=dev))
+    b = shuffle_indices(torch.empty(n, dtype=torch.int64, device=dev), 1234, 1)
+    assert torch.equal(a, b)
+    if n >= 4096:
+        c = shuffle_indices(torch.empty(n, dtype=torch.int64, device=dev), 1234, 2)
+        d = shuffle_indices(torch.empty(n, dtype=torch.int64, device=dev), 1235, 1)
+        for other in (c, d):
+            assert torch.equal(torch.sort(other).values, torch.arange(n, device=dev))
+            assert float((other == a).float().mean()) < 0.01                 # two orders agree in ~1/n of the places
+        assert float((a == torch.arange(n, device=dev)).float().mean()) < 0.01
+
+
+def test_shuffle_indices_mixes_the_buffer_layout():
+    """What minibatch SGD needs of the order: a minibatch (a contiguous slice of it) draws evenly from the rollout buffer's
+    (time, drone) layout and consecutive entries are unrelated.  2^21 rows as 32 steps x 65 536 drones, eight minibatches: each holds
+    each time step's rows and each drone block's rows within 5 standard deviations of the binomial expectation; the lag-1 correlation of
+    the order is that of independent draws; an element's position is independent of its value (rank correlation ~ 0)."""
+    from fpv_drone_rl_agent_amd.ops import shuffle_indices
+    dev = torch.device("cuda:0")
+    n, mbs = 1 << 21, 8
+    p = shuffle_indices(torch.empty(n, dtype=torch.int64, device=dev), 7, 3)
+    mb = n // mbs
+    for k in range(mbs):
+        sl = p[k * mb:(k + 1) * mb]
+        for bins, key in ((32, sl // 65536), (64, (sl % 65536) // 1024)):
+            cnt = torch.bincount(key, minlength=bins).double()
+            exp = mb / bins
+            assert float((cnt - exp).abs().max()) < 5 * (exp * (1 - 1 / bins)) ** 0.5, (k, bins)
+    x = p.double() / n - 0.5
+    lag1 = float((x[:-1] * x[1:]).mean() / x.var())
+    assert abs(lag1) < 5 / n ** 0.5, lag1
+    pos = torch.arange(n, device=dev).double() / n - 0.5
+    assert abs(float((x * pos).mean() / x.var())) < 5 / n ** 0.5

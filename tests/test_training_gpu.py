@@ -103,3 +103,30 @@ def test_splitk_linear_gradients_match_autograd():
         ((vb.square().sum() + lpb.sum()) / 16384).backward()
     for (n, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
         assert torch.allclose(pa.grad, pb.grad, rtol=2e-3, atol=2e-5), n
+
+
+def test_epoch_graph_equals_eager_minibatches_and_both_shuffles_run():
+    """The fused update replays ONE HIP graph per epoch (every minibatch in it, on the row order drawn into a persistent buffer): two
+    identical set-ups, one with the graph and one launching every kernel eagerly, hold the same parameters bit for bit after two
+    iterations; `shuffle="randperm"` (torch's order) takes the same path and trains on every row once per epoch as well."""
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    from fpv_drone_rl_agent_amd.ppo import PPO
+    from fpv_drone_rl_agent_amd.rollout import RolloutCollector
+    n, T = 4096, 16
+    flats = {}
+    for name, kw in (("graph", {}), ("eager", {"use_graph": False}), ("randperm", {"shuffle": "randperm"})):
+        torch.manual_seed(0)
+        eng = FpvEngine(n, 0, seed=3)
+        pol = ActorCritic(log_std_init=-2.0).cuda()
+        model = PPO(RolloutCollector(eng, pol, n_steps=T, policy_seed=5), n_epochs=2, n_minibatches=4, **kw)
+        assert model.fused_update and model.shuffle == ("randperm" if name == "randperm" else "keyed")
+        model.learn(2 * T * n)
+        flats[name] = model._flat.detach().clone()
+        assert torch.isfinite(flats[name]).all()
+        if name != "randperm":
+            assert torch.equal(torch.sort(model._perm).values, torch.arange(T * n, device="cuda"))
+        eng.close()
+    assert torch.equal(flats["graph"], flats["eager"])
+    assert not torch.equal(flats["graph"], flats["randperm"])          # another order, other minibatches
+    assert float((flats["graph"] - flats["randperm"]).abs().max()) < 0.05
