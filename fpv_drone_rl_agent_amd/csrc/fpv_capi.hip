@@ -682,7 +682,7 @@ int fpv_policy_forward(fpv_policy* p, const fpv_policy_io* io, void* stream) {
 int fpv_rollout_step(fpv_env* e, fpv_policy* p, const fpv_policy_io* io, float* reward, uint8_t* terminated, uint8_t* truncated,
                      const fpv_step_extras* ex, void* stream) {
     if (!e || !p || !io) return fail(FPV_ERR_ARG, "fpv_rollout_step: null argument");
-    if (!io->obs || !io->value || !reward || !terminated || !truncated) return fail(FPV_ERR_ARG, "fpv_rollout_step: null buffer");
+    if (!io->obs || (!io->value && io->nets != 1) || !reward || !terminated || !truncated) return fail(FPV_ERR_ARG, "fpv_rollout_step: null buffer");
     if (e->cfg.precision != FPV_F32 || e->cfg.noise_ratio == 0.0)
         return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: fp32 handles with motor noise only");
     if (e->cfg.num_envs % 256 != 0) return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: num_envs must be a multiple of 256");
@@ -691,8 +691,10 @@ int fpv_rollout_step(fpv_env* e, fpv_policy* p, const fpv_policy_io* io, float* 
     if (p->in_dim != e->obs_words || p->act_dim != e->act_words || (p->gemm != 0 && p->gemm != 1))
         return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: policy widths must be the task's (%d / %d), gemm mode 0 or 1 (the bf16 split)",
                     e->obs_words, e->act_words);
-    if (io->eps_in || io->eps_out || io->deterministic || io->narrow || io->n_dev || io->scatter_out || (io->nets != 0 && io->nets != 3))
-        return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: eps_in / eps_out / deterministic / narrow / n_dev / scatter / single nets are not served");
+    if (io->eps_in || io->eps_out || io->deterministic || io->narrow || io->n_dev || io->scatter_out ||
+        (io->nets != 0 && io->nets != 3 && !(io->nets == 1 && p->gemm == 1)))
+        return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: eps_in / eps_out / deterministic / narrow / n_dev / scatter / V alone are not served; "
+                                         "pi alone (nets = 1, the critic deferred) in gemm mode 1 only");
     if (ex && (ex->obs_rms || ex->ret_rms || ex->snapshot))
         return fail(FPV_ERR_UNSUPPORTED, "fpv_rollout_step: the statistics update rides in the next call's io->merge_* fields");
     if (((uintptr_t)io->obs | (uintptr_t)io->obs_n | (yaw ? 0 : ((uintptr_t)io->action | (uintptr_t)io->clipped))) & 15)
@@ -730,7 +732,7 @@ int fpv_rollout_step(fpv_env* e, fpv_policy* p, const fpv_policy_io* io, float* 
     a.mg_count = (double)e->cfg.num_envs;
     if (p->gemm == 1)
         FPV_HIP(launch_rollout_step_split(p->split_image, io->rms, io->obs_n, io->action, io->clipped, io->value, io->logp, io->seed,
-                                          io->id_offset, io->clip_obs, io->eps_norm, mg, a, yaw ? 1 : 0, e->stamps, (hipStream_t)stream));
+                                          io->id_offset, io->clip_obs, io->eps_norm, mg, a, yaw ? 1 : 0, io->nets == 1 ? 0 : 1, e->stamps, (hipStream_t)stream));
     else
         FPV_HIP(launch_rollout_step(p->image, io->rms, io->obs_n, io->action, io->clipped, io->value, io->logp, io->seed, io->id_offset,
                                     io->clip_obs, io->eps_norm, mg, a, yaw ? 1 : 0, e->stamps, (hipStream_t)stream));

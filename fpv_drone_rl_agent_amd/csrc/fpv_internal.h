@@ -341,7 +341,7 @@ hipError_t launch_rollout_step(const float* image, const double* rms, float* obs
                                const MergeArgs& merge, const StepArgs<float>& st, int yaw, uint64_t* stamps, hipStream_t s);
 hipError_t launch_rollout_step_split(const unsigned char* image, const double* rms, float* obs_n, float* action, float* clipped, float* value,
                                      float* logp, uint64_t pol_seed, uint64_t pol_id_offset, float clip_obs, float eps_norm,
-                                     const MergeArgs& merge, const StepArgs<float>& st, int yaw, uint64_t* stamps, hipStream_t s);
+                                     const MergeArgs& merge, const StepArgs<float>& st, int yaw, int with_v, uint64_t* stamps, hipStream_t s);
 struct RollPersistHost {     // host-side description of a T-step launch (fpv_rollout_steps); fields as RollPersistArgs, fpv_rollstep.hip
     const float* image;
     uint64_t pol_seed, pol_id_offset;

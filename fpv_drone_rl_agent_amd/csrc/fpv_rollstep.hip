@@ -768,7 +768,12 @@ struct RollStepSplitArgs {
 constexpr int kRsSplitLdsBytes = (kRsPix + RsPix::kWords) * 4 > kSplitLdsBytes ? (kRsPix + RsPix::kWords) * 4 : kSplitLdsBytes;
 
 #pragma clang fp contract(fast)
-template <int TASK>                                    // 0: hover (20 -> 4), 1: yaw (12 -> 1; round 5)
+// WITHV = false (fpv_policy_io.nets = 1, "the critic deferred"): pi only.  V(s_t) enters GAE alone, the normalised row is in the
+// rollout buffer, and fpv_policy_forward evaluates V-only on stored rows to the same bits — so a collector can run V over all T x N
+// rows once, behind the last step, with V's image staged once per workgroup instead of once per step and workgroup.  Measured and
+// NOT the default: the step drops 57 -> 43 us, the batched V pass costs 12.3-12.7 us per 65 536 rows (a sustained bf16
+// stream runs at the chip's lower clock), 0.7-1.4 us per step more than it returns.
+template <int TASK, bool WITHV>                        // TASK 0: hover (20 -> 4), 1: yaw (12 -> 1; round 5)
 __global__ __launch_bounds__(512) void rollout_step_split_kernel(RollStepSplitArgs p) {
     constexpr int IN = TASK == 0 ? kIn : kYawObsWords, ACT = TASK == 0 ? kAct : 1;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -806,12 +811,14 @@ __global__ __launch_bounds__(512) void rollout_step_split_kernel(RollStepSplitAr
         RSS_STAMP(1);
         split_net_hidden<IN>(lds_raw, nrm, clip, p.st.obs, d, d < p.st.n, lane, p.obs_n, hd);
         cl = split_net_head<ACT>(0, head, hd, d, d < p.st.n, lane, out, nullptr, tick, false, p.pol_seed, p.pol_id_offset);
-        __syncthreads();                               // every wave is done with pi's image
-        split_stage_request(p.image, 1, stage);
-        split_stage_commit(stage, lds_raw);
-        __syncthreads();
-        split_net_hidden<IN>(lds_raw, nrm, clip, p.st.obs, d, d < p.st.n, lane, nullptr, hd);
-        (void)split_net_head<ACT>(1, head, hd, d, d < p.st.n, lane, out, nullptr, tick, false, p.pol_seed, p.pol_id_offset);
+        if constexpr (WITHV) {
+            __syncthreads();                           // every wave is done with pi's image
+            split_stage_request(p.image, 1, stage);
+            split_stage_commit(stage, lds_raw);
+            __syncthreads();
+            split_net_hidden<IN>(lds_raw, nrm, clip, p.st.obs, d, d < p.st.n, lane, nullptr, hd);
+            (void)split_net_head<ACT>(1, head, hd, d, d < p.st.n, lane, out, nullptr, tick, false, p.pol_seed, p.pol_id_offset);
+        }
     }
     TileRegs tr;
     YawTileRegs ytr;
@@ -1127,21 +1134,29 @@ hipError_t launch_rollout_step(const float* image, const double* rms, float* obs
 
 hipError_t launch_rollout_step_split(const unsigned char* image, const double* rms, float* obs_n, float* action, float* clipped, float* value,
                                      float* logp, uint64_t pol_seed, uint64_t pol_id_offset, float clip_obs, float eps_norm,
-                                     const MergeArgs& merge, const StepArgs<float>& st, int yaw, uint64_t* stamps, hipStream_t s) {
+                                     const MergeArgs& merge, const StepArgs<float>& st, int yaw, int with_v, uint64_t* stamps, hipStream_t s) {
     static bool attr_tab[64] = {};                    // hipFuncSetAttribute holds for one device: one flag per ordinal
     int dev_ = 0;
     (void)hipGetDevice(&dev_);
     bool& attr_set = attr_tab[dev_ & 63];
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)rollout_step_split_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, kRsSplitLdsBytes);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)rollout_step_split_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kRsSplitLdsBytes);
-        if (e != hipSuccess) return e;
+        const void* const kernels[4] = {(const void*)rollout_step_split_kernel<0, true>, (const void*)rollout_step_split_kernel<1, true>,
+                                        (const void*)rollout_step_split_kernel<0, false>, (const void*)rollout_step_split_kernel<1, false>};
+        for (const void* k : kernels) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kRsSplitLdsBytes);
+            if (e != hipSuccess) return e;
+        }
         attr_set = true;
     }
     RollStepSplitArgs p{image, rms, obs_n, action, clipped, value, logp, pol_seed, pol_id_offset, clip_obs, eps_norm, merge, st, stamps};
-    if (yaw) hipLaunchKernelGGL(rollout_step_split_kernel<1>, dim3((unsigned)(st.n / 256)), dim3(512), (size_t)kRsSplitLdsBytes, s, p);
-    else hipLaunchKernelGGL(rollout_step_split_kernel<0>, dim3((unsigned)(st.n / 256)), dim3(512), (size_t)kRsSplitLdsBytes, s, p);
+    const dim3 grid((unsigned)(st.n / 256));
+    if (with_v) {
+        if (yaw) hipLaunchKernelGGL((rollout_step_split_kernel<1, true>), grid, dim3(512), (size_t)kRsSplitLdsBytes, s, p);
+        else hipLaunchKernelGGL((rollout_step_split_kernel<0, true>), grid, dim3(512), (size_t)kRsSplitLdsBytes, s, p);
+    } else {
+        if (yaw) hipLaunchKernelGGL((rollout_step_split_kernel<1, false>), grid, dim3(512), (size_t)kRsSplitLdsBytes, s, p);
+        else hipLaunchKernelGGL((rollout_step_split_kernel<0, false>), grid, dim3(512), (size_t)kRsSplitLdsBytes, s, p);
+    }
     return hipGetLastError();
 }
 

@@ -109,20 +109,24 @@ class FusedPolicy:
 
     def rollout_step(self, engine, *, rms=None, obs_n=None, action=None, clipped=None, value=None, logp=None,
                      clip_obs: float = 10.0, eps_norm: float = 1e-8, merge: dict | None = None, done=None, ret=None,
-                     partials=None, gamma: float = 0.99, reward=None):
+                     partials=None, gamma: float = 0.99, reward=None, nets: str = "both"):
         """fpv_rollout_step: forward() on the engine's raw observations and the env step of the same drones in ONE launch
         (fpv_rollstep.hip); engine.obs then holds the next observations.  Arguments as for forward() and
         FpvEngine.step_fused(); `partials` receives num_envs / 256 rows and must be a different table from
-        merge["partials"].  Bit-identical to forward() followed by engine.step_fused(clipped, ...)."""
+        merge["partials"].  Bit-identical to forward() followed by engine.step_fused(clipped, ...).
+        nets="pi" (gemm "bf16x6"): the critic deferred — no value is written; forward(obs_n rows, nets="v") gives the same bits later."""
         n = engine.num_envs
-        if value is None:
+        if nets not in ("both", "pi"):
+            raise ValueError("fpv_rollout_step serves nets 'both' or 'pi'")
+        if value is None and nets == "both":
             value = torch.empty((n,), dtype=torch.float32, device=engine.device)
         reward = engine.reward if reward is None else reward
         if partials is not None and (partials.dtype != torch.float64 or not partials.is_contiguous()
                                      or partials.shape[0] < n // 256 or partials.shape[1] != 2 * self.obs_dim + 4):
             raise ValueError(f"partials must be a contiguous float64 [>= num_envs / 256, {2 * self.obs_dim + 4}] device tensor")
         io = L.FpvPolicyIo(n, _ptr(engine.obs), _ptr(rms), None, None, _ptr(obs_n), _ptr(action), _ptr(clipped),
-                           _ptr(value), _ptr(logp), None, self.seed, self.id_offset, float(clip_obs), float(eps_norm), 0, 3, 0, 0)
+                           _ptr(value if nets == "both" else None), _ptr(logp), None, self.seed, self.id_offset, float(clip_obs),
+                           float(eps_norm), 0, 3 if nets == "both" else 1, 0, 0)
         if merge is not None:
             io.merge_partials, io.merge_rows = _ptr(merge["partials"]), merge["partials"].shape[0]
             io.merge_count = float(merge["count"])

@@ -109,7 +109,7 @@ class RolloutCollector:
                  clip_obs: float = 10.0, clip_reward: float = 10.0, fused: bool = True, policy_seed: int = 0,
                  policy_gemm: str | None = None, overlap_critic: bool = False, merge_in_policy: bool = True,
                  fused_step: bool = True, merge_in_step: bool = False, one_launch: bool | None = None,
-                 persistent: bool | None = None):
+                 persistent: bool | None = None, deferred_critic: bool | None = None):
         self._f64_env = engine.dtype == torch.float64
         if self._f64_env:                                  # fp32 policy kernel + fpv_step_f64 + stand-alone normaliser kernels
             if not fused:
@@ -220,6 +220,17 @@ class RolloutCollector:
                 raise ValueError("persistent needs what one_launch needs, num_envs <= 256 x the device's CU count and "
                                  "detector='analytic'")
             self._persistent = self._persistent_ok = False if persistent is None else bool(persistent)
+            # deferred_critic (round 5; measured, NOT the default — DESIGN §5b): V(s_t) is an input of GAE only, so the one-launch step
+            # can evaluate pi alone (fpv_policy_io.nets = 1) and the tail run V once over all T x N stored, normalised rows — the same
+            # kernel arithmetic on the same inputs, the same bits (tests/test_rollstep_gpu.py) — with V's 121 KB image staged once per
+            # workgroup and rollout instead of once per workgroup and step.  The step kernel drops 57 -> 43 us, but the batched pass
+            # costs 12.3-12.7 us per 65 536 rows: 0.7-1.4 us per step slower overall at 65 536 drones.  FPV_DEFER_CRITIC=1 selects it.
+            env_defer = os.environ.get("FPV_DEFER_CRITIC")
+            if deferred_critic is None and env_defer is not None:
+                deferred_critic = env_defer not in ("0", "")
+            self._defer_opt = bool(deferred_critic)
+            if deferred_critic and not (self._one_launch and policy_gemm == "bf16x6"):
+                raise ValueError("deferred_critic needs the one-launch step on policy_gemm 'bf16x6'")
             if self._one_launch or self._persistent:    # step t's rows are read while step t + 1's are written: two tables
                 self._rs_partials = torch.zeros((2, N // 256, 2 * O + 4), dtype=torch.float64, device=dev)
         # What the host / the collective read after a rollout — [0:8] ledger status words (fused policy), [8:11] {count, sum A,
@@ -294,6 +305,11 @@ class RolloutCollector:
         else:
             self._graphs[self._slot] = g
 
+    @property
+    def deferred_critic(self) -> bool:
+        """True when the rollout's steps evaluate pi only and V runs once over the stored rows in the tail."""
+        return bool(self.fused and self._one_launch and self.policy_gemm == "bf16x6" and self._defer_opt)
+
     # ------------------------------------------------------------------ one vectorised step
     def _normalise_obs(self, raw, out, update=True):
         if self.norm_obs:
@@ -351,7 +367,8 @@ class RolloutCollector:
             self.fp.rollout_step(eng, rms=self._stat_bufs(0)[0] if t == 0 else o_in, obs_n=self.buf_obs[t], action=self.buf_act[t],
                                  value=self.buf_val[t], logp=self.buf_logp[t], clip_obs=self.obs_norm.clip,
                                  eps_norm=self.obs_norm.eps, merge=merge, done=self._starts[t + 1], ret=self.rew_norm.ret,
-                                 partials=self._rs_partials[t % 2], gamma=self.gamma, reward=self.raw_rew[t])
+                                 partials=self._rs_partials[t % 2], gamma=self.gamma, reward=self.raw_rew[t],
+                                 nets="pi" if self.deferred_critic else "both")
             return
         if self.overlap_critic:
             self.fp.forward(eng.obs, rms=rms, tick=eng.tick_ptr, obs_n=self.buf_obs[t], action=self.buf_act[t],
@@ -477,6 +494,9 @@ class RolloutCollector:
                      "ret_rms_out": self.rew_norm.rms if self.norm_reward else None, "snapshot": self.snap[merge_step]}
             self.fp.forward(eng.obs, rms=o_in, obs_n=self.cur_obs, value=self.last_val, deterministic=True, nets="v",
                             clip_obs=self.obs_norm.clip, eps_norm=self.obs_norm.eps, merge=merge)
+        if self.deferred_critic:      # V(s_0 .. s_{T-1}) from the stored normalised rows: one launch, V's image staged once per workgroup
+            self.fp.forward(self.buf_obs.view(self.T * self.N, self.O), value=self.buf_val.view(self.T * self.N),
+                            deterministic=True, nets="v")
         # (V(s_T) beside the chain below on a second captured stream was measured: 70.7 vs 69.3 us per step with one 20-step
         # rollout per timed region — each fork / join edge of the graph costs 4-12 us, more than the overlap returns)
         # the deferred reward scaling rides in the ledger scan's launch (fpv_ledger_scan_finalize: the two are independent of each

@@ -376,8 +376,8 @@ int fpv_policy_set_gemm(fpv_policy* pol, int32_t mode);
  * obs_t, Box clip, env.step with auto-reset, VecNormalize bookkeeping — by ONE kernel whose 512-thread workgroups evaluate
  * pi / V for 256 drones and then step those drones (fpv_rollstep.hip): the action never leaves the chip and the env step
  * shares the launch.  `io` as for fpv_policy_forward with io->obs = the handle's raw observation rows obs_t, which are
- * REPLACED by obs_{t+1} (io->n = num_envs; eps_in, eps_out, deterministic, narrow, n_dev, nets other than 0 / 3 are not
- * served); reward / terminated / truncated / extras as for fpv_step_fused (extras->obs_rms / ret_rms / snapshot must be
+ * REPLACED by obs_{t+1} (io->n = num_envs; eps_in, eps_out, deterministic, narrow, n_dev, V alone are not served; nets = 1 —
+ * pi alone, io->value unused: the critic deferred to one fpv_policy_forward over the stored obs_n rows, same bits — in gemm mode 1); reward / terminated / truncated / extras as for fpv_step_fused (extras->obs_rms / ret_rms / snapshot must be
  * NULL: the statistics update rides in the NEXT call's io->merge_* fields).  One row of moment sums per workgroup:
  * extras->partials receives num_envs / 256 rows, and because every workgroup of call t + 1 reads call t's rows while it
  * writes its own, the caller alternates between two tables (io->merge_partials != extras->partials).

@@ -120,6 +120,56 @@ def test_collector_one_launch_equals_two_launches(oracle):
         assert ea["ep_len_mean"] == eb["ep_len_mean"] and ea["ep_rew_mean"] == eb["ep_rew_mean"]
 
 
+@pytest.mark.parametrize("task", ["hover", "yaw"])
+def test_deferred_critic_gives_the_in_step_critics_bits(oracle, task):
+    """RolloutCollector(deferred_critic=True) evaluates pi alone in the step kernel (fpv_policy_io.nets = 1) and V once over the
+    T x N stored rows in the tail: every buffer of the batch, V(s_t) first of all, equals the in-step critic's to the last bit, graph
+    replay included.  (Measured slower than the in-step critic, so opt-in: DESIGN §5b.)"""
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    from fpv_drone_rl_agent_amd.rollout import RolloutCollector
+    n, T = 16384, 10
+    cols = []
+    for defer in (True, False):
+        eng = FpvEngine(n, 0, seed=2, task=task)
+        if task == "yaw":
+            torch.manual_seed(4)
+            pol = ActorCritic(obs_dim=12, act_dim=1).cuda()
+        else:
+            pol = _policy(4)
+        cols.append(RolloutCollector(eng, pol, n_steps=T, policy_seed=9, deferred_critic=defer))
+        cols[-1].start()
+        if task == "hover":
+            _synthetic(eng, oracle, 6)
+    assert cols[0].deferred_critic and not cols[1].deferred_critic and cols[0]._one_launch and cols[1]._one_launch
+    for r in range(3):
+        ba, bb = cols[0].collect(), cols[1].collect()
+        assert float(ba["values"].abs().max()) > 0.0
+        for k in ("values", "obs", "actions", "log_probs", "advantages", "returns"):
+            assert torch.equal(ba[k], bb[k]), (r, k)
+        assert torch.equal(ba["adv_mean"], bb["adv_mean"]) and torch.equal(ba["adv_std"], bb["adv_std"])
+        assert torch.equal(cols[0].buf_rew, cols[1].buf_rew) and torch.equal(cols[0].last_val, cols[1].last_val)
+        assert torch.equal(cols[0].obs_norm.rms, cols[1].obs_norm.rms)
+
+
+def test_deferred_critic_is_opt_in_and_served_on_the_split_step_only():
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.ops_policy import FusedPolicy
+    from fpv_drone_rl_agent_amd.rollout import RolloutCollector
+    assert not RolloutCollector(FpvEngine(4096, 0), _policy(), n_steps=4).deferred_critic
+    c = RolloutCollector(FpvEngine(4096, 0), _policy(), n_steps=4, deferred_critic=True)
+    assert c.deferred_critic
+    c.set_policy_gemm("f32"); assert not c.deferred_critic          # the exact-fp32 step kernel keeps both nets in LDS: nothing to defer
+    with pytest.raises(ValueError, match="deferred_critic"):        # two-kernel shape
+        RolloutCollector(FpvEngine(4000, 0), _policy(), n_steps=4, deferred_critic=True)
+    with pytest.raises(ValueError, match="deferred_critic"):
+        RolloutCollector(FpvEngine(4096, 0), _policy(), n_steps=4, policy_gemm="f32", deferred_critic=True)
+    eng = FpvEngine(1024, 0)
+    with pytest.raises(RuntimeError, match="fpv_rollout_step"):     # pi alone is served in gemm mode 1 only
+        FusedPolicy(_policy(), gemm="f32").rollout_step(eng, nets="pi")
+    eng.close()
+
+
 def test_default_collector_takes_the_one_launch_path_where_served():
     from fpv_drone_rl_agent_amd.engine import FpvEngine
     from fpv_drone_rl_agent_amd.rollout import RolloutCollector
