@@ -118,6 +118,34 @@ __device__ __forceinline__ void mfma6x4(const bf16x8* __restrict__ wfrag /* tile
 #endif
 }
 
+
+// FPV_SPLIT_HAND (round 5, second session): layer 2 as a hand-placed stream.  An MFMA 32x32x16 occupies the matrix pipe for 32 cycles
+// and the SIMD's vector issue for 8 of them (MI355X_MICROARCH.md, per-instruction constants): about 24 cycles of vector issue behind
+// every product are free IF vector instructions stand there in program order.  hipcc emits a k-step's 24 products back to back and
+// the 52 instructions of the next cut as one block, so with two waves per SIMD in step the phase costs the SUM of the two.  Here the
+// order is written out and pinned (scheduling barriers): behind every second product half a pair's cut of the NEXT k-step (5 - 6
+// instructions), behind the products of the last two groups one tanh of layer 1's tiles 2 and 3 (needed from k-step 4 on), and a
+// group's weight fragments are requested for the next k-step into the registers the group has just finished with.  The products
+// per accumulator tile and the cut's arithmetic are those of mfma6x4 / split8: the same bits.
+#ifndef FPV_SPLIT_HAND
+#define FPV_SPLIT_HAND 0
+#endif
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t split_pk2(float a, float b) {        // v_cvt_pk_bf16_f32: {bf16(a), bf16(b)}, round to nearest even
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf16x2));
+}
+__device__ __forceinline__ void split_cut_a(float v0, float v1, uint32_t& p1, float& r0, float& r1) {
+    p1 = split_pk2(v0, v1);
+    r0 = v0 - __uint_as_float(p1 << 16);
+    r1 = v1 - __uint_as_float(p1 & 0xffff0000u);
+}
+__device__ __forceinline__ void split_cut_b(float r0, float r1, uint32_t& p2, uint32_t& p3) {
+    p2 = split_pk2(r0, r1);
+    p3 = split_pk2(r0 - __uint_as_float(p2 << 16), r1 - __uint_as_float(p2 & 0xffff0000u));
+}
+#define FPV_PIN() __builtin_amdgcn_sched_barrier(0)
+
 // Which outputs a pass over one net writes for its row (each pointer may be null)
 struct SplitOut {
     float *obs_n, *action, *clipped, *value, *logp, *eps_out;
@@ -179,11 +207,100 @@ __device__ __forceinline__ void split_net_layer1(const unsigned char* img, const
         FPV_SPLIT_FENCE();
     }
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < (FPV_SPLIT_HAND ? 2 : 4); ++m)       // (hand-placed layer 2: tiles 2 and 3 get theirs between its products)
 #pragma unroll
         for (int r = 0; r < 16; ++r) a[m][r] = split_carrier(a[m][r]);
 }
 
+#if FPV_SPLIT_HAND
+__device__ __forceinline__ void split_net_layer2(const unsigned char* img, int lane, f32x16 (&a)[4], SplitHidden& hd) {
+    const int h = lane >> 5;
+    const bf16x8* w2img = reinterpret_cast<const bf16x8*>(img);
+    const float* bias = reinterpret_cast<const float*>(img + kW2Bytes + kW1Bytes);
+    constexpr int kTile = 4 * 2 * 3 * 64, kStep = 3 * 64;       // fragment strides: output tile, k-step (parts are 64 apart)
+    f32x16 c[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[m][r] = bias[128 + (m * 2 + h) * 16 + r];
+    bf16x8 w1[4], w2[4], w3[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        w3[m] = w2img[m * kTile + 128 + lane]; w1[m] = w2img[m * kTile + lane]; w2[m] = w2img[m * kTile + 64 + lane];
+    }
+    u32x4 x1, x2, x3;
+    {
+        float r0, r1;
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+            uint32_t p1, p2, p3;
+            split_cut_a(a[0][2 * pr], a[0][2 * pr + 1], p1, r0, r1);
+            split_cut_b(r0, r1, p2, p3);
+            x1[pr] = p1; x2[pr] = p2; x3[pr] = p3;
+        }
+    }
+    FPV_PIN();
+#define FPV_MF(W, X, m) c[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[m], __builtin_bit_cast(bf16x8, X), c[m], 0, 0, 0)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const bool more = q < 7;
+        const int nt = (q + 1) >> 1, ns = (q + 1) & 1;          // next k-step's activations: a[nt][8 ns ..]
+        const bf16x8* nw = w2img + (q + 1) * kStep + lane;      // next k-step's fragments (tile m at + m kTile, part at + 64 part)
+        u32x4 n1 = x1, n2 = x2, n3 = x3;
+        float r0 = 0.f, r1 = 0.f;
+        // groups 0 .. 3: products (w3 x1) (w1 x3) (w2 x2) (w2 x1); behind every second product half of pair g's cut
+#define FPV_GROUP_CUT(g, W, X)                                                                                                       \
+        FPV_MF(W, X, 0); FPV_MF(W, X, 1); FPV_PIN();                                                                                 \
+        if (more) { uint32_t p1_; split_cut_a(a[nt][8 * ns + 2 * g], a[nt][8 * ns + 2 * g + 1], p1_, r0, r1); n1[g] = p1_;          \
+                    asm volatile("" : "+v"(r0), "+v"(r1)); /* the residuals exist HERE, not where half b uses them */ }              \
+        FPV_PIN();                                                                                                                   \
+        FPV_MF(W, X, 2); FPV_MF(W, X, 3); FPV_PIN();                                                                                 \
+        if (more) { uint32_t p2_, p3_; split_cut_b(r0, r1, p2_, p3_); n2[g] = p2_; n3[g] = p3_; }                                    \
+        FPV_PIN();
+        FPV_GROUP_CUT(0, w3, x1)
+        if (more) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) w3[m] = nw[m * kTile + 128];
+        }
+        FPV_PIN();
+        FPV_GROUP_CUT(1, w1, x3)
+        FPV_GROUP_CUT(2, w2, x2)
+        FPV_GROUP_CUT(3, w2, x1)
+        if (more) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) w2[m] = nw[m * kTile + 64];
+        }
+        FPV_PIN();
+#undef FPV_GROUP_CUT
+        // groups 4, 5: products (w1 x2) (w1 x1); behind each one tanh of layer 1's tiles 2 (k-steps 0, 1) and 3 (k-steps 2, 3)
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                if (g == 0) FPV_MF(w1, x2, m); else FPV_MF(w1, x1, m);
+                FPV_PIN();
+                if (q < 4) {
+                    const int e = (q & 1) * 8 + g * 4 + m;
+                    a[2 + (q >> 1)][e] = split_carrier(a[2 + (q >> 1)][e]);
+                    FPV_PIN();
+                }
+            }
+        if (more) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) w1[m] = nw[m * kTile];
+        }
+        FPV_PIN();
+        x1 = n1; x2 = n2; x3 = n3;
+    }
+#undef FPV_MF
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) c[m][r] = split_carrier(c[m][r]);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) hd.c[m] = c[m];
+}
+#else
 __device__ __forceinline__ void split_net_layer2(const unsigned char* img, int lane, const f32x16 (&a)[4], SplitHidden& hd) {
     const int h = lane >> 5;
     const bf16x8* w2img = reinterpret_cast<const bf16x8*>(img);
@@ -214,6 +331,7 @@ __device__ __forceinline__ void split_net_layer2(const unsigned char* img, int l
 #pragma unroll
     for (int m = 0; m < 4; ++m) hd.c[m] = c[m];
 }
+#endif   // FPV_SPLIT_HAND
 
 template <int IN = kIn>
 __device__ __forceinline__ void split_net_hidden(const unsigned char* img, const float* nrm, float clip, const float* __restrict__ obs,
@@ -224,10 +342,15 @@ __device__ __forceinline__ void split_net_hidden(const unsigned char* img, const
 }
 
 // ACT: action words (4 hover, 1 yaw; the head block holds zeros beyond)
-template <int ACT = 4>
+// Pre: called in the action net's pass behind its arithmetic and in front of its stores (a caller with LDS-DMA in flight waits there:
+// vmcnt(0) before the row stores are issued waits for the DMA alone)
+struct SplitNoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <int ACT = 4, class Pre = SplitNoHook>
 __device__ __forceinline__ f32x4 split_net_head(int net, const float* head, const SplitHidden& hd, int64_t d, bool live, int lane,
                                                 const SplitOut& out, const float* eps_in, uint64_t tick, bool deterministic,
-                                                uint64_t seed, uint64_t id_offset) {
+                                                uint64_t seed, uint64_t id_offset, Pre pre = Pre()) {
     const int h = lane >> 5;
     const f32x16 (&c)[4] = hd.c;
     f32x4 cl = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -297,6 +420,7 @@ __device__ __forceinline__ f32x4 split_net_head(int net, const float* head, cons
         }
         cl = f32x4{fminf(fmaxf(act[0], -1.f), 1.f), fminf(fmaxf(act[1], -1.f), 1.f), fminf(fmaxf(act[2], -1.f), 1.f),
                    fminf(fmaxf(act[3], -1.f), 1.f)};
+        pre();
         if (live) {
             if (h == 0) {
                 if constexpr (ACT == 4) {
@@ -392,6 +516,29 @@ __device__ __forceinline__ void split_stage_image(const unsigned char* __restric
     SplitStage<THREADS> st;
     split_stage_request(image, net, st);
     split_stage_commit(st, lds_raw);
+}
+
+// The same image by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no registers, no ds_write pass), for a caller that
+// has other work for the flight time.  Inline asm on purpose: hipcc counts a builtin LDS-DMA as a pending LDS write and drains
+// vmcnt(0) in front of the next ds_read (cdna_hip_programming.md §5); an asm statement is outside its bookkeeping, so the caller
+// waits itself — s_waitcnt vmcnt(0), then a workgroup barrier — before anyone reads the image.  lds_base: the image's LDS byte address.
+template <int THREADS>
+__device__ __forceinline__ void split_stage_dma(const unsigned char* __restrict__ image, int net, unsigned lds_base) {
+    static_assert(kNetBytes % 1024 == 0, "whole 1-KiB pieces");
+    constexpr int kPieces = kNetBytes / 1024, kWaves = THREADS / 64;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned char* src = image + (size_t)net * kNetBytes + lane * 16;
+#pragma unroll
+    for (int i = 0; i < (kPieces + kWaves - 1) / kWaves; ++i) {
+        const int piece = i * kWaves + wave;                       // wave-uniform
+        if (piece < kPieces) {
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)piece * 1024u);
+            const unsigned char* s = src + piece * 1024;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(s), "s"(dst) : "memory");
+        }
+    }
 }
 
 }  // namespace fpv

@@ -26,6 +26,18 @@
 #ifndef FPV_ROLLSTEP_KEEP_SPLIT_FENCE
 #define FPV_SPLIT_FENCE()            // the rollout-step kernel schedules its k-steps freely (fpv_policy_split.h; A/B: -DFPV_ROLLSTEP_KEEP_SPLIT_FENCE)
 #endif
+// Round 5, second session (same-box A/B, profiles/r05_split_kernel_ab.txt: 57.22 / 57.25 -> 56.69 / 56.67 us per step with both, the
+// same bits): V's image by LDS-DMA in flight under pi's head arithmetic, and layer 2 as a hand-placed stream in THIS translation
+// unit's kernels (fpv_policy_split.h; the stand-alone kernel keeps the compiler's order).  -DFPV_RSS_DMA_V=0 / -DFPV_SPLIT_HAND=0: A/B.
+#ifndef FPV_RSS_DMA_V
+#define FPV_RSS_DMA_V 1
+#endif
+#ifndef FPV_SPLIT_HAND
+#define FPV_SPLIT_HAND 1
+#endif
+#ifndef FPV_RSS_DMA_PI
+#define FPV_RSS_DMA_PI 1              // pi's image by LDS-DMA ahead of the statistics merge (57.73 / 57.69 -> 57.53 / 57.45 us on another box; =0: A/B)
+#endif
 #include "fpv_policy_split.h"   // (the split policy arithmetic is compiled as in fpv_policy_split.hip: contract fast)
 #pragma clang fp contract(on)
 #include "fpv_pixel_tile.h"
@@ -784,6 +796,11 @@ __global__ __launch_bounds__(512) void rollout_step_split_kernel(RollStepSplitAr
     const float clip = p.rms ? p.clip_obs : 3.0e38f;
 #define RSS_STAMP(k) do { if (p.stamps && threadIdx.x == 0) p.stamps[(int64_t)blockIdx.x * kStampStride + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     RSS_STAMP(0);
+#if FPV_RSS_DMA_PI
+    // pi's image by LDS-DMA ahead of everything: in flight under the statistics merge (no registers held, unlike the requests of
+    // split_stage_request, which lost 0.4 us in that place: DESIGN §5b)
+    split_stage_dma<512>(p.image, 0, (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds_raw);
+#endif
     for (int q = threadIdx.x; q < kHeadFloats; q += 512)
         head[q] = reinterpret_cast<const float*>(p.image + 2 * (size_t)kNetBytes)[q];
     if (p.mg.rows) {                            // fold the previous env step's tile sums into the statistics first
@@ -805,17 +822,34 @@ __global__ __launch_bounds__(512) void rollout_step_split_kernel(RollStepSplitAr
     SplitHidden hd;
     {
         SplitStage<512> stage;
+#if FPV_RSS_DMA_PI
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
         split_stage_request(p.image, 0, stage);
         split_stage_commit(stage, lds_raw);
+#endif
         __syncthreads();                               // pi's image, the head block and the normaliser are in LDS
         RSS_STAMP(1);
         split_net_hidden<IN>(lds_raw, nrm, clip, p.st.obs, d, d < p.st.n, lane, p.obs_n, hd);
+#if FPV_RSS_DMA_V
+        // V's image by LDS-DMA over pi's as soon as every wave is through pi's layer 2, in flight under pi's head arithmetic and
+        // sampling (which read the head block and registers only); the wait stands in front of the head's row stores
+        if constexpr (WITHV) {
+            lds_barrier();                             // every wave is done with pi's image
+            split_stage_dma<512>(p.image, 1, (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds_raw);
+            cl = split_net_head<ACT>(0, head, hd, d, d < p.st.n, lane, out, nullptr, tick, false, p.pol_seed, p.pol_id_offset,
+                                     [] { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); });
+            lds_barrier();                             // every wave's pieces have landed
+        } else
+#endif
         cl = split_net_head<ACT>(0, head, hd, d, d < p.st.n, lane, out, nullptr, tick, false, p.pol_seed, p.pol_id_offset);
         if constexpr (WITHV) {
+#if !FPV_RSS_DMA_V
             __syncthreads();                           // every wave is done with pi's image
             split_stage_request(p.image, 1, stage);
             split_stage_commit(stage, lds_raw);
             __syncthreads();
+#endif
             split_net_hidden<IN>(lds_raw, nrm, clip, p.st.obs, d, d < p.st.n, lane, nullptr, hd);
             (void)split_net_head<ACT>(1, head, hd, d, d < p.st.n, lane, out, nullptr, tick, false, p.pol_seed, p.pol_id_offset);
         }
