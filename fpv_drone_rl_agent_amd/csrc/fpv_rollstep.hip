@@ -796,20 +796,28 @@ __global__ __launch_bounds__(512) void rollout_step_split_kernel(RollStepSplitAr
     const float clip = p.rms ? p.clip_obs : 3.0e38f;
 #define RSS_STAMP(k) do { if (p.stamps && threadIdx.x == 0) p.stamps[(int64_t)blockIdx.x * kStampStride + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     RSS_STAMP(0);
-#if FPV_RSS_DMA_PI
-    // pi's image by LDS-DMA ahead of everything: in flight under the statistics merge (no registers held, unlike the requests of
-    // split_stage_request, which lost 0.4 us in that place: DESIGN §5b)
-    split_stage_dma<512>(p.image, 0, (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds_raw);
-#endif
     for (int q = threadIdx.x; q < kHeadFloats; q += 512)
         head[q] = reinterpret_cast<const float*>(p.image + 2 * (size_t)kNetBytes)[q];
+    // pi's image by LDS-DMA (FPV_RSS_DMA_PI): requested BEHIND the merge table's loads and in front of their sums, inside the same
+    // branch, so that the two travel together — a load hipcc knows of is waited for with a counter threshold, which also waits for
+    // every DMA issued before it (the head block above is therefore read first), and a load under a branch is waited for at the join
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds_raw;
+    (void)lds0;
     if (p.mg.rows) {                            // fold the previous env step's tile sums into the statistics first
         MergeRegs mr;
         merge_request(p.mg, mr);
+#if FPV_RSS_DMA_PI
+        split_stage_dma<512>(p.image, 0, lds0);
+#endif
         merge_prologue(p.mg, mr, p.rms, reinterpret_cast<double*>(nrm + 40), p.eps_norm, nrm, nrm + 20);
-    } else if ((int)threadIdx.x < IN) {
-        nrm[threadIdx.x] = p.rms ? (float)p.rms[threadIdx.x] : 0.0f;
-        nrm[20 + threadIdx.x] = p.rms ? (float)(1.0 / sqrt(p.rms[IN + threadIdx.x] + (double)p.eps_norm)) : 1.0f;
+    } else {
+#if FPV_RSS_DMA_PI
+        split_stage_dma<512>(p.image, 0, lds0);
+#endif
+        if ((int)threadIdx.x < IN) {
+            nrm[threadIdx.x] = p.rms ? (float)p.rms[threadIdx.x] : 0.0f;
+            nrm[20 + threadIdx.x] = p.rms ? (float)(1.0 / sqrt(p.rms[IN + threadIdx.x] + (double)p.eps_norm)) : 1.0f;
+        }
     }
     const int64_t d = (int64_t)blockIdx.x * 256 + wave * 32 + col;
     const uint64_t tick = p.st.tick[(int64_t)blockIdx.x * 4];       // this workgroup's own tile's copy (rollout_step_kernel)
