@@ -4,9 +4,13 @@
 # boundary from a kernel trace, the PMC traffic passes and the SQ counters of the rollout-step kernel, env-step sweeps over drone
 # counts, the fp32-vs-fp64 trajectory record, PPO update profile.
 # Run as: gpurun -- 'bash tools/gpu_session.sh'; then tools/collect_profiles.sh copies the summaries into profiles/.
+# PART=a (suite, bench lines, stamps, traces, counters) / PART=b (sweeps, records, training, PPO profiles): the whole set is longer than
+# one gpurun call may last; default: both.
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/session; mkdir -p $O
+PART=${PART:-all}
+if [ "$PART" != b ]; then
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > $O/tests.txt 2>&1 || { tail -30 $O/tests.txt; exit 1; }
 tail -2 $O/tests.txt
 python bench.py > $O/bench.json 2> $O/bench.err
@@ -30,6 +34,8 @@ python tools/trace_gaps.py $(ls $O/prof_hover/*/*kernel_trace.csv | head -1) 1 >
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 128 --warmup 32 --repeats 1 --no-cpu-baseline --no-split-extra --no-host-mode --no-f64-rollout --kernel-launches 20 > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 128 --warmup 32 --repeats 1 --no-cpu-baseline --no-split-extra --no-host-mode --no-f64-rollout --kernel-launches 20 > $O/pmc_write.log 2>&1
 bash tools/pmc_rollstep.sh > $O/pmc_k0.txt 2>&1
+fi
+if [ "$PART" != a ]; then
 python tools/step_sweep.py $O/step_sweep_pixel.json pixel > /dev/null 2>&1
 python tools/step_quad_sweep.py $O/step_quad_sweep.json > /dev/null 2>&1
 python tools/trajectory_drift.py > $O/fp32_vs_fp64_trajectory.json 2> /dev/null
@@ -54,10 +60,13 @@ if [ -f variants/ppo_v1.so ]; then bash tools/ab_ppo.sh ppo_v1 > $O/ppo_ab.txt 2
 if [ -f variants/ppo_stamps.so ]; then
   FPV_LIB_VARIANT=ppo_stamps python tools/ppo_stamps.py > $O/ppo_stamps.txt 2> /dev/null
 fi
+fi
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -size +3M -delete
 python - <<'PY'
-import json
+import json, os
 for k in ("bench", "bench_s20", "bench_analytic", "bench_two", "bench_yaw", "bench_gpus2_gloo"):
+    if not os.path.exists(f"gpurun_out/session/{k}.json"):
+        continue
     d = json.loads(open(f"gpurun_out/session/{k}.json").read().strip().splitlines()[-1])
     print(k, round(d["value"]), round(d["ms_per_step"] * 1e3, 2), d["roofline"]["frac"], d["roofline"]["us_per_launch"], d.get("cpu_baseline", {}).get("value"))
 PY
