@@ -46,7 +46,7 @@ def save_model(path: str, model) -> None:
         data = {"num_timesteps": model.num_timesteps, "n_epochs": model.n_epochs, "n_minibatches": model.n_minibatches,
                 "clip_range": model.clip_range, "ent_coef": model.ent_coef, "vf_coef": model.vf_coef,
                 "max_grad_norm": model.max_grad_norm, "gamma": model.col.gamma, "gae_lambda": model.col.lam,
-                "n_steps": model.col.T, "algo": "PPO", "policy": "MlpPolicy[128,128]", "logger": model.logger}
+                "n_steps": model.col.T, "algo": "PPO", "policy": "MlpPolicy[128,128]", "logger": dict(model.logger.items())}
         z.writestr("data.json", json.dumps(data))
 
 

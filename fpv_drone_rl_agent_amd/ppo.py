@@ -24,6 +24,65 @@ from . import ops as O
 from .rollout import RolloutCollector
 
 
+class _LazyLog(dict):
+    """model.logger: a dict whose update-time values may still be on their way from the device.  train_on() leaves the last epoch's
+    statistics and the policy's log-std as asynchronous copies into pinned host words (so that the host can queue the next rollout
+    while the update still runs) and registers a resolver; any READ of the dict waits for them and fills the numbers in."""
+
+    def __init__(self):
+        super().__init__()
+        self._pending = None
+
+    def defer(self, resolver) -> None:
+        self._resolve()                         # (an earlier update's numbers first: each resolver reads its own pinned words)
+        self._pending = resolver
+
+    def _resolve(self) -> None:
+        if self._pending is not None:
+            resolver, self._pending = self._pending, None
+            dict.update(self, resolver())
+
+    def __getitem__(self, k):
+        self._resolve()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        self._resolve()
+        return dict.get(self, k, default)
+
+    def __contains__(self, k):
+        self._resolve()
+        return dict.__contains__(self, k)
+
+    def __iter__(self):
+        self._resolve()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._resolve()
+        return dict.__len__(self)
+
+    def keys(self):
+        self._resolve()
+        return dict.keys(self)
+
+    def values(self):
+        self._resolve()
+        return dict.values(self)
+
+    def items(self):
+        self._resolve()
+        return dict.items(self)
+
+    def copy(self):
+        self._resolve()
+        return dict(self)
+
+    def __repr__(self):
+        self._resolve()
+        return dict.__repr__(self)
+
+
 class PPO:
     def __init__(self, collector: RolloutCollector, learning_rate: float = 3e-4, n_epochs: int = 4,
                  n_minibatches: int = 8, clip_range: float = 0.2, ent_coef: float = 0.0, vf_coef: float = 0.5,
@@ -77,7 +136,8 @@ class PPO:
         # sigma < 0.01 within 10^8 steps, where the importance ratios of a PPO epoch become violently sensitive
         self.log_std_min = log_std_min
         self.num_timesteps = 0
-        self.logger: dict[str, float] = {}
+        self.logger: dict[str, float] = _LazyLog()
+        self._stats_host = self._stats_event = self._logstd_host = None    # pinned mirrors of the epoch statistics (fused update)
         self._gen = torch.Generator(device=collector.device)
         self._gen.manual_seed(1234 + D.rank())
 
@@ -223,6 +283,46 @@ class PPO:
                                torch.zeros((mb,), dtype=f32, device=dev)], dev)
         graph = graph and not getattr(self, "_graph_failed", False)
         stats = []
+        if self.fused_update and D.world_size() == 1 and os.environ.get("FPV_PPO_SYNC_LOG", "") in ("", "0"):
+            # (FPV_PPO_SYNC_LOG=1: the synchronising loop below, for an A/B)
+            # One rank, fused update: the host never waits for more than it must.  An epoch is one graph replay; its statistics leave
+            # as an asynchronous copy into pinned host words behind it; only target_kl's decision about the NEXT epoch waits for them
+            # (nothing depends on the last epoch's), the logged numbers are resolved when somebody reads model.logger, and the host
+            # goes on to queue the image repack and the next rollout while the last epoch still runs (tools/train_gaps.py: 0.5 ms of
+            # a 18 ms iteration at 65 536 drones was the device waiting for the host after those synchronisations).
+            if self._stats_host is None or len(self._stats_host) != self.n_epochs or self._stats_host[0].shape[0] != self.n_minibatches:
+                self._stats_host = [torch.zeros((self.n_minibatches, 4), dtype=torch.float32).pin_memory() for _ in range(self.n_epochs)]
+                self._stats_event = [torch.cuda.Event() for _ in range(self.n_epochs + 1)]
+                self._logstd_host = torch.zeros(self.policy.log_std.shape, dtype=torch.float32).pin_memory()
+            self.logger._resolve()               # the previous update's numbers leave the pinned words before they are written again
+            ran = 0
+            for epoch in range(self.n_epochs):
+                self._draw_order(total, dev)
+                if graph:
+                    self._mb_graph.replay()
+                    st = self._g_out
+                else:
+                    st = self._fused_epoch(self._perm)
+                self._stats_host[epoch].copy_(st, non_blocking=True)
+                self._stats_event[epoch].record()
+                ran = epoch + 1
+                if self.target_kl is not None and epoch + 1 < self.n_epochs:
+                    self._stats_event[epoch].synchronize()
+                    if float(self._stats_host[epoch][:, 2].mean()) > 1.5 * self.target_kl:
+                        break
+            self._logstd_host.copy_(self.policy.log_std.detach(), non_blocking=True)
+            self._stats_event[self.n_epochs].record()
+            hosts, events, logstd, vf = self._stats_host[:ran], self._stats_event, self._logstd_host, self.vf_coef
+
+            def resolve():
+                events[self.n_epochs].synchronize()
+                m = torch.cat(hosts).mean(0).tolist()
+                return {"train/policy_gradient_loss": m[0], "train/value_loss": m[1], "train/approx_kl": m[2],
+                        "train/clip_fraction": m[3], "train/loss": m[0] + vf * m[1], "train/std": float(torch.exp(logstd).mean())}
+
+            self.logger.defer(resolve)
+            self.col.sync_policy()
+            return
         for epoch in range(self.n_epochs):
             if self.fused_update:               # the whole epoch is one graph replay on the order drawn into the persistent buffer
                 self._draw_order(total, dev)
@@ -269,11 +369,13 @@ class PPO:
         while self.num_timesteps < total_timesteps:
             batch = self.col.collect()
             self.num_timesteps += per_iter
+            self.train_on(batch)
+            # (the episode statistics wait for the rollout's end: read behind the update's launches, where that costs nothing, not in
+            # front of them, where the device would idle until the host has woken up and queued the update)
             ep = self.col.episodes
             if ep["count"] > 0 and ep["ep_len_mean"] == ep["ep_len_mean"]:
-                self.logger["rollout/ep_len_mean"] = ep["ep_len_mean"]
-                self.logger["rollout/ep_rew_mean"] = ep["ep_rew_mean"]
-            self.train_on(batch)
+                dict.__setitem__(self.logger, "rollout/ep_len_mean", ep["ep_len_mean"])
+                dict.__setitem__(self.logger, "rollout/ep_rew_mean", ep["ep_rew_mean"])
             it += 1
             if callback is not None:
                 callback(self)

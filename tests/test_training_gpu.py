@@ -27,6 +27,38 @@ def test_ppo_learns_to_hover():
     eng.close()
 
 
+def test_deferred_logging_gives_the_synchronising_loops_numbers(monkeypatch):
+    """PPO.train_on with one rank and the fused update leaves the epoch statistics as asynchronous copies in pinned host words and
+    resolves model.logger when it is read (no host wait behind the last epoch, target_kl decided from the pinned words): the same
+    parameters, the same logged numbers and the same early stops as the loop that synchronises after every epoch
+    (FPV_PPO_SYNC_LOG=1)."""
+    from fpv_drone_rl_agent_amd.engine import FpvEngine
+    from fpv_drone_rl_agent_amd.policy import ActorCritic
+    from fpv_drone_rl_agent_amd.ppo import PPO
+    from fpv_drone_rl_agent_amd.rollout import RolloutCollector
+    runs = []
+    for sync in ("1", "0"):
+        monkeypatch.setenv("FPV_PPO_SYNC_LOG", sync)
+        torch.manual_seed(0)
+        n = 4096
+        eng = FpvEngine(n, 0, seed=0)
+        pol = ActorCritic(log_std_init=-2.0).cuda()
+        model = PPO(RolloutCollector(eng, pol, n_steps=16), n_epochs=4, n_minibatches=4, target_kl=0.002)   # (tight: epochs are cut short)
+        logs = []
+        for it in range(6):
+            model.learn(16 * n * (it + 1))
+            logs.append(dict(model.logger.items()))
+        runs.append((logs, torch.cat([p.detach().flatten() for p in pol.parameters()]).clone()))
+        eng.close()
+    (la, pa), (lb, pb) = runs
+    assert torch.equal(pa, pb)
+    assert "rollout/ep_len_mean" in la[-1] and "train/std" in la[-1]
+    for a, b in zip(la, lb):
+        assert a.keys() == b.keys() and len(a) >= 6
+        for k in a:
+            assert a[k] == pytest.approx(b[k], rel=1e-6, abs=1e-9), k
+
+
 def test_ppo_learns_the_yaw_task_under_domain_randomisation():
     """BASELINE cfg 5 end to end: simulation/yaw.py's yaw-setpoint task with per-episode mass / drag randomisation;
     episodes always run to the truncation limit, so learning shows in the return."""
