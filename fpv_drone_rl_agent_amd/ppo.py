@@ -249,7 +249,7 @@ class PPO:
         old_lp = batch["log_probs"].reshape(-1)
         ret = batch["returns"].reshape(-1)
         adv = batch["advantages"].reshape(-1)
-        if self.normalize_advantage:
+        if self.normalize_advantage and not self.fused_update:
             # global statistics from the rollout's single all-gather (identical on every rank)
             adv = (adv - batch["adv_mean"].float()) / (batch["adv_std"].float() + 1e-8)
         total = T * N
@@ -262,7 +262,11 @@ class PPO:
         if self.fused_update:
             if self._adv_n is None or self._adv_n.numel() != total:
                 self._adv_n = torch.empty(total, dtype=torch.float32, device=dev)
-            self._adv_n.copy_(adv)
+            if self.normalize_advantage:        # the same two roundings as above, straight into the persistent buffer (two passes, not three)
+                torch.sub(adv, batch["adv_mean"].float(), out=self._adv_n)
+                self._adv_n.div_(batch["adv_std"].float() + 1e-8)
+            else:
+                self._adv_n.copy_(adv)
             if self._ws is None or self._ws_rows != mb:
                 self._ws, self._ws_rows = self._fp.ppo_workspace(mb), mb
             src = {"obs": obs, "act": act, "old_lp": old_lp, "adv": self._adv_n, "ret": ret}
