@@ -13,7 +13,7 @@ from .build import LIB_PATH, LIB_PATH_EXPERIMENTS, build_extension, variant_path
 FPV_F32, FPV_F64 = 0, 1
 TASK_HOVER, TASK_YAW = 0, 1
 DETECTOR_PIXEL, DETECTOR_ANALYTIC = 0, 1   # fpv_detector: the reference's pixel rules are the default
-ABI_VERSION = 6                              # FPV_ABI_VERSION of include/fpv_env.h this binding was written against
+ABI_VERSION = 7                              # FPV_ABI_VERSION of include/fpv_env.h this binding was written against
 STATE_WORDS, OBS_WORDS, ACT_WORDS = 36, 20, 4
 INFO_TERMINATED, INFO_TRUNCATED, INFO_OUT_OF_BOUNDS, INFO_ON_FLOOR = 1, 2, 4, 8
 
@@ -121,6 +121,8 @@ SIGNATURES = {
     "fpv_ppo_workspace_bytes": (C.c_int, [_vp, _i64, C.POINTER(_i64)]),
     "fpv_ppo_grad": (C.c_int, [_vp, C.POINTER(FpvPpoIo), _vp]),
     "fpv_adam_clip_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp]),
+    "fpv_adam_clip_step_gated": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),
+    "fpv_ppo_kl_gate": (C.c_int, [_vp, C.c_int32, _f32, _vp, _vp]),
     "fpv_shuffle_indices": (C.c_int, [_vp, _i64, C.c_uint64, C.c_uint64, _vp]),
     "fpv_last_error": (C.c_char_p, []),
     "fpv_version": (C.c_int, []),

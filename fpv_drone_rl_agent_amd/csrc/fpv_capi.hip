@@ -832,17 +832,37 @@ int fpv_ppo_grad(fpv_policy* p, const fpv_ppo_io* io, void* stream) {
     return FPV_OK;
 }
 
+static int adam_clip_step(const char* who, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t* step,
+                          float* grad_norm, int64_t n, float lr, float beta1, float beta2, float eps, float max_grad_norm,
+                          const int32_t* gate, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !step || n <= 0)
+        return fail(FPV_ERR_ARG, "%s: null argument or n <= 0", who);
+    if (n > (1 << 20))
+        return fail(FPV_ERR_UNSUPPORTED, "%s: built for policy-sized tensors (n <= 2^20): every workgroup recomputes the norm", who);
+    if (!(lr >= 0.f) || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) || !(eps > 0.f))
+        return fail(FPV_ERR_ARG, "%s: need lr >= 0, betas in [0, 1), eps > 0", who);
+    FPV_HIP(launch_adam_clip(param, grad, exp_avg, exp_avg_sq, step, grad_norm, n, lr, beta1, beta2, eps, max_grad_norm, gate,
+                             (hipStream_t)stream));
+    return FPV_OK;
+}
+
 int fpv_adam_clip_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t* step,
                        float* grad_norm, int64_t n, float lr, float beta1, float beta2, float eps, float max_grad_norm,
                        void* stream) {
-    if (!param || !grad || !exp_avg || !exp_avg_sq || !step || n <= 0)
-        return fail(FPV_ERR_ARG, "fpv_adam_clip_step: null argument or n <= 0");
-    if (n > (1 << 20))
-        return fail(FPV_ERR_UNSUPPORTED, "fpv_adam_clip_step: built for policy-sized tensors (n <= 2^20): every workgroup recomputes the norm");
-    if (!(lr >= 0.f) || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f) || !(eps > 0.f))
-        return fail(FPV_ERR_ARG, "fpv_adam_clip_step: need lr >= 0, betas in [0, 1), eps > 0");
-    FPV_HIP(launch_adam_clip(param, grad, exp_avg, exp_avg_sq, step, grad_norm, n, lr, beta1, beta2, eps, max_grad_norm,
-                             (hipStream_t)stream));
+    return adam_clip_step("fpv_adam_clip_step", param, grad, exp_avg, exp_avg_sq, step, grad_norm, n, lr, beta1, beta2, eps,
+                          max_grad_norm, nullptr, stream);
+}
+
+int fpv_adam_clip_step_gated(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t* step,
+                             float* grad_norm, int64_t n, float lr, float beta1, float beta2, float eps, float max_grad_norm,
+                             const int32_t* gate, void* stream) {
+    return adam_clip_step("fpv_adam_clip_step_gated", param, grad, exp_avg, exp_avg_sq, step, grad_norm, n, lr, beta1, beta2, eps,
+                          max_grad_norm, gate, stream);
+}
+
+int fpv_ppo_kl_gate(const float* epoch_stats, int32_t n_minibatches, float limit, int32_t* gate, void* stream) {
+    if (!epoch_stats || !gate || n_minibatches <= 0) return fail(FPV_ERR_ARG, "fpv_ppo_kl_gate: null argument or n_minibatches <= 0");
+    FPV_HIP(launch_ppo_kl_gate(epoch_stats, n_minibatches, limit, gate, (hipStream_t)stream));
     return FPV_OK;
 }
 

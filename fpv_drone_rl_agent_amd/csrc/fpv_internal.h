@@ -369,7 +369,8 @@ hipError_t launch_ppo_grad(const float* const* w, float* const* grads, const int
 hipError_t launch_shuffle_indices(int64_t* out, int64_t n, uint64_t seed, uint64_t counter, hipStream_t s);
 hipError_t launch_adam_clip(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t* step,
                             float* grad_norm, int64_t n, float lr, float beta1, float beta2, float eps, float max_norm,
-                            hipStream_t s);
+                            const int32_t* gate, hipStream_t s);
+hipError_t launch_ppo_kl_gate(const float* stats, int n_minibatches, float limit, int32_t* gate, hipStream_t s);
 // fpv_policy_split.hip
 hipError_t launch_policy_split_pack(const float* const* w, unsigned char* image, int in_dim, int act_dim, hipStream_t s);
 hipError_t launch_policy_split_forward(const unsigned char* image, const float* obs, const double* rms, const float* eps_in,

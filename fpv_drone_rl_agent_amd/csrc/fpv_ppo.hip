@@ -1461,6 +1461,7 @@ struct AdamArgs {
     float* grad_norm;         // out (may be null): the norm before clipping
     int64_t n;
     float lr, beta1, beta2, eps, max_norm;
+    const int32_t* gate;      // device word or null: non-zero = this launch changes nothing (target_kl's early stop, decided on the device)
 };
 
 // Every 1024-thread workgroup recomputes the norm of the whole gradient (a few 10^4 elements out of L2, the same
@@ -1468,6 +1469,7 @@ struct AdamArgs {
 __global__ __launch_bounds__(1024) void adam_clip_kernel(AdamArgs p) {
     __shared__ float red[16];
     __shared__ float bc[3];
+    if (p.gate && *p.gate != 0) return;          // (uniform over the grid: no workgroup takes a ticket)
     float ss[4] = {0.f, 0.f, 0.f, 0.f};
     constexpr int kPer = 40;                    // the policy's 39 049 parameters: every read of the gradient in flight at once (the
     if (p.n <= (int64_t)kPer * 1024) {          // loop below waits for memory ten times in a row: 7 of the kernel's 8.8 us)
@@ -1540,9 +1542,25 @@ __global__ __launch_bounds__(1024) void adam_clip_kernel(AdamArgs p) {
 
 hipError_t launch_adam_clip(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t* step,
                             float* grad_norm, int64_t n, float lr, float beta1, float beta2, float eps, float max_norm,
-                            hipStream_t s) {
-    AdamArgs a{param, grad, exp_avg, exp_avg_sq, step, grad_norm, n, lr, beta1, beta2, eps, max_norm};
+                            const int32_t* gate, hipStream_t s) {
+    AdamArgs a{param, grad, exp_avg, exp_avg_sq, step, grad_norm, n, lr, beta1, beta2, eps, max_norm, gate};
     hipLaunchKernelGGL(adam_clip_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, s, a);
+    return hipGetLastError();
+}
+
+// SB3 PPO.train's target_kl rule for an epoch, on the device: gate = {stopped, epochs that counted}.  Behind an epoch's minibatches:
+// an epoch that started unstopped counts, and stops the epochs behind it when the mean of its minibatches' approx_kl is above the limit.
+__global__ void ppo_kl_gate_kernel(const float* __restrict__ stats, int n_minibatches, float limit, int32_t* gate) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || gate[0] != 0) return;
+    float kl = 0.f;
+    for (int k = 0; k < n_minibatches; ++k) kl += stats[4 * k + 2];
+    kl /= (float)n_minibatches;
+    gate[1] += 1;
+    if (kl > limit) gate[0] = 1;
+}
+
+hipError_t launch_ppo_kl_gate(const float* stats, int n_minibatches, float limit, int32_t* gate, hipStream_t s) {
+    hipLaunchKernelGGL(ppo_kl_gate_kernel, dim3(1), dim3(64), 0, s, stats, n_minibatches, limit, gate);
     return hipGetLastError();
 }
 

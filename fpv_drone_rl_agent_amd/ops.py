@@ -208,6 +208,17 @@ def shuffle_indices(out: torch.Tensor, seed: int, counter: int) -> torch.Tensor:
     return out
 
 
+def ppo_kl_gate(epoch_stats: torch.Tensor, limit: float, gate: torch.Tensor) -> None:
+    """fpv_ppo_kl_gate behind an epoch's minibatches: gate = int32[2] {stopped, epochs that counted}; epoch_stats = fp32 [n_minibatches, 4]
+    (column 2: approx_kl).  An epoch that started unstopped counts, and stops the ones behind it when its mean approx_kl > limit."""
+    if epoch_stats.dtype != torch.float32 or not epoch_stats.is_contiguous() or epoch_stats.dim() != 2 or epoch_stats.shape[1] != 4:
+        raise ValueError("ppo_kl_gate: epoch_stats is a contiguous fp32 [n_minibatches, 4] device tensor")
+    if gate.dtype != torch.int32 or gate.numel() != 2 or not gate.is_cuda:
+        raise ValueError("ppo_kl_gate: gate is an int32[2] device tensor")
+    L.check(L.load().fpv_ppo_kl_gate(_ptr(epoch_stats), epoch_stats.shape[0], float(limit), _ptr(gate), _stream(gate.device)),
+            "fpv_ppo_kl_gate")
+
+
 class FusedAdam:
     """clip_grad_norm_ + torch.optim.Adam.step() for ONE flat fp32 parameter tensor as a single launch
     (fpv_adam_clip_step).  state_dict() has torch.optim.Adam's shape ({"state": {0: {step, exp_avg, exp_avg_sq}},
@@ -224,11 +235,20 @@ class FusedAdam:
         self.grad_norm = torch.zeros((), dtype=torch.float32, device=param.device)
         self.lib = L.load()
 
-    def step(self, grad: torch.Tensor | None = None) -> None:
+    def step(self, grad: torch.Tensor | None = None, gate: torch.Tensor | None = None) -> None:
+        """gate: optional int32 device tensor (fpv_adam_clip_step_gated): a launch that finds gate[0] != 0 changes nothing."""
         g = self.param.grad if grad is None else grad
         if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.numel() != self.param.numel():
             raise ValueError("FusedAdam.step: gradient must be a contiguous fp32 tensor of the parameter's size")
         st = self.state[0]
+        if gate is not None:
+            if gate.dtype != torch.int32 or not gate.is_cuda:
+                raise ValueError("FusedAdam.step: gate is an int32 device tensor")
+            L.check(self.lib.fpv_adam_clip_step_gated(_ptr(self.param.data), _ptr(g), _ptr(st["exp_avg"]), _ptr(st["exp_avg_sq"]),
+                                                      _ptr(st["step"]), _ptr(self.grad_norm), self.param.numel(), self.lr,
+                                                      self.betas[0], self.betas[1], self.eps, self.max_grad_norm, _ptr(gate),
+                                                      _stream(self.param.device)), "fpv_adam_clip_step_gated")
+            return
         L.check(self.lib.fpv_adam_clip_step(_ptr(self.param.data), _ptr(g), _ptr(st["exp_avg"]), _ptr(st["exp_avg_sq"]),
                                             _ptr(st["step"]), _ptr(self.grad_norm), self.param.numel(), self.lr,
                                             self.betas[0], self.betas[1], self.eps, self.max_grad_norm,

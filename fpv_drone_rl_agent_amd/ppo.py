@@ -138,6 +138,12 @@ class PPO:
         self.num_timesteps = 0
         self.logger: dict[str, float] = _LazyLog()
         self._stats_host = self._stats_event = self._logstd_host = None    # pinned mirrors of the epoch statistics (fused update)
+        # target_kl's early stop decided on the device (fpv_ppo_kl_gate / fpv_adam_clip_step_gated): one rank, fused update
+        self._device_gate = (self.fused_update and target_kl is not None and D.world_size() == 1
+                             and os.environ.get("FPV_PPO_SYNC_LOG", "") in ("", "0")
+                             and os.environ.get("FPV_PPO_DEVICE_GATE", "1") != "0")      # (=0: the host decides, one wait per epoch; A/B)
+        self._gate = torch.zeros(2, dtype=torch.int32, device=collector.device) if self._device_gate else None
+        self._gate_host = torch.zeros(2, dtype=torch.int32).pin_memory() if self._device_gate else None
         self._gen = torch.Generator(device=collector.device)
         self._gen.manual_seed(1234 + D.rank())
 
@@ -180,8 +186,11 @@ class PPO:
                           vf_coef=self.vf_coef, ent_coef=self.ent_coef, stats=self._stats, workspace=self._ws,
                           storage=self.grad_storage, path=self.update_path)
         self._allreduce_grads()
-        self.opt.step(self._flat_grad)
-        if self.log_std_min is not None:
+        if self._device_gate:
+            self.opt.step(self._flat_grad, gate=self._gate)
+        else:
+            self.opt.step(self._flat_grad)
+        if self.log_std_min is not None:        # (idempotent: harmless behind a stopped update)
             self.policy.log_std.data.clamp_(min=self.log_std_min)
         return self._stats
 
@@ -193,13 +202,15 @@ class PPO:
         for k in range(self.n_minibatches):
             self._stats = self._epoch_stats[k]
             self._fused_minibatch(perm[k * mb:(k + 1) * mb])
+        if self._device_gate:                   # does this epoch count, and does it stop the ones queued behind it?
+            O.ppo_kl_gate(self._epoch_stats, 1.5 * self.target_kl, self._gate)
         return self._epoch_stats
 
-    def _draw_order(self, total: int, dev) -> torch.Tensor:
-        """The epoch's row order into the persistent index buffer (the epoch graph holds its address)."""
+    def _draw_order(self, total: int, dev, epoch: int) -> torch.Tensor:
+        """The epoch's row order into the persistent index buffer (the epoch graph holds its address).  The key of the order is
+        (update, epoch) — not a count of the orders drawn, which would depend on whether the epochs behind an early stop were queued."""
         if self.shuffle == "keyed":
-            self._shuffle_count += 1
-            O.shuffle_indices(self._perm, 1234 + D.rank(), self._shuffle_count)
+            O.shuffle_indices(self._perm, 1234 + D.rank(), self._shuffle_count * self.n_epochs + epoch + 1)
         else:
             torch.randperm(total, device=dev, generator=self._gen, out=self._perm)
         return self._perm
@@ -260,6 +271,7 @@ class PPO:
         graph = self.use_graph and not getattr(self, "_graph_failed", False) and not (
             D.world_size() > 1 and (td.get_backend() == "gloo" or os.environ.get("FPV_GRAPH_COLLECTIVES", "1") == "0"))
         if self.fused_update:
+            self._shuffle_count += 1            # (the number of this update: part of the epochs' shuffle keys)
             if self._adv_n is None or self._adv_n.numel() != total:
                 self._adv_n = torch.empty(total, dtype=torch.float32, device=dev)
             if self.normalize_advantage:        # the same two roundings as above, straight into the persistent buffer (two passes, not three)
@@ -299,9 +311,11 @@ class PPO:
                 self._stats_event = [torch.cuda.Event() for _ in range(self.n_epochs + 1)]
                 self._logstd_host = torch.zeros(self.policy.log_std.shape, dtype=torch.float32).pin_memory()
             self.logger._resolve()               # the previous update's numbers leave the pinned words before they are written again
+            if self._device_gate:
+                self._gate.zero_()
             ran = 0
             for epoch in range(self.n_epochs):
-                self._draw_order(total, dev)
+                self._draw_order(total, dev, epoch)
                 if graph:
                     self._mb_graph.replay()
                     st = self._g_out
@@ -310,17 +324,23 @@ class PPO:
                 self._stats_host[epoch].copy_(st, non_blocking=True)
                 self._stats_event[epoch].record()
                 ran = epoch + 1
-                if self.target_kl is not None and epoch + 1 < self.n_epochs:
+                # target_kl: with the device gate every epoch is queued at once — an epoch behind the stop computes its gradients and
+                # changes nothing (wasted only in updates that do stop) —; without it the decision about the next epoch waits here
+                if self.target_kl is not None and not self._device_gate and epoch + 1 < self.n_epochs:
                     self._stats_event[epoch].synchronize()
                     if float(self._stats_host[epoch][:, 2].mean()) > 1.5 * self.target_kl:
                         break
             self._logstd_host.copy_(self.policy.log_std.detach(), non_blocking=True)
+            if self._device_gate:
+                self._gate_host.copy_(self._gate, non_blocking=True)
             self._stats_event[self.n_epochs].record()
-            hosts, events, logstd, vf = self._stats_host[:ran], self._stats_event, self._logstd_host, self.vf_coef
+            hosts, events, logstd, vf = self._stats_host, self._stats_event, self._logstd_host, self.vf_coef
+            gate_host, n_last = self._gate_host, self.n_epochs
 
             def resolve():
-                events[self.n_epochs].synchronize()
-                m = torch.cat(hosts).mean(0).tolist()
+                events[n_last].synchronize()
+                counted = int(gate_host[1]) if gate_host is not None else ran
+                m = torch.cat(hosts[:counted]).mean(0).tolist()
                 return {"train/policy_gradient_loss": m[0], "train/value_loss": m[1], "train/approx_kl": m[2],
                         "train/clip_fraction": m[3], "train/loss": m[0] + vf * m[1], "train/std": float(torch.exp(logstd).mean())}
 
@@ -329,7 +349,7 @@ class PPO:
             return
         for epoch in range(self.n_epochs):
             if self.fused_update:               # the whole epoch is one graph replay on the order drawn into the persistent buffer
-                self._draw_order(total, dev)
+                self._draw_order(total, dev, epoch)
                 if graph:
                     self._mb_graph.replay()
                     st = self._g_out.clone()

@@ -31,8 +31,9 @@ extern "C" {
  * (FPV_DETECTOR_PIXEL = 0 is the default, debug hooks moved to fpv_env_debug.h); 3 = fpv_ledger_scan(status_out),
  * fpv_policy_io.scatter_*, the whole-rollout launch moved to fpv_env_experiments.h; 4 = round 4: fpv_ppo_io.reserved1 became
  * fpv_ppo_io.path (same layout; 0 now selects the one-kernel gradient), fpv_ppo_workspace_bytes covers every path; 5 = round 5:
- * fpv_ledger_pack and fpv_ledger_scan_finalize added (no layout changed); 6 = fpv_shuffle_indices added (no layout changed). */
-#define FPV_ABI_VERSION 6
+ * fpv_ledger_pack and fpv_ledger_scan_finalize added (no layout changed); 6 = fpv_shuffle_indices added (no layout changed);
+ * 7 = fpv_adam_clip_step_gated and fpv_ppo_kl_gate added, fpv_rollout_step serves fpv_policy_io.nets = 1 (no layout changed). */
+#define FPV_ABI_VERSION 7
 
 #define FPV_STATE_WORDS 36 /* docs/SPEC.md §2 canonical order */
 #define FPV_OBS_WORDS 20   /* simulation/hover.py:63-70 */
@@ -442,6 +443,16 @@ int fpv_ppo_grad(fpv_policy* pol, const fpv_ppo_io* io, void* stream);
 int fpv_adam_clip_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t* step,
                        float* grad_norm, int64_t n, float lr, float beta1, float beta2, float eps, float max_grad_norm,
                        void* stream);
+/* SB3 PPO.train's target_kl rule ("stop the update when approx_kl > 1.5 target_kl") without a host round trip per epoch: every epoch of
+ * an update is queued at once; `gate` (device int32[2], zeroed by the caller before the update: {stopped, epochs that counted}) is read
+ * by fpv_adam_clip_step_gated — a launch that finds gate[0] != 0 changes nothing: parameters, moments and step count stay as the last
+ * counted epoch left them — and written by fpv_ppo_kl_gate behind an epoch's minibatches: an epoch that started unstopped counts
+ * (gate[1] += 1), and sets gate[0] when the mean of its n_minibatches approx_kl values (epoch_stats[k][2], the statistics rows of
+ * fpv_ppo_io.stats) is above `limit` (= 1.5 target_kl).  The host reads gate[1] with the statistics, whenever it wants them. */
+int fpv_adam_clip_step_gated(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t* step,
+                             float* grad_norm, int64_t n, float lr, float beta1, float beta2, float eps, float max_grad_norm,
+                             const int32_t* gate, void* stream);
+int fpv_ppo_kl_gate(const float* epoch_stats, int32_t n_minibatches, float limit, int32_t* gate, void* stream);
 
 /* The row order of a PPO epoch (SB3 PPO.train draws np.random.permutation(buffer rows) per epoch — stable_baselines3's
  * RolloutBuffer.get, the learner SURVEY §8(f) N1 puts in place of train_hover.py:47-60's): out[i], i = 0..n-1, is a permutation of

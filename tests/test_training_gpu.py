@@ -36,7 +36,7 @@ def test_deferred_logging_gives_the_synchronising_loops_numbers(monkeypatch):
     from fpv_drone_rl_agent_amd.policy import ActorCritic
     from fpv_drone_rl_agent_amd.ppo import PPO
     from fpv_drone_rl_agent_amd.rollout import RolloutCollector
-    runs = []
+    runs, counted = [], []
     for sync in ("1", "0"):
         monkeypatch.setenv("FPV_PPO_SYNC_LOG", sync)
         torch.manual_seed(0)
@@ -48,11 +48,15 @@ def test_deferred_logging_gives_the_synchronising_loops_numbers(monkeypatch):
         for it in range(6):
             model.learn(16 * n * (it + 1))
             logs.append(dict(model.logger.items()))
+            if sync == "0":                     # (target_kl decided on the device: how many of the four queued epochs counted)
+                assert model._device_gate
+                counted.append(int(model._gate_host[1]))
         runs.append((logs, torch.cat([p.detach().flatten() for p in pol.parameters()]).clone()))
         eng.close()
     (la, pa), (lb, pb) = runs
     assert torch.equal(pa, pb)
     assert "rollout/ep_len_mean" in la[-1] and "train/std" in la[-1]
+    assert min(counted) < 4 and len(set(counted)) > 1, counted     # updates were cut short, at different epochs
     for a, b in zip(la, lb):
         assert a.keys() == b.keys() and len(a) >= 6
         for k in a:
