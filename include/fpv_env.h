@@ -384,7 +384,7 @@ int fpv_policy_set_gemm(fpv_policy* pol, int32_t mode);
  * writes its own, the caller alternates between two tables (io->merge_partials != extras->partials).
  * Results are bit-identical to fpv_policy_forward followed by fpv_step_fused.  Needs: an fp32 handle (hover or yaw task) with
  * noise_ratio > 0, num_envs a multiple of 256, the policy widths of the task (20 / 4, 12 / 1: fpv_policy_set_dims) in gemm
- * mode 0; FPV_ERR_UNSUPPORTED otherwise.  Rows of moment sums are 2 x obs_words + 4 doubles wide, as for fpv_step_fused. */
+ * mode 0 or 1 (rollout_step_kernel / rollout_step_split_kernel); FPV_ERR_UNSUPPORTED otherwise.  Rows of moment sums are 2 x obs_words + 4 doubles wide, as for fpv_step_fused. */
 int fpv_rollout_step(fpv_env* env, fpv_policy* pol, const fpv_policy_io* io, float* reward, uint8_t* terminated,
                      uint8_t* truncated, const fpv_step_extras* extras, void* stream);
 
