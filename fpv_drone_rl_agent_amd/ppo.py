@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import os
 import sys
+from collections.abc import MutableMapping
 
 import torch
 import torch.distributed as td
@@ -24,13 +25,15 @@ from . import ops as O
 from .rollout import RolloutCollector
 
 
-class _LazyLog(dict):
-    """model.logger: a dict whose update-time values may still be on their way from the device.  train_on() leaves the last epoch's
+class _LazyLog(MutableMapping):
+    """model.logger: a mapping whose update-time values may still be on their way from the device.  train_on() leaves the last epoch's
     statistics and the policy's log-std as asynchronous copies into pinned host words (so that the host can queue the next rollout
-    while the update still runs) and registers a resolver; any READ of the dict waits for them and fills the numbers in."""
+    while the update still runs) and registers a resolver; any READ of the mapping waits for them and fills the numbers in.  Not a
+    dict subclass on purpose: C-level readers of a dict (json.dumps, PyDict_Merge) would walk the storage behind the resolver's back —
+    here every access goes through these methods, and json.dumps(model.logger) fails loudly (use dict(model.logger))."""
 
     def __init__(self):
-        super().__init__()
+        self._d: dict[str, float] = {}
         self._pending = None
 
     def defer(self, resolver) -> None:
@@ -40,47 +43,37 @@ class _LazyLog(dict):
     def _resolve(self) -> None:
         if self._pending is not None:
             resolver, self._pending = self._pending, None
-            dict.update(self, resolver())
+            self._d.update(resolver())
+
+    def record(self, k, v) -> None:
+        """A write that does not wait for pending values (PPO.learn's episode statistics)."""
+        self._d[k] = v
 
     def __getitem__(self, k):
         self._resolve()
-        return dict.__getitem__(self, k)
+        return self._d[k]
 
-    def get(self, k, default=None):
-        self._resolve()
-        return dict.get(self, k, default)
+    def __setitem__(self, k, v):
+        self._d[k] = v
 
-    def __contains__(self, k):
+    def __delitem__(self, k):
         self._resolve()
-        return dict.__contains__(self, k)
+        del self._d[k]
 
     def __iter__(self):
         self._resolve()
-        return dict.__iter__(self)
+        return iter(self._d)
 
     def __len__(self):
         self._resolve()
-        return dict.__len__(self)
-
-    def keys(self):
-        self._resolve()
-        return dict.keys(self)
-
-    def values(self):
-        self._resolve()
-        return dict.values(self)
-
-    def items(self):
-        self._resolve()
-        return dict.items(self)
+        return len(self._d)
 
     def copy(self):
-        self._resolve()
         return dict(self)
 
     def __repr__(self):
         self._resolve()
-        return dict.__repr__(self)
+        return repr(self._d)
 
 
 class PPO:
@@ -398,8 +391,8 @@ class PPO:
             # front of them, where the device would idle until the host has woken up and queued the update)
             ep = self.col.episodes
             if ep["count"] > 0 and ep["ep_len_mean"] == ep["ep_len_mean"]:
-                dict.__setitem__(self.logger, "rollout/ep_len_mean", ep["ep_len_mean"])
-                dict.__setitem__(self.logger, "rollout/ep_rew_mean", ep["ep_rew_mean"])
+                self.logger.record("rollout/ep_len_mean", ep["ep_len_mean"])
+                self.logger.record("rollout/ep_rew_mean", ep["ep_rew_mean"])
             it += 1
             if callback is not None:
                 callback(self)
