@@ -823,10 +823,11 @@ __global__ __launch_bounds__(512) void rollout_step_split_kernel(RollStepSplitAr
     const uint64_t tick = p.st.tick[(int64_t)blockIdx.x * 4];       // this workgroup's own tile's copy (rollout_step_kernel)
     const SplitOut out{p.obs_n, p.action, p.clipped, p.value, p.logp, nullptr};
     f32x4 cl = f32x4{0.f, 0.f, 0.f, 0.f};
-    // Each net's whole image in front of the net.  Measured and not kept: pi's image requested before the statistics
-    // merge (+0.4 us per step), V's requested before pi's head arithmetic (same), and the image in two parts — W1 + biases first,
-    // layer 1 on it while W2 is on its way — (+1.8 us: two more workgroup barriers and 48 registers in flight cost more than the
-    // fetch they hide).
+    // Each net's whole image in front of the net.  With REGISTER staging (FPV_RSS_DMA_PI / _V = 0) these were measured and not kept
+    // (DESIGN §5b): pi's image requested before the statistics merge (+0.4 us per step), V's requested before pi's head arithmetic
+    // (same), and the image in two parts — W1 + biases first, layer 1 on it while W2 is on its way — (+1.8 us: two more workgroup
+    // barriers and 48 registers in flight cost more than the fetch they hide).  By LDS-DMA, which holds no registers, the first two
+    // are what the kernel does now (-0.5 us together).
     SplitHidden hd;
     {
         SplitStage<512> stage;
