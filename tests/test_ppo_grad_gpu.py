@@ -336,3 +336,44 @@ def test_shuffle_indices_mixes_the_buffer_layout():
     assert abs(lag1) < 5 / n ** 0.5, lag1
     pos = torch.arange(n, device=dev).double() / n - 0.5
     assert abs(float((x * pos).mean() / x.var())) < 5 / n ** 0.5
+
+
+def test_kl_gate_counts_epochs_and_a_gated_adam_changes_nothing():
+    """fpv_ppo_kl_gate / fpv_adam_clip_step_gated (SB3 PPO.train's target_kl rule decided on the device): an epoch that starts unstopped
+    counts and stops the ones behind it when its mean approx_kl is above the limit; behind the stop nothing counts and an Adam launch
+    leaves parameters, moments and step count as they are, bit for bit; an open gate is the ungated launch."""
+    from fpv_drone_rl_agent_amd import ops
+    from fpv_drone_rl_agent_amd.ops import FusedAdam
+    dev = "cuda"
+    gate = torch.zeros(2, dtype=torch.int32, device=dev)
+    stats = torch.zeros((8, 4), dtype=torch.float32, device=dev)
+    stats[:, 2] = torch.tensor([0.01, 0.02, 0.03, 0.0, 0.01, 0.02, 0.03, 0.04])        # mean 0.02
+    ops.ppo_kl_gate(stats, 0.03, gate)
+    assert gate.tolist() == [0, 1]                       # counted, below the limit
+    ops.ppo_kl_gate(stats, 0.019, gate)
+    assert gate.tolist() == [1, 2]                       # counted, and it stops what follows
+    ops.ppo_kl_gate(stats, 10.0, gate)
+    assert gate.tolist() == [1, 2]                       # behind the stop nothing counts
+    stats[:, 2] = 0.5
+    stats[:, 0] = 100.0                                  # (only column 2 is looked at)
+    g2 = torch.zeros(2, dtype=torch.int32, device=dev)
+    ops.ppo_kl_gate(stats[:2].contiguous(), 0.5, g2)
+    assert g2.tolist() == [0, 1]                         # strictly above, as SB3's comparison
+    torch.manual_seed(3)
+    p0 = torch.randn(39049, device=dev)
+    grad = torch.randn(39049, device=dev)
+    runs = []
+    for gated in (None, 0, 1):
+        par = torch.nn.Parameter(p0.clone())
+        opt = FusedAdam(par, lr=3e-4, eps=1e-5, max_grad_norm=0.5)
+        gt = None if gated is None else torch.tensor([gated, 0], dtype=torch.int32, device=dev)
+        for _ in range(3):
+            opt.step(grad, gate=gt)
+        st = opt.state[0]
+        runs.append((par.data.clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone(), int(st["step"])))
+    plain, open_, shut = runs
+    assert plain[3] == open_[3] == 3 and all(torch.equal(a, b) for a, b in zip(plain[:3], open_[:3]))
+    assert shut[3] == 0 and torch.equal(shut[0], p0) and not shut[1].any() and not shut[2].any()
+    assert not torch.equal(plain[0], p0)
+    with pytest.raises(ValueError):
+        ops.ppo_kl_gate(stats, 0.1, torch.zeros(2, dtype=torch.int64, device=dev))
